@@ -1,0 +1,313 @@
+"""Minibatch collator for the MI355X message-passing path.
+
+Replaces the per-element Python list appends of the reference's
+`GnnBugLabModel.initialize/extend/finalize_minibatch`
+(reference buglab/models/gnn.py:431-604) and of ptgnn's
+`GraphNeuralNetworkModel.*_minibatch` with NumPy array concatenation, and emits
+what the HIP kernels want instead of ptgnn's per-type `(int64[E_t], int64[E_t])`
+adjacency lists:
+
+  msg_src, msg_tgt : int32[E]   messages grouped TYPE-MAJOR, sorted by target inside a type
+  type_ptr         : int32[T+1] extent of each edge type in that order (the GEMM groups)
+  tgt_ptr/tgt_msgs : int32[N+1]/int32[E]  CSR node -> ids of its incoming messages (ascending)
+  src_ptr/src_msgs : int32[N+1]/int32[E]  CSR node -> ids of the messages it is the source of
+
+Target-sorted CSR turns the reference's atomic `scatter_max` (torch_scatter) into
+a segmented reduction: no atomics, deterministic, ties resolve to the lowest
+message id.  Everything is int32 (the reference ships int64) and all index
+arrays of a minibatch travel to the device in ONE pinned blob / ONE H2D copy
+(`to_device`), instead of ~15 `torch.tensor(list)` copies (gnn.py:549-604).
+
+The keys of the finished minibatch dict are the ones `GnnBugLabModule.forward`
+takes in the reference (gnn.py:144-167), so `nn(**minibatch)` is unchanged.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, NamedTuple, Optional, Sequence
+
+import numpy as np
+
+I32 = np.int32
+
+
+@dataclass
+class TensorizedGraphData:
+    """Per-graph arrays (the role of ptgnn's TensorizedGraphData; reference gnn.py:30,478)."""
+
+    token_ids: np.ndarray  # int32 [n, S]   subtoken ids, padded
+    token_lens: np.ndarray  # int32 [n]
+    adjacency_lists: List[np.ndarray]  # per presented edge type: int32 [E_t, 2] (src, tgt)
+    reference_nodes: Dict[str, np.ndarray] = field(default_factory=dict)
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.token_ids.shape[0])
+
+    @property
+    def num_messages(self) -> int:
+        return int(sum(a.shape[0] for a in self.adjacency_lists))
+
+
+class BaseTensorizedBugLabGnn(NamedTuple):
+    """Same fields as the reference's NamedTuple (gnn.py:29-52)."""
+
+    graph_data: TensorizedGraphData
+    target_location_node_idx: Optional[int]
+    target_rewrites: Sequence[int]
+    target_rewrite_to_location_group: Sequence[int]
+    correct_rewrite_target: Optional[int]
+    text_rewrite_original_idx: Sequence[int]
+    candidate_symbol_to_varmisused_node: Sequence[int]
+    correct_candidate_symbol_node: Optional[int]
+    candidate_rewrite_original_idx: Sequence[int]
+    swapped_pair_to_call: Sequence[int]
+    correct_swapped_pair: Optional[int]
+    pair_rewrite_original_idx: Sequence[int]
+    num_rewrite_locations_considered: int
+    rewrite_logprobs: Optional[Sequence[float]]
+
+
+REFERENCE_KEYS_1D = (
+    "candidate_nodes",
+    "target_rewrite_nodes",
+    "varmisused_node_ids",
+    "candidate_symbol_node_ids",
+    "call_node_ids",
+)
+REFERENCE_KEY_PAIRS = "candidate_swapped_node_ids"
+
+
+def _csr(keys: np.ndarray, n: int):
+    """CSR over `keys` (values in [0, n)): ptr int32[n+1], items int32[len(keys)] ascending inside a segment."""
+    items = np.argsort(keys, kind="stable").astype(I32)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    if keys.size:
+        np.cumsum(np.bincount(keys, minlength=n), out=ptr[1:])
+    return ptr.astype(I32), items
+
+
+def segments_from_index(index: np.ndarray, num_segments: int):
+    """CSR (ptr, items) for an arbitrary (unsorted) segment-id vector; used for the repair
+    log-softmax whose ids are the concatenation of three per-scout lists (gnn.py:296-298)."""
+    return _csr(np.asarray(index, dtype=np.int64), num_segments)
+
+
+def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -> Dict[str, Any]:
+    """Disjoint union of graphs -> one `graph_data` dict of NumPy arrays."""
+    B = len(graphs)
+    n_per_graph = np.array([g.num_nodes for g in graphs], dtype=np.int64)
+    node_off = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(n_per_graph, out=node_off[1:])
+    N = int(node_off[-1])
+
+    S = max((g.token_ids.shape[1] for g in graphs), default=1)
+    token_ids = np.zeros((N, S), dtype=I32)
+    token_lens = np.zeros(N, dtype=I32)
+    for g, o in zip(graphs, node_off[:-1]):
+        token_ids[o : o + g.num_nodes, : g.token_ids.shape[1]] = g.token_ids
+        token_lens[o : o + g.num_nodes] = g.token_lens
+
+    srcs, tgts = [], []
+    type_ptr = np.zeros(num_edge_types + 1, dtype=np.int64)
+    for t in range(num_edge_types):
+        parts = [g.adjacency_lists[t].astype(np.int64) + o for g, o in zip(graphs, node_off[:-1]) if t < len(g.adjacency_lists) and g.adjacency_lists[t].shape[0]]
+        if parts:
+            adj = np.concatenate(parts, axis=0)
+            order = np.argsort(adj[:, 1], kind="stable")  # target-sorted inside the type
+            adj = adj[order]
+            srcs.append(adj[:, 0])
+            tgts.append(adj[:, 1])
+            type_ptr[t + 1] = type_ptr[t] + adj.shape[0]
+        else:
+            type_ptr[t + 1] = type_ptr[t]
+    msg_src = np.concatenate(srcs).astype(I32) if srcs else np.zeros(0, dtype=I32)
+    msg_tgt = np.concatenate(tgts).astype(I32) if tgts else np.zeros(0, dtype=I32)
+    tgt_ptr, tgt_msgs = _csr(msg_tgt.astype(np.int64), N)
+    src_ptr, src_msgs = _csr(msg_src.astype(np.int64), N)
+
+    ref_ids: Dict[str, np.ndarray] = {}
+    ref_graph: Dict[str, np.ndarray] = {}
+    for key in REFERENCE_KEYS_1D:
+        ids, gidx = [], []
+        for b, (g, o) in enumerate(zip(graphs, node_off[:-1])):
+            r = np.asarray(g.reference_nodes.get(key, ()), dtype=np.int64).reshape(-1)
+            ids.append(r + o)
+            gidx.append(np.full(r.shape[0], b, dtype=np.int64))
+        ref_ids[key] = np.concatenate(ids).astype(I32) if ids else np.zeros(0, I32)
+        ref_graph[key] = np.concatenate(gidx).astype(I32) if gidx else np.zeros(0, I32)
+    pairs, pair_g = [], []
+    for b, (g, o) in enumerate(zip(graphs, node_off[:-1])):
+        r = np.asarray(g.reference_nodes.get(REFERENCE_KEY_PAIRS, np.zeros((0, 2))), dtype=np.int64).reshape(-1, 2)
+        pairs.append(r + o)
+        pair_g.append(np.full(r.shape[0], b, dtype=np.int64))
+    ref_ids[REFERENCE_KEY_PAIRS] = (np.concatenate(pairs, axis=0) if pairs else np.zeros((0, 2))).astype(I32)
+    ref_graph[REFERENCE_KEY_PAIRS] = (np.concatenate(pair_g) if pair_g else np.zeros(0)).astype(I32)
+
+    node_to_graph = np.repeat(np.arange(B, dtype=I32), n_per_graph)
+    cand_graph = ref_graph["candidate_nodes"]
+    cand_ptr = np.zeros(B + 1, dtype=np.int64)
+    if cand_graph.size:
+        np.cumsum(np.bincount(cand_graph, minlength=B), out=cand_ptr[1:])
+    return {
+        "token_ids": token_ids,
+        "token_lens": token_lens,
+        "msg_src": msg_src,
+        "msg_tgt": msg_tgt,
+        "type_ptr": type_ptr.astype(I32),
+        "tgt_ptr": tgt_ptr,
+        "tgt_msgs": tgt_msgs,
+        "src_ptr": src_ptr,
+        "src_msgs": src_msgs,
+        "node_to_graph": node_to_graph,
+        "num_nodes_per_graph": n_per_graph.astype(I32),
+        "num_graphs": B,
+        "candidate_ptr": cand_ptr.astype(I32),
+        "reference_node_ids": ref_ids,
+        "reference_node_graph_idx": ref_graph,
+    }
+
+
+def collate_samples(samples: Sequence[BaseTensorizedBugLabGnn], num_edge_types: int) -> Dict[str, Any]:
+    """B tensorized samples -> the minibatch dict (NumPy).  Offsets follow reference
+    gnn.py:463-542 (`extend_minibatch_with`) exactly; only the mechanism (array ops) differs."""
+    gd = collate_graphs([s.graph_data for s in samples], num_edge_types)
+    B = len(samples)
+    has_bug = np.zeros(B, dtype=np.bool_)
+    correct_cand = np.zeros(B, dtype=I32)
+    n_cand = np.array([len(s.graph_data.reference_nodes["candidate_nodes"]) for s in samples], dtype=np.int64)
+    cand_off = np.concatenate([[0], np.cumsum(n_cand)])
+    n_text = np.array([len(s.target_rewrites) for s in samples], dtype=np.int64)
+    n_var = np.array([len(s.candidate_symbol_to_varmisused_node) for s in samples], dtype=np.int64)
+    n_pair = np.array([len(s.swapped_pair_to_call) for s in samples], dtype=np.int64)
+    n_groups = np.array([s.num_rewrite_locations_considered for s in samples], dtype=np.int64)
+    text_off = np.concatenate([[0], np.cumsum(n_text)])
+    var_off = np.concatenate([[0], np.cumsum(n_var)])
+    pair_off = np.concatenate([[0], np.cumsum(n_pair)])
+    group_off = np.concatenate([[0], np.cumsum(n_groups)])
+    n_rw = n_text + n_var + n_pair
+    rw_off = np.concatenate([[0], np.cumsum(n_rw)])
+
+    def cat(parts, dtype=I32):
+        parts = [np.asarray(p, dtype=np.int64).reshape(-1) for p in parts]
+        return (np.concatenate(parts) if parts else np.zeros(0)).astype(dtype)
+
+    correct_rewrite, correct_symbol, correct_pair = [], [], []
+    for b, s in enumerate(samples):
+        if s.target_location_node_idx is not None:
+            has_bug[b] = True
+            correct_cand[b] = s.target_location_node_idx + cand_off[b]  # gnn.py:473-476
+        if s.correct_rewrite_target is not None:
+            correct_rewrite.append(s.correct_rewrite_target + text_off[b])  # :485-488
+        if s.correct_candidate_symbol_node is not None:
+            correct_symbol.append(s.correct_candidate_symbol_node + var_off[b])  # :499-503
+        if s.correct_swapped_pair is not None:
+            correct_pair.append(s.correct_swapped_pair + pair_off[b])  # :513-517
+    mb: Dict[str, Any] = {
+        "graph_data": gd,
+        "has_bug": has_bug,
+        "correct_candidate_node_idxs": correct_cand,
+        "target_rewrites": cat([s.target_rewrites for s in samples]),
+        "rewrite_to_location_group": cat([np.asarray(s.target_rewrite_to_location_group, np.int64) + group_off[b] for b, s in enumerate(samples)]),
+        "correct_rewrite_idxs": cat([correct_rewrite]),
+        "text_rewrite_idxs": cat([np.asarray(s.text_rewrite_original_idx, np.int64) + rw_off[b] for b, s in enumerate(samples)]),
+        "candidate_symbol_to_location_group": cat([np.asarray(s.candidate_symbol_to_varmisused_node, np.int64) + group_off[b] for b, s in enumerate(samples)]),
+        "correct_candidate_symbols": cat([correct_symbol]),
+        "candidate_rewrite_idxs": cat([np.asarray(s.candidate_rewrite_original_idx, np.int64) + rw_off[b] for b, s in enumerate(samples)]),
+        "swapped_pair_to_call_location_group": cat([np.asarray(s.swapped_pair_to_call, np.int64) + group_off[b] for b, s in enumerate(samples)]),
+        "correct_swapped_pair": cat([correct_pair]),
+        "pair_rewrite_idxs": cat([np.asarray(s.pair_rewrite_original_idx, np.int64) + rw_off[b] for b, s in enumerate(samples)]),
+        "rewrite_to_graph_id": np.repeat(np.arange(B, dtype=I32), n_rw),
+        # visualisation info kept as python lists (gnn.py:527-530)
+        "text_rewrite_original_idxs": [list(s.text_rewrite_original_idx) for s in samples],
+        "candidate_rewrite_original_idxs": [list(s.candidate_rewrite_original_idx) for s in samples],
+        "pair_rewrite_original_idx": [list(s.pair_rewrite_original_idx) for s in samples],
+        "num_repair_groups": int(group_off[-1]),
+    }
+    # one CSR for the single repair log-softmax over location groups (gnn.py:295-299)
+    groups = np.concatenate(
+        [mb["rewrite_to_location_group"], mb["candidate_symbol_to_location_group"], mb["swapped_pair_to_call_location_group"]]
+    )
+    mb["repair_group_ptr"], mb["repair_group_items"] = segments_from_index(groups, mb["num_repair_groups"])
+    if any(s.rewrite_logprobs is not None for s in samples):  # gnn.py:536-540, 598-603
+        lp = [np.asarray(s.rewrite_logprobs[:-1], dtype=np.float32) for s in samples if s.rewrite_logprobs is not None]
+        nb = [np.float32(s.rewrite_logprobs[-1]) for s in samples if s.rewrite_logprobs is not None]
+        mb["rewrite_logprobs"] = np.concatenate(lp + [np.asarray(nb, dtype=np.float32)])
+    return mb
+
+
+_INT_KEYS_MB = (
+    "correct_candidate_node_idxs",
+    "target_rewrites",
+    "rewrite_to_location_group",
+    "correct_rewrite_idxs",
+    "text_rewrite_idxs",
+    "candidate_symbol_to_location_group",
+    "correct_candidate_symbols",
+    "candidate_rewrite_idxs",
+    "swapped_pair_to_call_location_group",
+    "correct_swapped_pair",
+    "pair_rewrite_idxs",
+    "rewrite_to_graph_id",
+    "repair_group_ptr",
+    "repair_group_items",
+)
+_INT_KEYS_GD = ("token_ids", "token_lens", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
+
+
+def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
+    """NumPy minibatch -> torch tensors on `device` with ONE host->device copy for all int32 arrays.
+
+    Host-side copies that kernels' launch geometry needs (`type_ptr_host`, counts) stay as
+    Python/NumPy values so no device->host sync is ever needed to size a grid."""
+    import torch
+
+    gd = mb["graph_data"]
+    arrays = []
+    for k in _INT_KEYS_GD:
+        arrays.append(("gd", k, np.ascontiguousarray(gd[k], dtype=I32)))
+    for k, v in gd["reference_node_ids"].items():
+        arrays.append(("ref", k, np.ascontiguousarray(v, dtype=I32)))
+    for k, v in gd["reference_node_graph_idx"].items():
+        arrays.append(("refg", k, np.ascontiguousarray(v, dtype=I32)))
+    for k in _INT_KEYS_MB:
+        arrays.append(("mb", k, np.ascontiguousarray(mb[k], dtype=I32)))
+    arrays.append(("mb", "has_bug", np.ascontiguousarray(mb["has_bug"], dtype=I32)))
+    # 16-byte align every array inside the blob
+    offs, total = [], 0
+    for _, _, a in arrays:
+        offs.append(total)
+        total += (a.size + 3) // 4 * 4
+    blob = torch.empty(max(total, 4), dtype=torch.int32)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        blob = blob.pin_memory()
+    bnp = blob.numpy()
+    for (_, _, a), o in zip(arrays, offs):
+        bnp[o : o + a.size] = a.reshape(-1)
+    dblob = blob.to(dev, non_blocking=True)
+    out_gd: Dict[str, Any] = {"reference_node_ids": {}, "reference_node_graph_idx": {}}
+    out: Dict[str, Any] = {"graph_data": out_gd}
+    for (where, k, a), o in zip(arrays, offs):
+        t = dblob[o : o + a.size].view(a.shape)
+        if where == "gd":
+            out_gd[k] = t
+        elif where == "ref":
+            out_gd["reference_node_ids"][k] = t
+        elif where == "refg":
+            out_gd["reference_node_graph_idx"][k] = t
+        else:
+            out[k] = t
+    out["has_bug"] = out["has_bug"].bool()
+    out_gd["num_graphs"] = int(gd["num_graphs"])
+    out_gd["num_nodes"] = int(gd["token_ids"].shape[0])
+    out_gd["num_messages"] = int(gd["msg_src"].shape[0])
+    out_gd["type_ptr_host"] = np.asarray(gd["type_ptr"], dtype=np.int64)
+    out_gd["num_nodes_per_graph"] = np.asarray(gd["num_nodes_per_graph"])
+    out_gd["_blob"] = dblob  # keeps the single allocation alive
+    out["num_repair_groups"] = int(mb["num_repair_groups"])
+    for k in ("text_rewrite_original_idxs", "candidate_rewrite_original_idxs", "pair_rewrite_original_idx"):
+        out[k] = mb[k]
+    if "rewrite_logprobs" in mb:
+        out["rewrite_logprobs"] = torch.from_numpy(np.asarray(mb["rewrite_logprobs"], dtype=np.float32)).to(dev)
+    return out

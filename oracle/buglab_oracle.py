@@ -1,0 +1,451 @@
+"""CPU oracle for the BugLab `gnn-mlp` hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this file.  The product path (`buglab.models.*` under
+`neurips21-self-supervised-bug-detection-and-repair_amd/`) never imports it and
+fails loudly when the HIP extension is missing.
+
+PARITY STATUS
+-------------
+* Scoring heads, segment ops and loss assembly (sections H1-H8 below) restate
+  code that IS in the reference tree and are PINNED: `tests/golden/make_golden.py`
+  imports the reference's own `buglab/models/layers/*.py` + `buglab/models/utils.py`
+  (with a tiny stand-in for the absent `torch_scatter` / `ptgnn` imports), runs
+  them on seeded inputs and commits the outputs under `tests/golden/`;
+  `tests/test_oracle_golden.py` checks this file against those vectors.
+* Message-passing layers, node embedder and GNN stack (sections M0-M5):
+  **parity unpinned**.  Their arithmetic lives in the third-party package
+  `ptgnn` (bare, un-versioned name in reference `requirements.txt:13`), which is
+  neither vendored in /root/reference nor installable offline, and no reference
+  test holds a vector for it.  The choices ptgnn leaves unverifiable are frozen
+  here as an explicit written spec (see `MpSpec` and DESIGN.md section 2); the
+  stack recipe itself follows reference `buglab/models/gnnlayerdefs.py:5-39`.
+
+Everything is plain PyTorch on CPU (fp32 by default, fp64 for error budgeting)
+so autograd provides the backward oracle.  No fused tricks, no caching.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+# ----------------------------------------------------------------------------
+# Counter-based dropout mask (shared spec with csrc/bl_common.h: bl_keep()).
+# The reference uses torch's stateful Philox dropout (nn.Dropout inside ptgnn);
+# a stateless counter hash is used instead so that forward, backward and this
+# oracle regenerate the identical mask from (seed, stream, element index).
+# ----------------------------------------------------------------------------
+_M32 = 0xFFFFFFFF
+
+
+def _lowbias32_np(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64) & _M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & _M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def dropout_keep_mask(seed: int, stream: int, numel: int, p: float) -> np.ndarray:
+    """keep[i] for flat row-major element index i.  p in [0, 1)."""
+    key = _lowbias32_np(np.array([(seed & _M32) ^ ((stream * 0x9E3779B9) & _M32)], dtype=np.uint64))[0]
+    idx = np.arange(numel, dtype=np.uint64)
+    h = _lowbias32_np((idx + key) & _M32)
+    thresh = np.uint64(int(p * 16777216.0))
+    return (h >> np.uint64(8)) >= thresh
+
+
+def apply_dropout(x: torch.Tensor, p: float, seed: Optional[int], stream: int) -> torch.Tensor:
+    if seed is None or p <= 0.0:
+        return x
+    keep = torch.from_numpy(dropout_keep_mask(seed, stream, x.numel(), p)).view(x.shape)
+    return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+
+
+# ----------------------------------------------------------------------------
+# Layer-stack recipe (reference buglab/models/gnnlayerdefs.py:5-39)
+# ----------------------------------------------------------------------------
+@dataclass
+class MpSpec:
+    """Frozen spec of ptgnn's MlpMessagePassingLayer as this repo defines it.
+
+    message     m_e = act_msg( [h_src(e) ; h_tgt(e)] @ W[type(e)] )      W: [T, 2*Din, Dm], no bias
+    aggregate   a_v = max_{e -> v} m_e  (per channel); empty segment -> 0; ties -> lowest message index
+    update      h'_v = Dropout( tanh( LayerNorm(a_v; eps 1e-5) @ Wd + bd ) )
+    Kwargs pinned by the reference call site (gnnlayerdefs.py:6-23): input/message/output
+    dimension, num_edge_types, aggregation "max", dropout_rate.  Everything else above is the
+    un-pinned part (see module docstring).
+    """
+
+    din: int
+    dm: int
+    dout: int
+    msg_act: str = "gelu"  # "gelu" (exact erf form) or "none"
+
+
+def gnn_mlp_stack(hidden: int, num_layers: int = 8) -> List[Tuple]:
+    """gnnlayerdefs.py:26-39: per block of 4 MP layers: stash, 3x(H,H,H), concat, 1x(2H,2H,H)."""
+    assert num_layers % 4 == 0 and num_layers >= 4
+    ops: List[Tuple] = []
+    li = 0
+    for blk in range(num_layers // 4):
+        ops.append(("stash", blk))
+        for _ in range(3):
+            ops.append(("mp", li, hidden, hidden, hidden))
+            li += 1
+        ops.append(("concat", blk))
+        ops.append(("mp", li, 2 * hidden, 2 * hidden, hidden))
+        li += 1
+    return ops
+
+
+@dataclass
+class OracleConfig:
+    hidden: int = 128
+    num_layers: int = 8
+    num_edge_types: int = 16
+    vocab_size: int = 15000
+    max_subtokens: int = 6
+    rewrite_vocab_size: int = 48
+    dropout: float = 0.0
+    msg_act: str = "gelu"
+    buggy_samples_weight: float = 1.0
+
+
+# ----------------------------------------------------------------------------
+# Parameter construction (names shared with the product's state_dict)
+# ----------------------------------------------------------------------------
+def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    H = cfg.hidden
+
+    def uni(shape, bound):
+        return (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1).mul_(bound).to(dtype)
+
+    p: Dict[str, torch.Tensor] = {}
+    p["embed.table"] = torch.randn((cfg.vocab_size, H), generator=g, dtype=torch.float64).to(dtype)
+    for op in gnn_mlp_stack(H, cfg.num_layers):
+        if op[0] != "mp":
+            continue
+        _, li, din, dm, dout = op
+        # each W[t] initialised like nn.Linear(2*din, dm, bias=False): U(-1/sqrt(fan_in), +)
+        p[f"mp.{li}.W"] = uni((cfg.num_edge_types, 2 * din, dm), 1.0 / math.sqrt(2 * din))
+        p[f"mp.{li}.ln_g"] = torch.ones(dm, dtype=dtype)
+        p[f"mp.{li}.ln_b"] = torch.zeros(dm, dtype=dtype)
+        p[f"mp.{li}.Wd"] = uni((dm, dout), math.sqrt(6.0 / (dm + dout)))  # xavier uniform
+        p[f"mp.{li}.bd"] = uni((dout,), 1.0 / math.sqrt(dm))
+
+    b = 1.0 / math.sqrt(H)
+    p["loc.Ws"] = uni((H, H), b)
+    p["loc.bs"] = uni((H,), b)
+    p["loc.W1"] = uni((2 * H, H), 1.0 / math.sqrt(2 * H))
+    p["loc.b1"] = uni((H,), 1.0 / math.sqrt(2 * H))
+    p["loc.w"] = uni((H,), b)
+    p["text.emb"] = torch.randn((cfg.rewrite_vocab_size, H), generator=g, dtype=torch.float64).to(dtype)
+    for name, k in (("text", 2), ("var", 2), ("swap", 3)):
+        p[f"{name}.W1"] = uni((k * H, H), 1.0 / math.sqrt(k * H))
+        p[f"{name}.b1"] = uni((H,), 1.0 / math.sqrt(k * H))
+        p[f"{name}.w2"] = uni((H,), b)
+        p[f"{name}.b2"] = uni((1,), b)
+    return p
+
+
+# ----------------------------------------------------------------------------
+# Segment ops (reference buglab/models/utils.py:15-48; torch_scatter semantics)
+# ----------------------------------------------------------------------------
+def scatter_max_with_arg(src: torch.Tensor, index: torch.Tensor, dim_size: int):
+    """torch_scatter.scatter_max(src, index, dim=0, dim_size) restated.
+
+    Returns (values [dim_size, ...], arg [dim_size, ...]).  Empty segments: value 0 and
+    arg == src.shape[0] (torch_scatter's sentinel).  Ties: lowest source row (the CPU
+    implementation of torch_scatter scans rows in order and replaces only on strict '>').
+    Gradient flows only to the arg row (torch_scatter backward = gather of grad at arg).
+    """
+    E = src.shape[0]
+    flat = src.reshape(E, -1)
+    D = flat.shape[1]
+    idx = index.view(E, 1).expand(E, D)
+    with torch.no_grad():
+        vmax = torch.full((dim_size, D), -math.inf, dtype=src.dtype)
+        vmax = vmax.scatter_reduce(0, idx, flat, reduce="amax", include_self=True)
+        is_max = flat == vmax.gather(0, idx)
+        rows = torch.arange(E, dtype=torch.int64).view(E, 1).expand(E, D)
+        cand = torch.where(is_max, rows, torch.full_like(rows, E))
+        arg = torch.full((dim_size, D), E, dtype=torch.int64)
+        arg = arg.scatter_reduce(0, idx, cand, reduce="amin", include_self=True)
+        empty = arg == E
+    if E == 0:
+        out = torch.zeros((dim_size, D), dtype=src.dtype)
+    else:
+        out = flat.gather(0, arg.clamp(max=E - 1))
+        out = torch.where(empty, torch.zeros_like(out), out)
+    shape = (dim_size,) + tuple(src.shape[1:])
+    return out.view(shape), arg.view(shape)
+
+
+def scatter_log_softmax(src: torch.Tensor, index: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """reference utils.py:15-28, statement for statement (1-D src)."""
+    num_groups = int(index.max()) + 1 if index.numel() > 0 else 0
+    max_value_per_index = scatter_max_with_arg(src.detach(), index, num_groups)[0]  # :20 (no grad through max: it cancels)
+    max_per_src_element = max_value_per_index.gather(0, index)  # :21
+    recentered_scores = src - max_per_src_element  # :23
+    sum_per_index = torch.zeros_like(max_value_per_index).scatter_add(0, index, recentered_scores.exp())  # :25
+    normalizing_constants = (sum_per_index + eps).log().gather(0, index)  # :26
+    return recentered_scores - normalizing_constants  # :28
+
+
+# ----------------------------------------------------------------------------
+# M0  node embedder  (ptgnn StrElementRepresentationModel, configured at
+#     reference modelregistry.py:59-82: subtoken splitting, <=6 subtokens, "max")
+# ----------------------------------------------------------------------------
+def embed_nodes(table, token_ids, token_lens, p_drop, seed):
+    ids = torch.as_tensor(token_ids, dtype=torch.int64)
+    lens = torch.as_tensor(token_lens, dtype=torch.int64).clamp(min=1)
+    emb = table[ids]  # [N, S, H]
+    S = ids.shape[1]
+    pad = torch.arange(S).view(1, S) >= lens.view(-1, 1)
+    emb = emb.masked_fill(pad.unsqueeze(-1), -math.inf)
+    h = emb.max(dim=1).values
+    return apply_dropout(h, p_drop, seed, stream=0)
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+# ----------------------------------------------------------------------------
+# M1-M3  one MlpMessagePassingLayer (spec: MpSpec)
+# ----------------------------------------------------------------------------
+def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_drop, seed, stream, trace=None):
+    N = h.shape[0]
+    src = torch.as_tensor(msg_src, dtype=torch.int64)
+    tgt = torch.as_tensor(msg_tgt, dtype=torch.int64)
+    msgs = []
+    for t in range(W.shape[0]):
+        lo, hi = int(type_ptr[t]), int(type_ptr[t + 1])
+        a = torch.cat([h[src[lo:hi]], h[tgt[lo:hi]]], dim=-1)  # [E_t, 2*Din]
+        msgs.append(a @ W[t])
+    pre = torch.cat(msgs, dim=0) if msgs else h.new_zeros((0, W.shape[2]))
+    m = _gelu(pre) if msg_act == "gelu" else pre
+    agg, arg = scatter_max_with_arg(m, tgt, N)
+    ln = torch.nn.functional.layer_norm(agg, (agg.shape[1],), ln_g, ln_b, eps=1e-5)
+    out = torch.tanh(ln @ Wd + bd)
+    out = apply_dropout(out, p_drop, seed, stream)
+    if trace is not None:
+        trace.append({"pre": pre, "agg": agg, "arg": arg, "ln": ln, "out": out})
+    return out
+
+
+# ----------------------------------------------------------------------------
+# M4-M5  GNN stack (gnnlayerdefs.py:26-39; ConcatResidualLayer = [stash ; current])
+# ----------------------------------------------------------------------------
+def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None):
+    h = embed_nodes(params["embed.table"], gd["token_ids"], gd["token_lens"], cfg.dropout, seed)
+    if trace is not None:
+        trace.append({"embed": h})
+    stash = {}
+    for op in gnn_mlp_stack(cfg.hidden, cfg.num_layers):
+        if op[0] == "stash":
+            stash[op[1]] = h
+        elif op[0] == "concat":
+            h = torch.cat([stash[op[1]], h], dim=-1)
+        else:
+            li = op[1]
+            h = mp_layer(
+                h,
+                params[f"mp.{li}.W"],
+                params[f"mp.{li}.ln_g"],
+                params[f"mp.{li}.ln_b"],
+                params[f"mp.{li}.Wd"],
+                params[f"mp.{li}.bd"],
+                gd["msg_src"],
+                gd["msg_tgt"],
+                gd["type_ptr"],
+                cfg.msg_act,
+                cfg.dropout,
+                seed,
+                stream=1 + li,
+                trace=trace,
+            )
+    return h
+
+
+# ----------------------------------------------------------------------------
+# H1  LocalizationModule.compute_localization_logprobs (localizationmodule.py:54-79)
+# ----------------------------------------------------------------------------
+def localization_logprobs(params, cand_reprs, cand_to_graph, num_graphs):
+    idx = torch.as_tensor(cand_to_graph, dtype=torch.int64)
+    s = cand_reprs @ params["loc.Ws"] + params["loc.bs"]
+    pooled = scatter_max_with_arg(s, idx, num_graphs)[0][idx]  # :56-58
+    l1 = torch.sigmoid(torch.cat([cand_reprs, pooled], dim=-1) @ params["loc.W1"] + params["loc.b1"])  # :59
+    scores = l1 @ params["loc.w"]  # :60  (Linear(H,1,bias=False)).squeeze(-1)
+    arange = torch.arange(num_graphs, dtype=torch.int64)
+    all_scores = torch.cat([scores, torch.ones(num_graphs, dtype=scores.dtype)])  # :63-68 constant NO_BUG logit 1.0
+    all_idx = torch.cat([idx, arange])  # :69-71
+    return all_idx, scatter_log_softmax(all_scores, all_idx), arange  # :72-77
+
+
+# ----------------------------------------------------------------------------
+# H2  LocalizationModule.forward (localizationmodule.py:81-124)
+# ----------------------------------------------------------------------------
+def localization_loss(params, cand_reprs, cand_to_graph, has_bug, correct_candidate_idxs, buggy_weight=1.0):
+    has_bug = torch.as_tensor(has_bug, dtype=torch.bool)
+    B = has_bug.shape[0]
+    all_idx, logprobs, arange = localization_logprobs(params, cand_reprs, cand_to_graph, B)
+    correct = torch.where(has_bug, torch.as_tensor(correct_candidate_idxs, dtype=torch.int64), arange + cand_reprs.shape[0])
+    lp = logprobs[correct].clamp(max=math.log(0.995))  # :92-93
+    if buggy_weight == 1.0:
+        loss = -lp.mean()  # :116-117
+    else:
+        w = torch.where(has_bug, torch.full_like(lp, buggy_weight), torch.ones_like(lp))  # :119-123
+        loss = -(lp * w).sum() / w.sum()
+    with torch.no_grad():
+        pred = scatter_max_with_arg(logprobs, all_idx, B)[1]  # :104-106
+        num_correct = int((pred == correct).sum())
+    return loss, logprobs, {"num_correct": num_correct, "loc_nll_sum": float(-lp.detach().sum())}
+
+
+# ----------------------------------------------------------------------------
+# H3-H5  repair scorers (fixermodules.py:31-39, 65-73, 110-124; mlp.py:6-20)
+#        MLP(k*H -> H -> 1) with ReLU.  H5 uses pair_representations.shape[-1]
+#        instead of the reference's never-assigned `self._input_dim`
+#        (fixermodules.py:120) -- documented deviation, SURVEY section 0.
+# ----------------------------------------------------------------------------
+def _mlp_score(params, name, x):
+    hid = torch.relu(x @ params[f"{name}.W1"] + params[f"{name}.b1"])
+    return hid @ params[f"{name}.w2"] + params[f"{name}.b2"]
+
+
+def text_rewrite_logits(params, node_reprs, rewrite_ids):
+    emb = params["text.emb"][torch.as_tensor(rewrite_ids, dtype=torch.int64)]
+    return _mlp_score(params, "text", torch.cat([emb, node_reprs], dim=-1))  # :36-39 (embedding first)
+
+
+def varmisuse_logits(params, slot_reprs, cand_reprs):
+    return _mlp_score(params, "var", torch.cat([slot_reprs, cand_reprs], dim=-1))  # :71-73
+
+
+def argswap_logits(params, call_reprs, pair_reprs):
+    flat = pair_reprs.reshape(pair_reprs.shape[0], 2 * pair_reprs.shape[-1])
+    return _mlp_score(params, "swap", torch.cat([call_reprs, flat], dim=-1))  # :116-124
+
+
+# ----------------------------------------------------------------------------
+# H6  GnnBugLabModule._compute_repair_logprobs (gnn.py:253-322)
+# ----------------------------------------------------------------------------
+def repair_logprobs(params, h, refs, target_rewrites, rewrite_to_group, symbol_to_group, pair_to_group):
+    L = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
+    tr = L(refs["target_rewrite_nodes"])
+    if tr.shape[0] > 0:
+        text_logits = text_rewrite_logits(params, h[tr], target_rewrites)  # :261-267
+    else:
+        text_logits = h.new_zeros(0)  # :268-269
+    vm = L(refs["varmisused_node_ids"])
+    if vm.shape[0] > 0:
+        var_logits = varmisuse_logits(params, h[vm], h[L(refs["candidate_symbol_node_ids"])])  # :271-280
+    else:
+        var_logits = h.new_zeros(0)
+    cn = L(refs["call_node_ids"])
+    if cn.shape[0] > 0:
+        sw = L(refs["candidate_swapped_node_ids"]).view(-1, 2)
+        swap_logits = argswap_logits(params, h[cn], h[sw])  # :284-292
+    else:
+        swap_logits = h.new_zeros(0)
+    all_logits = torch.cat([text_logits, var_logits, swap_logits])  # :295
+    groups = torch.cat([L(rewrite_to_group), L(symbol_to_group), L(pair_to_group)])  # :296-298
+    logprobs = scatter_log_softmax(all_logits, groups) if all_logits.numel() else all_logits  # :299
+    sizes = [text_logits.shape[0], var_logits.shape[0], swap_logits.shape[0]]
+    text_lp, var_lp, swap_lp = torch.split(logprobs, sizes)  # :300-302
+    with torch.no_grad():  # :304-311
+        if all_logits.numel():
+            ng = int(groups.max()) + 1
+            mx = scatter_max_with_arg(all_logits, groups, ng)[0].gather(0, groups)
+            sel = mx == all_logits
+        else:
+            sel = torch.zeros(0, dtype=torch.bool)
+        text_sel, var_sel, swap_sel = torch.split(sel, sizes)
+    return swap_lp, text_lp, var_lp, (swap_sel, text_sel, var_sel), all_logits
+
+
+# ----------------------------------------------------------------------------
+# H8  GnnBugLabModule.forward, detector branch (gnn.py:168-187, 221-251)
+# ----------------------------------------------------------------------------
+def forward_loss(params, mb, cfg: OracleConfig, seed=None, trace=None):
+    gd = mb["graph_data"]
+    L = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
+    h = gnn_forward(params, gd, cfg, seed=seed, trace=trace)
+    refs = gd["reference_node_ids"]
+    cand_reprs = h[L(refs["candidate_nodes"])]  # :170-172
+    swap_lp, text_lp, var_lp, sel, all_logits = repair_logprobs(
+        params,
+        h,
+        refs,
+        mb["target_rewrites"],
+        mb["rewrite_to_location_group"],
+        mb["candidate_symbol_to_location_group"],
+        mb["swapped_pair_to_call_location_group"],
+    )
+    loc_loss, loc_logprobs, loc_stats = localization_loss(
+        params,
+        cand_reprs,
+        gd["reference_node_graph_idx"]["candidate_nodes"],
+        mb["has_bug"],
+        mb["correct_candidate_node_idxs"],
+        cfg.buggy_samples_weight,
+    )
+    text_loss = -text_lp[L(mb["correct_rewrite_idxs"])]  # fixermodules.py:53
+    var_loss = -var_lp[L(mb["correct_candidate_symbols"])]  # :98
+    swap_loss = -swap_lp[L(mb["correct_swapped_pair"])]  # :147
+    repair = (text_loss.sum() + var_loss.sum() + swap_loss.sum()) * cfg.buggy_samples_weight  # gnn.py:240-242
+    B = len(mb["has_bug"])
+    loss = loc_loss + repair / B  # :251
+    return {
+        "loss": loss,
+        "node_reprs": h,
+        "loc_logprobs": loc_logprobs,
+        "repair_logits": all_logits,
+        "text_logprobs": text_lp,
+        "var_logprobs": var_lp,
+        "swap_logprobs": swap_lp,
+        "loc_loss": loc_loss,
+        "repair_loss": repair,
+        "loc_stats": loc_stats,
+        "is_selected_fix": sel,
+    }
+
+
+def forward_backward(params, mb, cfg: OracleConfig, seed=None):
+    """loss + grads for every parameter (dict, same names)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    out = forward_loss(leaves, mb, cfg, seed=seed)
+    out["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+    return out, grads
+
+
+# ----------------------------------------------------------------------------
+# T1  optimiser step: clip_grad_norm_(0.5) (train.py:104) + Adam lr 1e-4 (utils.py:51-52)
+#     + LinearWarmupScheduler(800) (utils.py:55-66)
+# ----------------------------------------------------------------------------
+def adam_clip_step(params, grads, m, v, step, lr=1e-4, clip=0.5, warmup=800, b1=0.9, b2=0.999, eps=1e-8):
+    """`step` is 1-based.  lr factor follows LambdaLR semantics: the k-th optimiser step
+    (k = 1, 2, ...) runs with factor min(1, (k-1)/warmup) -- the first step has lr 0."""
+    tot = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+    scale = min(1.0, clip / (tot + 1e-6))  # torch.nn.utils.clip_grad_norm_
+    factor = min(1.0, float(step - 1) / float(max(1, warmup))) if warmup > 0 else 1.0
+    eff_lr = lr * factor
+    for k in params:
+        g = grads[k] * scale
+        m[k].mul_(b1).add_(g, alpha=1 - b1)
+        v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - b1**step
+        bc2 = 1 - b2**step
+        denom = (v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        params[k].addcdiv_(m[k], denom, value=-eff_lr / bc1)
+    return tot

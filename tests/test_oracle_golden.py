@@ -1,0 +1,60 @@
+"""CPU: the oracle's head / segment / loss restatement against vectors produced by the
+reference's own code (tests/golden/make_golden.py).  Pins SURVEY section 8a rows H1-H8."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import buglab_oracle as O
+from tests.refmap import MAP, _tx, golden_minibatch, head_params_from_golden
+
+
+def test_scatter_log_softmax_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "heads_logsoftmax.npz"))
+    out = O.scatter_log_softmax(torch.from_numpy(z["src"]), torch.from_numpy(z["index"]))
+    np.testing.assert_allclose(out.numpy(), z["out"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_heads_forward_backward_match_reference(golden_dir, case):
+    z = np.load(os.path.join(golden_dir, f"heads_forward_{case}.npz"))
+    params = {k: v.requires_grad_(True) for k, v in head_params_from_golden(z).items()}
+    h = torch.from_numpy(z["node_states"]).requires_grad_(True)
+    mb = golden_minibatch(z)
+    refs = mb["graph_data"]["reference_node_ids"]
+    L = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
+    swap_lp, text_lp, var_lp, sel, _ = O.repair_logprobs(
+        params, h, refs, mb["target_rewrites"], mb["rewrite_to_location_group"],
+        mb["candidate_symbol_to_location_group"], mb["swapped_pair_to_call_location_group"])
+    loc_loss, loc_lp, stats = O.localization_loss(
+        params, h[L(refs["candidate_nodes"])], mb["graph_data"]["reference_node_graph_idx"]["candidate_nodes"],
+        mb["has_bug"], mb["correct_candidate_node_idxs"], float(z["buggy_weight"]))
+    repair = -(text_lp[L(mb["correct_rewrite_idxs"])].sum() + var_lp[L(mb["correct_candidate_symbols"])].sum()
+               + swap_lp[L(mb["correct_swapped_pair"])].sum()) * float(z["buggy_weight"])
+    loss = loc_loss + repair / int(z["B"])
+    np.testing.assert_allclose(loc_lp.detach().numpy(), z["loc_logprobs"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(text_lp.detach().numpy(), z["text_logprobs"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(var_lp.detach().numpy(), z["var_logprobs"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(swap_lp.detach().numpy(), z["swap_logprobs"], atol=2e-6, rtol=0)
+    assert abs(float(loss) - float(z["loss"])) < 2e-6
+    assert abs(stats["num_correct"] / int(z["B"]) - float(z["metrics_loc_accuracy"])) < 1e-9
+    loss.backward()
+    np.testing.assert_allclose(h.grad.numpy(), z["grad_node_states"], atol=2e-6, rtol=1e-5)
+    for ours, (ref, how) in MAP.items():
+        np.testing.assert_allclose(params[ours].grad.numpy(), _tx(z["g_" + ref], how), atol=2e-6, rtol=1e-5, err_msg=ours)
+
+
+def test_logprobs_normalise():
+    """The reference's own sanity comments (basemodel.py:257-258, 342-344): per-graph
+    localization probabilities sum to one."""
+    from buglab.data.collate import collate_samples
+    from buglab.data.synthetic import make_samples
+
+    cfg = O.OracleConfig(hidden=32, num_layers=4, num_edge_types=4, vocab_size=100)
+    mb = collate_samples(make_samples(3, seed=1, num_nodes=40, num_messages=150, num_edge_types=4, vocab_size=100, num_candidates=5), 4)
+    out = O.forward_loss(O.init_params(cfg), mb, cfg)
+    idx = np.concatenate([mb["graph_data"]["reference_node_graph_idx"]["candidate_nodes"], np.arange(3)])
+    for b in range(3):
+        assert abs(float(torch.logsumexp(out["loc_logprobs"][torch.from_numpy(idx == b)], 0))) < 1e-5
