@@ -1,0 +1,158 @@
+/*
+ * buglab_hip.h -- C ABI of libbuglab_hip.so, the MI355X (gfx950) kernels behind BugLab's
+ * `gnn-mlp` message-passing + scoring-head hot path.
+ *
+ * Conventions:
+ *   - every function is extern "C", returns 0 on success, a positive hipError_t or a negative
+ *     BL_E* argument error otherwise; bl_last_error() gives the text for the calling thread;
+ *   - the CALLER owns every buffer (PyTorch-ROCm tensors -> data_ptr()); nothing here allocates;
+ *   - all index arrays are int32, all values float32, matrices row-major with an explicit
+ *     leading dimension where one is given; pointers must be 16-byte aligned and every leading
+ *     dimension / width a multiple of 4 floats;
+ *   - the last argument is the hipStream_t to launch on
+ *     (torch.cuda.current_stream().cuda_stream); entry points never synchronise.
+ *
+ * The reference has no native code at all: each entry point below names the reference Python
+ * (or the third-party op called from it) that it replaces.  Paths are relative to
+ * /root/reference.
+ */
+#ifndef BUGLAB_HIP_H
+#define BUGLAB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BL_OK 0
+#define BL_EINVAL (-1) /* bad argument (null pointer, misaligned, unsupported size) */
+#define BL_ERANGE (-2) /* dimension outside what the kernels were built for */
+
+/* activation codes shared by every entry point */
+enum { BL_ACT_NONE = 0, BL_ACT_RELU = 1, BL_ACT_SIGMOID = 2, BL_ACT_TANH = 3, BL_ACT_GELU = 4 };
+
+const char* bl_last_error(void);
+int bl_version(void);
+
+/* Rows of a (virtually) concatenated, gathered operand:
+ *   row r = [ x[0][idx[0][r], 0:width[0]] ; x[1][idx[1][r], 0:width[1]] ; ... ]   (nsrc <= 3)
+ * idx[j] == NULL means the identity (row r of x[j]).  This is how `torch.cat((h[src], h[tgt]), -1)`
+ * and the heads' `torch.cat((a[i], b[j]), -1)` are consumed without ever being materialised. */
+typedef struct {
+  const float* x[3];
+  const int32_t* idx[3];
+  int32_t ld[3];
+  int32_t width[3];
+  int32_t nsrc;
+} bl_rows_t;
+
+/* counter-based dropout (oracle: oracle/buglab_oracle.py::dropout_keep_mask).  p == 0 disables. */
+typedef struct {
+  float p;
+  uint32_t seed;
+  uint32_t stream;
+} bl_dropout_t;
+
+/* ---------------------------------------------------------------------------------------------
+ * M0  node embedder: out[n,:] = Dropout(max_{s < lens[n]} table[ids[n,s], :]), argsub = winning s.
+ * Replaces ptgnn StrElementRepresentationModel (configured at buglab/models/modelregistry.py:59-82:
+ * subtoken splitting, <= 6 subtokens, "max" combination).
+ * bwd: g_table[ids[n, argsub[n,h]], h] += g_out[n,h] (masked by the same dropout), fp32 atomics. */
+int bl_embed_subtoken_max_fwd(const float* table, int32_t V, int32_t H, const int32_t* ids, const int32_t* lens,
+                              int32_t N, int32_t S, bl_dropout_t drop, float* out, int32_t ld_out, int8_t* argsub,
+                              void* stream);
+int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const int32_t* ids, const int8_t* argsub, int32_t N,
+                              int32_t S, int32_t H, int32_t V, bl_dropout_t drop, float* g_table, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Grouped, gathered fp32 GEMM on MFMA (v_mfma_f32_32x32x2_f32, exact fp32).
+ *   for group g (rows group_ptr[g] .. group_ptr[g+1]):  C[r, 0:N] = drop(act(rows(a)[r, 0:K] . B_g + bias))
+ *   B_g = b + group_w[g] * b_group_stride ; if b_is_nk == 0, B_g is [K, N] row-major (ldb),
+ *   else B_g is [N, K] row-major and is used transposed (C = A . B_g^T).
+ * group_ptr == NULL: one group covering rows 0..M.  group_w == NULL: identity.
+ * Replaces, per edge type, ptgnn MlpMessagePassingLayer's gather + cat + Linear
+ * (call site buglab/models/gnnlayerdefs.py:6-23), ptgnn's dense node update, and the heads'
+ * nn.Linear / MLP layers (buglab/models/layers/mlp.py:6-20, localizationmodule.py:22-24, 56-60,
+ * fixermodules.py:36-39, 71-73, 116-124).  With b_is_nk = 1 it is the input-gradient GEMM. */
+int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_stride, int32_t ldb, int32_t b_is_nk,
+                 const float* bias, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M, int32_t N,
+                 int32_t K, int32_t act, bl_dropout_t drop, float* c, int32_t ldc, void* stream);
+
+/* Weight-gradient GEMM (reduction over rows, split across row chunks, fp32 atomics):
+ *   gw[group_w[g]][0:K, 0:N] += rows(a)[rows of g, 0:K]^T . g_c[rows of g, 0:N]
+ * gw must be zeroed (or hold the running gradient) by the caller.  autograd equivalent:
+ * the weight gradient of every Linear named above. */
+int bl_gemm_wgrad(const bl_rows_t* a, const float* g_c, int32_t ld_g, const int32_t* group_ptr,
+                  const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
+                  int64_t gw_group_stride, int32_t ld_gw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * M2(+M3a)  segmented max with argmax, optional fused LayerNorm.
+ *   out[v, d] = max_{i in seg_ptr[v]..seg_ptr[v+1]} act(x[item(i), d]),  item(i) = seg_items ? seg_items[i] : i
+ *   arg[v, d] = that item (ties: first in segment order), -1 and out = 0 for an empty segment;
+ *   if ln_g != NULL also  ln_out[v,:] = LayerNorm(out[v,:]; ln_g, ln_b, eps), mean[v], rstd[v].
+ * Replaces torch_scatter.scatter_max at ptgnn's "max" aggregation (gnnlayerdefs.py:11,21) and at
+ * buglab/models/layers/localizationmodule.py:56-58, plus ptgnn's nn.LayerNorm. */
+int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg,
+                       int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g, const float* ln_b,
+                       float eps, float* ln_out, float* mean, float* rstd, void* stream);
+
+/* backward of the segmented max, gather form (deterministic, no atomics):
+ *   g_x[i, d] = (arg[seg_of[i], d] == i) ? g_out[seg_of[i], d] * act'(x[i, d]) : 0      (g_x may alias x) */
+int bl_segment_max_bwd(const float* g_out, const int32_t* arg, const float* x, int32_t ldx, const int32_t* seg_of,
+                       int32_t nitems, int32_t D, int32_t act, float* g_x, void* stream);
+
+/* LayerNorm backward (rows of D <= 512):  g_x, and g_gamma/g_beta ACCUMULATED with fp32 atomics. */
+int bl_layernorm_bwd(const float* g_y, const float* x, const float* mean, const float* rstd, const float* gamma,
+                     int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta, void* stream);
+
+/* activation(+dropout) backward from the OUTPUT y of y = drop(act(z + bias)); g_bias (if not NULL)
+ * accumulates column sums of g_z with fp32 atomics.  g_z may alias g_y.  (GELU is not supported
+ * here: it needs the pre-activation, see bl_segment_max_bwd.) */
+int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act, bl_dropout_t drop,
+               float* g_z, float* g_bias, void* stream);
+
+/* M1 backward, last step: gradient w.r.t. node states from the per-message input gradients
+ *   g_h[n, 0:Din] (+)= sum_{e in src CSR of n} g_a[e, 0:Din] + sum_{e in tgt CSR of n} g_a[e, Din:2Din]
+ * (deterministic segmented sums; replaces autograd's index_add of the two h[...] gathers). */
+int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
+                       const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din, int32_t accumulate,
+                       float* g_h, int32_t ld_gh, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Heads.
+ * H7  scatter_log_softmax (buglab/models/utils.py:15-28) over CSR segments:
+ *     y[i] = x[i] - max_seg - log(sum_seg exp(x - max_seg) + eps)
+ * bwd: g_x[i] = g_y[i] - exp(y[i]) * sum_seg g_y */
+int bl_segment_log_softmax_fwd(const float* x, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg,
+                               float eps, float* y, void* stream);
+int bl_segment_log_softmax_bwd(const float* g_y, const float* y, const int32_t* seg_ptr, const int32_t* seg_items,
+                               int32_t nseg, float* g_x, void* stream);
+
+/* final score layer Linear(H -> 1): y[r] = x[r, :] . w + b   (mlp.py:17, localizationmodule.py:24, 60) */
+int bl_rowdot_fwd(const float* x, int32_t ldx, const float* w, const float* b, int32_t R, int32_t H, float* y,
+                  void* stream);
+/* g_x[r,:] = g_y[r] * w ;  g_w += sum_r g_y[r] x[r,:] ;  g_b += sum_r g_y[r]   (atomics) */
+int bl_rowdot_bwd(const float* g_y, const float* x, int32_t ldx, const float* w, int32_t R, int32_t H, float* g_x,
+                  int32_t ld_gx, float* g_w, float* g_b, void* stream);
+
+/* out[idx[r], 0:width] += src[r, col_off : col_off + width]  (fp32 atomics).  Backward of every
+ * `reprs[node_idx]` gather in buglab/models/gnn.py:170-172, 261-289 and of the rewrite-embedding
+ * lookup in fixermodules.py:36. */
+int bl_scatter_add_rows(const float* src, int32_t ld_src, int32_t col_off, int32_t width, const int32_t* idx,
+                        int32_t R, float* out, int32_t ld_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * T1  optimiser on flat fp32 buffers: global-norm clip (buglab/models/train.py:104, clip 0.5) fused
+ * with Adam (buglab/models/utils.py:51-52).  bl_sqnorm writes sum(g^2) to *out (device scalar,
+ * zeroed inside); bl_adam_clip_step reads it on the device -- no host sync. */
+int bl_sqnorm(const float* g, int64_t n, float* out, void* stream);
+int bl_adam_clip_step(float* param, const float* grad, float* m, float* v, int64_t n, const float* grad_sqnorm,
+                      float grad_prescale, float clip_norm, float lr, float beta1, float beta2, float eps,
+                      int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BUGLAB_HIP_H */

@@ -143,13 +143,22 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
         pair_g.append(np.full(r.shape[0], b, dtype=np.int64))
     ref_ids[REFERENCE_KEY_PAIRS] = (np.concatenate(pairs, axis=0) if pairs else np.zeros((0, 2))).astype(I32)
     ref_graph[REFERENCE_KEY_PAIRS] = (np.concatenate(pair_g) if pair_g else np.zeros(0)).astype(I32)
+    # the two columns of the swapped-argument pairs as separate row-index vectors: the pair scorer
+    # consumes [h[call] ; h[a] ; h[b]] as three gathered sources (fixermodules.py:116-124)
+    ref_ids["candidate_swapped_a"] = np.ascontiguousarray(ref_ids[REFERENCE_KEY_PAIRS][:, 0])
+    ref_ids["candidate_swapped_b"] = np.ascontiguousarray(ref_ids[REFERENCE_KEY_PAIRS][:, 1])
 
     node_to_graph = np.repeat(np.arange(B, dtype=I32), n_per_graph)
     cand_graph = ref_graph["candidate_nodes"]
     cand_ptr = np.zeros(B + 1, dtype=np.int64)
     if cand_graph.size:
         np.cumsum(np.bincount(cand_graph, minlength=B), out=cand_ptr[1:])
+    # CSR for the localization log-softmax: items = [candidates..., one NO_BUG slot per graph]
+    # (localizationmodule.py:66-77: ids = cat(candidate_to_sample_idx, arange(B)))
+    loc_ptr, loc_items = _csr(np.concatenate([cand_graph.astype(np.int64), np.arange(B, dtype=np.int64)]), B)
     return {
+        "loc_group_ptr": loc_ptr,
+        "loc_group_items": loc_items,
         "token_ids": token_ids,
         "token_lens": token_lens,
         "msg_src": msg_src,
@@ -252,7 +261,7 @@ _INT_KEYS_MB = (
     "repair_group_ptr",
     "repair_group_items",
 )
-_INT_KEYS_GD = ("token_ids", "token_lens", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
+_INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
 
 
 def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:

@@ -1,0 +1,26 @@
+"""Layer-stack recipes, same function names/kwargs as reference buglab/models/gnnlayerdefs.py."""
+from buglab.models.layers.messagepassing import ConcatResidualLayer, MlpMessagePassingLayer
+
+
+def create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edges: int, features_dimension: int = 0,
+                         num_layers: int = 8, message_activation: str = "gelu"):
+    """Reference gnnlayerdefs.py:5-39: per block [stash, 3 x MP(H,H,H), concat, MP(2H,2H,H)]; the
+    reference hard-wires two blocks (8 MP layers); `num_layers` (multiple of 4) is the knob
+    BASELINE.json's 4-layer plumbing config needs and defaults to the reference's 8."""
+    assert num_layers % 4 == 0 and num_layers >= 4, "num_layers must be a positive multiple of 4"
+    mk = lambda din, dm: MlpMessagePassingLayer(
+        input_state_dimension=din, message_dimension=dm, output_state_dimension=hidden_state_size,
+        num_edge_types=num_edges, message_aggregation_function="max", dropout_rate=dropout_rate,
+        features_dimension=features_dimension, message_activation=message_activation)
+    layers = []
+    for _ in range(num_layers // 4):
+        r = ConcatResidualLayer(hidden_state_size)
+        layers += [r.pass_through_dummy_layer(), mk(hidden_state_size, hidden_state_size),
+                   mk(hidden_state_size, hidden_state_size), mk(hidden_state_size, hidden_state_size), r,
+                   mk(2 * hidden_state_size, 2 * hidden_state_size)]
+    return layers
+
+
+def create_ggnn_mp_layers(hidden_state_size, dropout_rate, num_edges: int):
+    raise NotImplementedError("`ggnn` (GatedMessagePassingLayer, reference gnnlayerdefs.py:42-68) is a SURVEY section 8f "
+                              "'next' row; only `gnn-mlp` runs on the HIP path so far")

@@ -1,0 +1,122 @@
+"""Host-side graph tensoriser: the roles ptgnn's `StrElementRepresentationModel` and
+`GraphNeuralNetworkModel` play in the reference (kwargs pinned at buglab/models/modelregistry.py:71-90;
+methods used at buglab/models/gnn.py:350,354,403,433,466,547).  Metadata pass -> vocabularies and
+edge-type table; `tensorize` -> int32 NumPy arrays per graph (buglab.data.collate.TensorizedGraphData).
+
+Choices ptgnn's call sites do not pin, frozen here: subtoken vocabulary
+built with count threshold 5; presented edge types = sorted forward types, then (if
+`add_backwards_edges`, default True) one reversed type per forward type, then (if
+`add_self_edges`) one self-loop type -- e.g. BugLab's 15 forward kinds -> 31 presented types.
+"""
+from __future__ import annotations
+
+from collections import Counter
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+
+from buglab.data.collate import TensorizedGraphData
+from buglab.representations.data import GraphData
+from buglab.runtime.vocabulary import Vocabulary, split_identifier_into_parts
+
+
+class StrElementRepresentationModel:
+    def __init__(self, *, token_splitting: str = "subtoken", embedding_size: int = 128, vocabulary_size: int = 15000,
+                 max_num_subtokens: int = 6, subtoken_combination: str = "max", dropout_rate: float = 0.0,
+                 min_freq_threshold: int = 5):
+        if token_splitting != "subtoken" or subtoken_combination != "max":
+            raise NotImplementedError("the HIP embedder implements the reference's gnn-mlp default: subtoken / max (modelregistry.py:61-67)")
+        self.token_splitting, self.subtoken_combination = token_splitting, subtoken_combination
+        self.embedding_size, self.vocabulary_size = embedding_size, vocabulary_size
+        self.max_num_subtokens, self.dropout_rate = max_num_subtokens, dropout_rate
+        self.min_freq_threshold = min_freq_threshold
+        self._counter: Optional[Counter] = Counter()
+        self.vocabulary: Optional[Vocabulary] = None
+        self._cache: Dict[str, np.ndarray] = {}
+
+    def update_metadata_from(self, node_str: str) -> None:
+        self._counter.update(split_identifier_into_parts(node_str))
+
+    def finalize_metadata(self) -> None:
+        self.vocabulary = Vocabulary.create_vocabulary(self._counter, max_size=self.vocabulary_size,
+                                                       count_threshold=self.min_freq_threshold, add_unk=True, add_pad=True)
+        self._counter = None
+
+    def build_neural_module(self):
+        from buglab.models.layers.messagepassing import SubtokenEmbedder
+
+        return SubtokenEmbedder(len(self.vocabulary), self.embedding_size, self.max_num_subtokens, self.dropout_rate)
+
+    def tensorize_nodes(self, node_strs: List[str]):
+        S = self.max_num_subtokens
+        ids = np.zeros((len(node_strs), S), dtype=np.int32)
+        lens = np.ones(len(node_strs), dtype=np.int32)
+        for i, s in enumerate(node_strs):
+            row = self._cache.get(s)
+            if row is None:
+                toks = split_identifier_into_parts(s)[:S]
+                row = np.array([self.vocabulary.get_id_or_unk(t) for t in toks], dtype=np.int32)
+                if len(self._cache) < 200000:
+                    self._cache[s] = row
+            ids[i, : len(row)] = row
+            lens[i] = max(1, len(row))
+        return ids, lens
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_cache"] = {}
+        return d
+
+
+class GraphNeuralNetworkModel:
+    def __init__(self, *, node_representation_model: StrElementRepresentationModel, edge_representation_model=None,
+                 add_self_edges: bool = False, add_backwards_edges: bool = True,
+                 message_passing_layer_creator: Callable[[int], List[Any]] = None,
+                 stop_extending_minibatch_after_num_nodes: int = 30000, max_nodes_per_graph: int = 35000):
+        if edge_representation_model is not None:
+            raise NotImplementedError("edge features (edge_feature_size > 0) are off in every reference configuration")
+        self.node_representation_model = node_representation_model
+        self.add_self_edges, self.add_backwards_edges = add_self_edges, add_backwards_edges
+        self.message_passing_layer_creator = message_passing_layer_creator
+        self.stop_extending_minibatch_after_num_nodes = stop_extending_minibatch_after_num_nodes
+        self.max_nodes_per_graph = max_nodes_per_graph
+        self._edge_types_seen = set()
+        self.edge_types: Optional[List[str]] = None
+
+    # metadata
+    def update_metadata_from(self, graph: GraphData) -> None:
+        for node in graph.node_information:
+            self.node_representation_model.update_metadata_from(node)
+        self._edge_types_seen.update(graph.edges.keys())
+
+    def finalize_metadata(self) -> None:
+        self.node_representation_model.finalize_metadata()
+        self.edge_types = sorted(self._edge_types_seen)
+        self._edge_types_seen = None
+
+    @property
+    def num_presented_edge_types(self) -> int:
+        n = len(self.edge_types)
+        return n * (2 if self.add_backwards_edges else 1) + (1 if self.add_self_edges else 0)
+
+    def build_neural_module(self):
+        from buglab.models.layers.messagepassing import GraphNeuralNetwork
+
+        return GraphNeuralNetwork(self.node_representation_model.build_neural_module(),
+                                  self.message_passing_layer_creator(self.num_presented_edge_types))
+
+    def tensorize(self, graph: GraphData) -> Optional[TensorizedGraphData]:
+        n = len(graph.node_information)
+        if n > self.max_nodes_per_graph:
+            return None
+        ids, lens = self.node_representation_model.tensorize_nodes(graph.node_information)
+        empty = np.zeros((0, 2), dtype=np.int32)
+        fwd = [np.asarray(graph.edges.get(t, empty), dtype=np.int32).reshape(-1, 2) for t in self.edge_types]
+        adj = list(fwd)
+        if self.add_backwards_edges:
+            adj += [np.ascontiguousarray(a[:, ::-1]) for a in fwd]
+        if self.add_self_edges:
+            ar = np.arange(n, dtype=np.int32)
+            adj.append(np.stack([ar, ar], axis=1))
+        refs = {k: np.asarray(v, dtype=np.int32) for k, v in graph.reference_nodes.items()}
+        return TensorizedGraphData(ids, lens, adj, refs)

@@ -1,0 +1,533 @@
+"""ctypes binding of libbuglab_hip.so (C ABI in include/buglab_hip.h) + torch.autograd wrappers.
+
+This is the ONLY place the HIP kernels are called from.  There is no CPU fallback: importing works
+anywhere (so host-side code can be tested without a GPU), but the first call that needs a kernel
+raises `HipOpsUnavailable` if the shared library is missing or the tensors are not on a ROCm device.
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; every FLOP of the
+message-passing layers and of the scoring heads runs in the kernels under csrc/.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int8, c_int32, c_int64, c_uint32, c_void_p
+from typing import List, NamedTuple, Optional, Sequence, Tuple
+
+import torch
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4
+_ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH, "gelu": ACT_GELU}
+LIB_NAME = "libbuglab_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+class HipOpsUnavailable(RuntimeError):
+    pass
+
+
+class bl_rows_t(Structure):
+    _fields_ = [("x", c_void_p * 3), ("idx", c_void_p * 3), ("ld", c_int32 * 3), ("width", c_int32 * 3), ("nsrc", c_int32)]
+
+
+class bl_dropout_t(Structure):
+    _fields_ = [("p", c_float), ("seed", c_uint32), ("stream", c_uint32)]
+
+
+_SIGNATURES = {
+    "bl_version": ([], ctypes.c_int),
+    "bl_last_error": ([], ctypes.c_char_p),
+    "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gemm_rows": ([POINTER(bl_rows_t), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
+    "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_segment_log_softmax_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p], ctypes.c_int),
+    "bl_segment_log_softmax_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_rowdot_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_rowdot_bwd": ([c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_scatter_add_rows": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_sqnorm": ([c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "bl_adam_clip_step": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p], ctypes.c_int),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libbuglab_hip.so and declare every prototype.  Loud failure, never a fallback."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipOpsUnavailable(
+            f"{p} not found: build it with `make -C neurips21-self-supervised-bug-detection-and-repair_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback for the hot path."
+        )
+    lib = ctypes.CDLL(p)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().bl_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise HipOpsUnavailable(f"{name}: tensor is on {t.device}; the BugLab hot path only runs on a ROCm GPU (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _f32(t, name="tensor"):
+    return _req(t, torch.float32, name)
+
+
+def _i32(t, name="index"):
+    return _req(t, torch.int32, name)
+
+
+class Dropout(NamedTuple):
+    p: float = 0.0
+    seed: int = 0
+    stream: int = 0
+
+    def c(self) -> bl_dropout_t:
+        return bl_dropout_t(float(self.p), int(self.seed) & 0xFFFFFFFF, int(self.stream) & 0xFFFFFFFF)
+
+
+NO_DROPOUT = Dropout()
+
+RowSource = Tuple[torch.Tensor, Optional[torch.Tensor]]  # (matrix [*, width], row index or None)
+
+
+def _rows(sources: Sequence[RowSource]) -> Tuple[bl_rows_t, int]:
+    r = bl_rows_t()
+    assert 1 <= len(sources) <= 3
+    K = 0
+    for j, (x, idx) in enumerate(sources):
+        _f32(x, f"rows source {j}")
+        assert x.dim() == 2
+        r.x[j] = x.data_ptr()
+        r.idx[j] = _i32(idx, f"rows index {j}").data_ptr() if idx is not None else None
+        r.ld[j] = x.stride(0)
+        r.width[j] = x.shape[1]
+        K += x.shape[1]
+    r.nsrc = len(sources)
+    return r, K
+
+
+# ------------------------------------------------------------------------------------------------
+# optional live kernel timing (bench.py): HIP events recorded on the launch stream around each GEMM
+class KernelTimer:
+    """`with KernelTimer() as t:` brackets every bl_gemm_* launch with a pair of HIP events on the
+    stream the kernel is launched on (torch's current stream is the one handed to the C ABI).
+    `t.summary()` (after a device sync) -> {kind: {"launches", "ms", "flop"}}."""
+
+    active: Optional["KernelTimer"] = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        out = {}
+        for kind, flop, e0, e1 in self.records:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flop": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flop"] += flop
+        return out
+
+
+class _timed:
+    def __init__(self, kind, flop):
+        self.t = KernelTimer.active
+        self.kind, self.flop = kind, flop
+
+    def __enter__(self):
+        if self.t is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.t.records.append((self.kind, self.flop, self.e0, e1))
+
+
+# ------------------------------------------------------------------------------------------------
+# raw (non-autograd) entry points
+def gemm_rows(sources, b, M, N, *, b_is_nk=False, b_group_stride=0, ldb=None, bias=None, group_ptr=None, group_w=None,
+              G=1, act=ACT_NONE, drop: Dropout = NO_DROPOUT, out=None):
+    rows, K = _rows(sources)
+    _f32(b, "b")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=b.device)
+    if M == 0:
+        return out
+    kind = ("gemm_rows_nk" if b_is_nk else "gemm_rows") + ("_grouped" if group_ptr is not None else "")
+    with _timed(kind, 2.0 * M * N * K):
+        _check(
+            load_library().bl_gemm_rows(
+                ctypes.byref(rows), b.data_ptr(), int(b_group_stride), int(ldb if ldb is not None else b.shape[-1]), int(b_is_nk),
+                _p(bias), _p(group_ptr), _p(group_w), int(G), int(M), int(N), int(K), int(act), drop.c(), out.data_ptr(),
+                out.stride(0), _stream()),
+            "bl_gemm_rows")
+    return out
+
+
+def gemm_wgrad(sources, g_c, M, N, gw, *, gw_group_stride=0, group_ptr=None, group_w=None, G=1):
+    rows, K = _rows(sources)
+    _f32(g_c, "g_c")
+    _f32(gw, "gw")
+    if M == 0:
+        return gw
+    with _timed("gemm_wgrad" + ("_grouped" if group_ptr is not None else ""), 2.0 * M * N * K):
+        _check(
+            load_library().bl_gemm_wgrad(ctypes.byref(rows), g_c.data_ptr(), g_c.stride(0), _p(group_ptr), _p(group_w), int(G),
+                                         int(M), int(N), int(K), gw.data_ptr(), int(gw_group_stride), int(gw.shape[-1]), _stream()),
+            "bl_gemm_wgrad")
+    return gw
+
+
+def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5):
+    """-> (out [nseg, D], arg int32 [nseg, D], ln_out | None, mean | None, rstd | None)"""
+    _f32(x, "x")
+    D = x.shape[1]
+    dev = x.device
+    out = torch.empty((nseg, D), dtype=torch.float32, device=dev)
+    arg = torch.empty((nseg, D), dtype=torch.int32, device=dev)
+    ln_out = mean = rstd = None
+    if ln is not None:
+        ln_out = torch.empty((nseg, D), dtype=torch.float32, device=dev)
+        mean = torch.empty((nseg,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((nseg,), dtype=torch.float32, device=dev)
+    _check(
+        load_library().bl_segment_max_fwd(x.data_ptr(), x.stride(0), _i32(seg_ptr).data_ptr(), _p(seg_items), int(nseg), int(D),
+                                          int(act), out.data_ptr(), arg.data_ptr(), _p(ln[0]) if ln else None,
+                                          _p(ln[1]) if ln else None, float(eps), _p(ln_out), _p(mean), _p(rstd), _stream()),
+        "bl_segment_max_fwd")
+    return out, arg, ln_out, mean, rstd
+
+
+def segment_max_bwd(g_out, arg, x, seg_of, act=ACT_NONE, out=None):
+    nitems, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _check(
+        load_library().bl_segment_max_bwd(_f32(g_out).data_ptr(), _i32(arg).data_ptr(), x.data_ptr(), x.stride(0),
+                                          _i32(seg_of).data_ptr(), int(nitems), int(D), int(act), out.data_ptr(), _stream()),
+        "bl_segment_max_bwd")
+    return out
+
+
+def layernorm_bwd(g_y, x, mean, rstd, gamma, g_gamma, g_beta):
+    n, D = x.shape
+    g_x = torch.empty_like(x)
+    _check(
+        load_library().bl_layernorm_bwd(_f32(g_y).data_ptr(), _f32(x).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                        _f32(gamma).data_ptr(), int(n), int(D), g_x.data_ptr(), g_gamma.data_ptr(),
+                                        g_beta.data_ptr(), _stream()),
+        "bl_layernorm_bwd")
+    return g_x
+
+
+def act_bwd(g_y, y, act, drop: Dropout = NO_DROPOUT, g_bias=None):
+    n, N = y.shape
+    g_z = torch.empty_like(y)
+    _check(
+        load_library().bl_act_bwd(_f32(g_y).data_ptr(), _f32(y).data_ptr(), int(n), int(N), y.stride(0), int(act), drop.c(),
+                                  g_z.data_ptr(), _p(g_bias), _stream()),
+        "bl_act_bwd")
+    return g_z
+
+
+def scatter_add_rows(src, col_off, width, idx, out):
+    R = src.shape[0]
+    _check(
+        load_library().bl_scatter_add_rows(_f32(src).data_ptr(), src.stride(0), int(col_off), int(width), _i32(idx).data_ptr(),
+                                           int(R), _f32(out).data_ptr(), out.stride(0), _stream()),
+        "bl_scatter_add_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd wrappers
+class GraphIndex(NamedTuple):
+    """Device-side index arrays of one minibatch (buglab.data.collate.to_device)."""
+
+    msg_src: torch.Tensor
+    msg_tgt: torch.Tensor
+    type_ptr: torch.Tensor
+    tgt_ptr: torch.Tensor
+    tgt_msgs: torch.Tensor
+    src_ptr: torch.Tensor
+    src_msgs: torch.Tensor
+    num_nodes: int
+    num_messages: int
+    num_types: int
+
+
+class _EmbedSubtokenMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, ids, lens, drop: Dropout):
+        _f32(table, "embedding table")
+        N, S = ids.shape
+        V, H = table.shape
+        out = torch.empty((N, H), dtype=torch.float32, device=table.device)
+        argsub = torch.empty((N, H), dtype=torch.int8, device=table.device)
+        _check(
+            load_library().bl_embed_subtoken_max_fwd(table.data_ptr(), V, H, _i32(ids).data_ptr(), _i32(lens).data_ptr(), N, S,
+                                                     drop.c(), out.data_ptr(), out.stride(0), argsub.data_ptr(), _stream()),
+            "bl_embed_subtoken_max_fwd")
+        ctx.saved = (ids, argsub, drop, V, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ids, argsub, drop, V, H = ctx.saved
+        g_out = g_out.contiguous()
+        N, S = ids.shape
+        g_table = torch.zeros((V, H), dtype=torch.float32, device=g_out.device)
+        _check(
+            load_library().bl_embed_subtoken_max_bwd(g_out.data_ptr(), g_out.stride(0), ids.data_ptr(), argsub.data_ptr(), N, S, H,
+                                                     V, drop.c(), g_table.data_ptr(), _stream()),
+            "bl_embed_subtoken_max_bwd")
+        return g_table, None, None, None
+
+
+def embed_subtoken_max(table, ids, lens, drop: Dropout = NO_DROPOUT):
+    return _EmbedSubtokenMax.apply(table, ids, lens, drop)
+
+
+class _MpLayer(torch.autograd.Function):
+    """One MlpMessagePassingLayer: message GEMM -> segmented max(+GELU) + LayerNorm -> dense+tanh+dropout.
+
+    Saved for backward: the pre-activation messages [E, Dm] (overwritten in place by their own
+    gradient during backward), argmax [N, Dm] int32, the aggregate, LayerNorm statistics/output and
+    the layer output.  Single backward only (buffers are recycled)."""
+
+    @staticmethod
+    def forward(ctx, h, W, ln_g, ln_b, Wd, bd, g: GraphIndex, msg_act: int, drop: Dropout):
+        _f32(h, "node states")
+        N, Din = h.shape
+        T, K2, Dm = W.shape
+        Dout = Wd.shape[1]
+        E = g.num_messages
+        assert K2 == 2 * Din and T == g.num_types and N == g.num_nodes
+        pre = gemm_rows([(h, g.msg_src), (h, g.msg_tgt)], _f32(W, "W"), E, Dm, b_group_stride=K2 * Dm, ldb=Dm,
+                        group_ptr=g.type_ptr, G=T)
+        agg, arg, ln_out, mean, rstd = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)))
+        out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
+        ctx.saved = (h, W, ln_g, Wd, pre, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        h, W, ln_g, Wd, pre, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
+        ctx.saved = None
+        N, Din = h.shape
+        T, K2, Dm = W.shape
+        Dout = Wd.shape[1]
+        E = g.num_messages
+        dev = h.device
+        g_out = g_out.contiguous()
+        # dense + tanh + dropout
+        g_bd = torch.zeros((Dout,), dtype=torch.float32, device=dev)
+        g_z = act_bwd(g_out, out, ACT_TANH, drop, g_bd)
+        g_Wd = torch.zeros_like(Wd)
+        gemm_wgrad([(ln_out, None)], g_z, N, Dout, g_Wd)
+        g_ln = gemm_rows([(g_z, None)], Wd, N, Dm, b_is_nk=True, ldb=Dout)
+        # LayerNorm
+        g_lng = torch.zeros((Dm,), dtype=torch.float32, device=dev)
+        g_lnb = torch.zeros((Dm,), dtype=torch.float32, device=dev)
+        g_agg = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb)
+        # max aggregation (+ message activation): route to the winning message, in place over `pre`
+        g_pre = segment_max_bwd(g_agg, arg, pre, g.msg_tgt, act=msg_act, out=pre)
+        # per-edge-type weights
+        g_W = torch.zeros_like(W)
+        gemm_wgrad([(h, g.msg_src), (h, g.msg_tgt)], g_pre, E, Dm, g_W, gw_group_stride=K2 * Dm, group_ptr=g.type_ptr, G=T)
+        # node states: per-message input gradients, then segmented sums over the src / tgt CSRs
+        g_a = gemm_rows([(g_pre, None)], W, E, K2, b_is_nk=True, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
+        g_h = torch.empty((N, Din), dtype=torch.float32, device=dev)
+        _check(
+            load_library().bl_mp_scatter_grad(g_a.data_ptr(), g_a.stride(0), g.src_ptr.data_ptr(), g.src_msgs.data_ptr(),
+                                              g.tgt_ptr.data_ptr(), g.tgt_msgs.data_ptr(), N, Din, 0, g_h.data_ptr(),
+                                              g_h.stride(0), _stream()),
+            "bl_mp_scatter_grad")
+        return g_h, g_W, g_lng, g_lnb, g_Wd, g_bd, None, None, None
+
+
+def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu", drop: Dropout = NO_DROPOUT):
+    return _MpLayer.apply(h.contiguous(), W, ln_g, ln_b, Wd, bd, graph, _ACTS[msg_act], drop)
+
+
+class _GatherLinear(torch.autograd.Function):
+    """act(concat_j(X_j[idx_j]) @ W + b) without materialising the gather/concat."""
+
+    @staticmethod
+    def forward(ctx, W, bias, act, nsrc, *flat):
+        xs, idxs = flat[:nsrc], flat[nsrc:]
+        sources = list(zip(xs, idxs))
+        R = idxs[0].shape[0] if idxs[0] is not None else xs[0].shape[0]
+        out = gemm_rows(sources, _f32(W, "W"), R, W.shape[1], bias=bias, act=act)
+        ctx.saved = (W, bias is not None, act, sources, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        W, has_bias, act, sources, out = ctx.saved
+        R, N = out.shape
+        K = W.shape[0]
+        dev = W.device
+        g_bias = torch.zeros((N,), dtype=torch.float32, device=dev) if has_bias else None
+        g_z = act_bwd(g_out.contiguous(), out, act, NO_DROPOUT, g_bias)
+        g_W = torch.zeros_like(W)
+        gemm_wgrad(sources, g_z, R, N, g_W)
+        g_a = gemm_rows([(g_z, None)], W, R, K, b_is_nk=True, ldb=N)
+        g_xs, off = [], 0
+        for j, (x, idx) in enumerate(sources):
+            w = x.shape[1]
+            if not ctx.needs_input_grad[4 + j]:
+                g_xs.append(None)
+            elif idx is None:
+                g_xs.append(g_a[:, off : off + w].contiguous())
+            else:
+                g_x = torch.zeros_like(x)
+                scatter_add_rows(g_a, off, w, idx, g_x)
+                g_xs.append(g_x)
+            off += w
+        return (g_W, g_bias, None, None) + tuple(g_xs) + (None,) * len(sources)
+
+
+def gather_linear(sources: Sequence[RowSource], W, bias, act: str = "none"):
+    xs = [x for x, _ in sources]
+    idxs = [i for _, i in sources]
+    return _GatherLinear.apply(W, bias, _ACTS[act], len(sources), *xs, *idxs)
+
+
+class _RowDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        R, H = x.shape
+        y = torch.empty((R,), dtype=torch.float32, device=x.device)
+        _check(load_library().bl_rowdot_fwd(_f32(x).data_ptr(), x.stride(0), _f32(w).data_ptr(), _p(b), R, H, y.data_ptr(), _stream()),
+               "bl_rowdot_fwd")
+        ctx.saved = (x, w, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, w, has_b = ctx.saved
+        R, H = x.shape
+        g_x = torch.empty_like(x)
+        g_w = torch.zeros_like(w)
+        g_b = torch.zeros((1,), dtype=torch.float32, device=x.device) if has_b else None
+        _check(
+            load_library().bl_rowdot_bwd(_f32(g_y.contiguous()).data_ptr(), x.data_ptr(), x.stride(0), w.data_ptr(), R, H,
+                                         g_x.data_ptr(), g_x.stride(0), g_w.data_ptr(), _p(g_b), _stream()),
+            "bl_rowdot_bwd")
+        return g_x, g_w, g_b
+
+
+def rowdot(x, w, b=None):
+    return _RowDot.apply(x, w, b)
+
+
+class _SegmentLogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg_ptr, seg_items, nseg, eps):
+        y = torch.empty_like(x)
+        _check(
+            load_library().bl_segment_log_softmax_fwd(_f32(x).data_ptr(), _i32(seg_ptr).data_ptr(), _p(seg_items), int(nseg),
+                                                      float(eps), y.data_ptr(), _stream()),
+            "bl_segment_log_softmax_fwd")
+        ctx.saved = (y, seg_ptr, seg_items, nseg)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        y, seg_ptr, seg_items, nseg = ctx.saved
+        g_x = torch.zeros_like(y)
+        _check(
+            load_library().bl_segment_log_softmax_bwd(_f32(g_y.contiguous()).data_ptr(), y.data_ptr(), seg_ptr.data_ptr(),
+                                                      _p(seg_items), int(nseg), g_x.data_ptr(), _stream()),
+            "bl_segment_log_softmax_bwd")
+        return g_x, None, None, None, None
+
+
+def segment_log_softmax(x, seg_ptr, seg_items, nseg: int, eps: float = 1e-12):
+    """scatter_log_softmax (reference buglab/models/utils.py:15-28) over a CSR of the segment ids."""
+    if x.numel() == 0:
+        return x
+    return _SegmentLogSoftmax.apply(x.contiguous(), seg_ptr, seg_items, nseg, eps)
+
+
+class _SegmentMaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg_ptr, seg_of, nseg):
+        out, arg, _, _, _ = segment_max(x, seg_ptr, None, nseg)
+        ctx.saved = (arg, x.shape, seg_of)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g_out, _g_arg):
+        arg, shape, seg_of = ctx.saved
+        x_like = torch.empty(shape, dtype=torch.float32, device=g_out.device)
+        g_x = segment_max_bwd(g_out.contiguous(), arg, x_like, seg_of, out=x_like)
+        return g_x, None, None, None
+
+
+def segment_max_pool(x, seg_ptr, seg_of, nseg: int):
+    """scatter_max over CONTIGUOUS segments (rows of segment s are seg_ptr[s]..seg_ptr[s+1]).
+    Returns (values [nseg, D], argmax row int32 [nseg, D]; -1 for an empty segment)."""
+    return _SegmentMaxPool.apply(x.contiguous(), seg_ptr, seg_of, nseg)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser on flat buffers
+def sqnorm(flat_grad: torch.Tensor, out: torch.Tensor):
+    _check(load_library().bl_sqnorm(_f32(flat_grad).data_ptr(), flat_grad.numel(), out.data_ptr(), _stream()), "bl_sqnorm")
+    return out
+
+
+def adam_clip_step(param, grad, m, v, sqn, *, prescale=1.0, clip=0.5, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
+    _check(
+        load_library().bl_adam_clip_step(_f32(param).data_ptr(), _f32(grad).data_ptr(), _f32(m).data_ptr(), _f32(v).data_ptr(),
+                                         param.numel(), _p(sqn), float(prescale), float(clip), float(lr), float(beta1), float(beta2),
+                                         float(eps), int(step), _stream()),
+        "bl_adam_clip_step")

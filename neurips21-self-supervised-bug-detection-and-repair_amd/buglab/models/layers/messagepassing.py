@@ -1,0 +1,135 @@
+"""GNN device modules: node embedder, MlpMessagePassingLayer, ConcatResidualLayer and the
+GraphNeuralNetwork container -- the roles ptgnn plays in the reference (call sites
+buglab/models/gnnlayerdefs.py:5-39, modelregistry.py:59-90, gnn.py:70-76,116-123).
+
+Arithmetic spec (frozen here because ptgnn's source is unavailable):
+  message    m_e  = act_msg([h_src ; h_tgt] @ W[type(e)])     W: [T, 2*Din, Dm], no bias
+  aggregate  a_v  = max over incoming messages (0 if none; ties -> lowest message id)
+  update     h'_v = Dropout(tanh(LayerNorm(a_v) @ Wd + bd))
+Every FLOP runs in libbuglab_hip (buglab.models.hip_ops); this file only owns parameters.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from buglab.models import hip_ops
+from buglab.models.hip_ops import Dropout, GraphIndex
+
+
+class GnnOutput(NamedTuple):
+    """Field names follow ptgnn's GnnOutput as used at reference gnn.py:119-139,264-289,631."""
+
+    input_node_representations: torch.Tensor
+    output_node_representations: torch.Tensor
+    node_to_graph_idx: torch.Tensor
+    node_idx_references: Dict[str, torch.Tensor]
+    node_graph_idx_reference: Dict[str, torch.Tensor]
+    num_graphs: int
+
+
+def _uniform_(t: torch.Tensor, bound: float) -> torch.Tensor:
+    return t.uniform_(-bound, bound)
+
+
+class SubtokenEmbedder(nn.Module):
+    """StrElementRepresentationModel in "subtoken"/"max" mode (modelregistry.py:59-82)."""
+
+    def __init__(self, vocabulary_size: int, embedding_size: int, max_num_subtokens: int = 6, dropout_rate: float = 0.0):
+        super().__init__()
+        self.embedding_size = embedding_size
+        self.max_num_subtokens = max_num_subtokens
+        self.dropout_rate = dropout_rate
+        self.table = nn.Parameter(torch.randn(vocabulary_size, embedding_size))
+
+    def forward(self, token_ids, token_lens, drop: Dropout):
+        return hip_ops.embed_subtoken_max(self.table, token_ids, token_lens, drop)
+
+
+class MlpMessagePassingLayer(nn.Module):
+    """kwargs as at the reference call site gnnlayerdefs.py:6-23."""
+
+    def __init__(self, input_state_dimension: int, message_dimension: int, output_state_dimension: int,
+                 num_edge_types: int, message_aggregation_function: str = "max", dropout_rate: float = 0.0,
+                 features_dimension: int = 0, message_activation: str = "gelu"):
+        super().__init__()
+        if message_aggregation_function != "max":
+            raise NotImplementedError("the HIP path implements the reference's `max` aggregation (gnnlayerdefs.py:11,21)")
+        if features_dimension != 0:
+            raise NotImplementedError("edge features are off in every reference gnn-mlp configuration (modelregistry.py:57)")
+        din, dm, dout, T = input_state_dimension, message_dimension, output_state_dimension, num_edge_types
+        self.input_state_dimension, self.message_dimension, self.output_state_dimension = din, dm, dout
+        self.num_edge_types, self.dropout_rate, self.message_activation = T, dropout_rate, message_activation
+        self.W = nn.Parameter(_uniform_(torch.empty(T, 2 * din, dm), 1.0 / math.sqrt(2 * din)))
+        self.ln_g = nn.Parameter(torch.ones(dm))
+        self.ln_b = nn.Parameter(torch.zeros(dm))
+        self.Wd = nn.Parameter(_uniform_(torch.empty(dm, dout), math.sqrt(6.0 / (dm + dout))))
+        self.bd = nn.Parameter(_uniform_(torch.empty(dout), 1.0 / math.sqrt(dm)))
+
+    def forward(self, node_states, graph: GraphIndex, drop: Dropout):
+        return hip_ops.mp_layer(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, graph,
+                                self.message_activation, drop)
+
+
+class ConcatResidualLayer:
+    """Stateless marker pair (gnnlayerdefs.py:24-38): `pass_through_dummy_layer()` stashes the
+    current node states, the layer itself returns [stash ; current]."""
+
+    def __init__(self, hidden_state_size: int):
+        self.hidden_state_size = hidden_state_size
+        self.output_state_dimension = 2 * hidden_state_size
+        self.dummy = _PassThrough(self)
+
+    def pass_through_dummy_layer(self):
+        return self.dummy
+
+
+class _PassThrough:
+    def __init__(self, owner: ConcatResidualLayer):
+        self.owner = owner
+        self.output_state_dimension = owner.hidden_state_size
+
+
+class GraphNeuralNetwork(nn.Module):
+    """Embeds nodes then applies the layer recipe.  Called as `gnn(**graph_data, return_all_states=bool)`
+    (reference gnn.py:117)."""
+
+    def __init__(self, node_embedder: SubtokenEmbedder, layer_recipe: List[Any]):
+        super().__init__()
+        self.embed = node_embedder
+        self._recipe = layer_recipe
+        self.mp = nn.ModuleList([l for l in layer_recipe if isinstance(l, MlpMessagePassingLayer)])
+        self.input_node_state_dim = node_embedder.embedding_size
+        self.output_node_state_dim = self.mp[-1].output_state_dimension
+
+    @property
+    def message_passing_layers(self):
+        return list(self.mp)
+
+    def forward(self, *, token_ids, token_lens, msg_src, msg_tgt, type_ptr, tgt_ptr, tgt_msgs, src_ptr, src_msgs,
+                node_to_graph, reference_node_ids, reference_node_graph_idx, num_graphs, num_nodes, num_messages,
+                return_all_states: bool = False, dropout_seed: Optional[int] = None, **_unused) -> GnnOutput:
+        graph = GraphIndex(msg_src, msg_tgt, type_ptr, tgt_ptr, tgt_msgs, src_ptr, src_msgs, int(num_nodes),
+                           int(num_messages), int(type_ptr.shape[0]) - 1)
+        training = self.training and dropout_seed is not None
+        seed = int(dropout_seed or 0)
+        mk = lambda rate, stream: Dropout(rate if training else 0.0, seed, stream)
+        h0 = self.embed(token_ids, token_lens, mk(self.embed.dropout_rate, 0))
+        h = h0
+        all_states = [h0]
+        stash: Dict[int, torch.Tensor] = {}
+        li = 0
+        for layer in self._recipe:
+            if isinstance(layer, _PassThrough):
+                stash[id(layer.owner)] = h
+            elif isinstance(layer, ConcatResidualLayer):
+                h = torch.cat([stash.pop(id(layer)), h], dim=-1)
+            else:
+                h = layer(h, graph, mk(layer.dropout_rate, 1 + li))
+                li += 1
+                all_states.append(h)
+        out = torch.cat(all_states, dim=-1) if return_all_states else h
+        return GnnOutput(h0, out, node_to_graph, reference_node_ids, reference_node_graph_idx, int(num_graphs))

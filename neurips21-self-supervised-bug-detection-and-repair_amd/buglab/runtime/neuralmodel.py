@@ -1,0 +1,140 @@
+"""`AbstractNeuralModel` -- the host-side half of ptgnn's (model, nn.Module) pair, reduced to the
+surface the reference uses: metadata pass, tensorize, minibatching,
+`save` / `restore_model` (gzip-pickled `(model, nn)`, reference gnn.py:325, evaluate.py:44,
+trainbugdetector.py:98, modelregistry.py:152-156)."""
+from __future__ import annotations
+
+import gzip
+import io
+import queue
+import threading
+from abc import ABC, abstractmethod
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+from typing import Any, Dict, Generic, Iterable, Iterator, List, Optional, Tuple, TypeVar, Union
+
+import torch
+
+TRawDatapoint = TypeVar("TRawDatapoint")
+TTensorizedDatapoint = TypeVar("TTensorizedDatapoint")
+TNeuralModule = TypeVar("TNeuralModule")
+
+
+class AbstractNeuralModel(ABC, Generic[TRawDatapoint, TTensorizedDatapoint, TNeuralModule]):
+    def __init__(self):
+        self.__metadata_initialized = False
+
+    # ---- to be implemented by models ----------------------------------------------------------
+    @abstractmethod
+    def update_metadata_from(self, datapoint) -> None: ...
+
+    def finalize_metadata(self) -> None:
+        pass
+
+    @abstractmethod
+    def build_neural_module(self): ...
+
+    @abstractmethod
+    def tensorize(self, datapoint): ...
+
+    @abstractmethod
+    def initialize_minibatch(self) -> Dict[str, Any]: ...
+
+    @abstractmethod
+    def extend_minibatch_with(self, tensorized_datapoint, partial_minibatch) -> bool: ...
+
+    @abstractmethod
+    def finalize_minibatch(self, accumulated_minibatch_data, device) -> Dict[str, Any]: ...
+
+    # ---- metadata -----------------------------------------------------------------------------
+    def compute_metadata(self, dataset_iterator: Iterable, parallelize: bool = True, show_progress_bar: bool = False) -> None:
+        assert not self.__metadata_initialized, "Metadata has already been initialized."
+        for datapoint in dataset_iterator:
+            if datapoint is not None:
+                self.update_metadata_from(datapoint)
+        self.finalize_metadata()
+        self.__metadata_initialized = True
+
+    # ---- tensorisation / minibatching ---------------------------------------------------------
+    def tensorize_dataset(self, dataset_iterator: Iterable, return_input_data: bool = False, parallelize: bool = False,
+                          num_workers: int = 8) -> Iterator:
+        """Tensorise lazily; samples for which `tensorize` returns None are dropped (reference
+        gnn.py:404-405).  `parallelize` tensorises in worker threads, preserving order."""
+        def one(d):
+            return self.tensorize(d), d
+
+        if parallelize:
+            with ThreadPoolExecutor(max_workers=num_workers) as pool:
+                window: List = []
+                for d in dataset_iterator:
+                    window.append(pool.submit(one, d))
+                    if len(window) >= 4 * num_workers:
+                        t, orig = window.pop(0).result()
+                        if t is not None:
+                            yield (t, orig) if return_input_data else t
+                for f in window:
+                    t, orig = f.result()
+                    if t is not None:
+                        yield (t, orig) if return_input_data else t
+        else:
+            for d in dataset_iterator:
+                t = self.tensorize(d)
+                if t is not None:
+                    yield (t, d) if return_input_data else t
+
+    def minibatch_iterator(self, tensorized_data: Iterable, device: Union[str, torch.device], max_minibatch_size: int,
+                           yield_partial_minibatches: bool = True, parallelize: bool = False) -> Iterator:
+        """Yields `(minibatch dict, [original datapoints])`.  With `parallelize` the next minibatch
+        is collated and copied (pinned, non-blocking) in a background thread while the device
+        works on the current one."""
+        def produce():
+            mb = self.initialize_minibatch()
+            originals: List = []
+            n = 0
+            for item in tensorized_data:
+                t, orig = item if isinstance(item, tuple) and len(item) == 2 and not hasattr(item, "_fields") else (item, None)
+                keep = self.extend_minibatch_with(t, mb)
+                originals.append(orig)
+                n += 1
+                if not keep or n >= max_minibatch_size:
+                    yield self.finalize_minibatch(mb, device), originals
+                    mb, originals, n = self.initialize_minibatch(), [], 0
+            if n > 0 and yield_partial_minibatches:
+                yield self.finalize_minibatch(mb, device), originals
+
+        if not parallelize:
+            yield from produce()
+            return
+        q: "queue.Queue" = queue.Queue(maxsize=2)
+        sentinel = object()
+
+        def worker():
+            try:
+                for x in produce():
+                    q.put(x)
+                q.put(sentinel)
+            except BaseException as e:  # surface collate errors in the consumer
+                q.put(e)
+
+        threading.Thread(target=worker, daemon=True).start()
+        while True:
+            x = q.get()
+            if x is sentinel:
+                return
+            if isinstance(x, BaseException):
+                raise x
+            yield x
+
+    # ---- persistence --------------------------------------------------------------------------
+    def save(self, path: Path, neural_module) -> None:
+        with gzip.open(path, "wb") as f:
+            torch.save((self, neural_module), f)
+
+    @classmethod
+    def restore_model(cls, path: Path, device=None) -> Tuple["AbstractNeuralModel", Any]:
+        with gzip.open(path, "rb") as f:
+            buf = io.BytesIO(f.read())
+        model, nn = torch.load(buf, map_location=device, weights_only=False)
+        if device is not None:
+            nn = nn.to(device)
+        return model, nn

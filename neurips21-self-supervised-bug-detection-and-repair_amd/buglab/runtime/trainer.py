@@ -1,0 +1,202 @@
+"""`ModelTrainer` -- the training loop the reference drives through ptgnn (contract pinned at
+reference buglab/models/train.py:98-134 and buglab/controllers/trainbugdetector.py:73-153): hooks,
+`load_metadata_and_create_network`, `train(..., patience=)`, overridable `_run_validation`, the
+module invoked as `nn(**minibatch)`.
+
+MI355X specifics: one process per GPU; when `torch.distributed` is initialised each rank consumes
+its own share of the tensorised stream, gradients are summed with ONE RCCL all-reduce of the flat
+gradient buffer per step (buglab.runtime.optim.FlatAdam) weighted by B_rank / B_total so the update
+equals the single-process full-minibatch update; only rank 0 saves checkpoints."""
+from __future__ import annotations
+
+import logging
+import time
+from pathlib import Path
+from typing import Callable, Dict, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from buglab.runtime import distributed as D
+from buglab.runtime.optim import FlatAdam
+
+LOGGER = logging.getLogger(__name__)
+
+
+class AbstractScheduler:
+    def step(self, epoch_idx: int, epoch_step: int) -> None:
+        raise NotImplementedError
+
+
+class LazyDataIterable:
+    """iterable-from-callable (reference train.py:76-91)."""
+
+    def __init__(self, base_iterable_func: Callable[[], Iterable]):
+        self._f = base_iterable_func
+
+    def __iter__(self):
+        return iter(self._f())
+
+
+class ModelTrainer:
+    def __init__(self, model, save_location: Path, *, max_num_epochs: int = 100, minibatch_size: int = 200,
+                 optimizer_creator: Optional[Callable] = None, clip_gradient_norm: Optional[float] = None,
+                 scheduler_creator: Optional[Callable] = None, target_validation_metric: Optional[str] = None,
+                 target_validation_metric_higher_is_better: bool = False, enable_amp: bool = False):
+        self.model = model
+        self._save_location = Path(save_location)
+        self._max_num_epochs = max_num_epochs
+        self._minibatch_size = minibatch_size
+        self._optimizer_creator = optimizer_creator or (lambda params: FlatAdam(params))
+        self._clip = clip_gradient_norm
+        self._scheduler_creator = scheduler_creator
+        self._target_metric = target_validation_metric
+        self._target_higher_better = target_validation_metric_higher_is_better
+        if enable_amp:
+            raise NotImplementedError("AMP is out of scope for the fp32-parity HIP path (SURVEY.md section 5)")
+        self._nn = None
+        self._train_epoch_end_hooks: List[Callable] = []
+        self._validation_epoch_end_hooks: List[Callable] = []
+        self._training_start_hooks: List[Callable] = []
+
+    # -- contract ---------------------------------------------------------------------------------
+    @property
+    def neural_module(self):
+        if self._nn is None:
+            raise Exception("Neural module does not exist. Metadata needs to be loaded first.")
+        return self._nn
+
+    @neural_module.setter
+    def neural_module(self, nn):
+        self._nn = nn
+
+    def register_train_epoch_end_hook(self, hook):
+        self._train_epoch_end_hooks.append(hook)
+
+    def register_validation_epoch_end_hook(self, hook):
+        self._validation_epoch_end_hooks.append(hook)
+
+    def register_training_start_hook(self, hook):
+        self._training_start_hooks.append(hook)
+
+    def load_metadata_and_create_network(self, training_data: Iterable, parallelize: bool = True, show_progress_bar: bool = True):
+        self.model.compute_metadata(training_data, parallelize, show_progress_bar)
+        self._nn = self.model.build_neural_module()
+        LOGGER.info("Model has %s trainable parameters.", sum(p.numel() for p in self._nn.parameters() if p.requires_grad))
+
+    # -- helpers ----------------------------------------------------------------------------------
+    @staticmethod
+    def _world():
+        return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+    def _rank_share(self, data: Iterable):
+        rank, world = self._world()
+        if world == 1:
+            yield from data
+            return
+        for i, d in enumerate(data):
+            if i % world == rank:
+                yield d
+
+    def _iter_minibatches(self, data, device, parallelize, shuffle_key=None):
+        tensors = self.model.tensorize_dataset(self._rank_share(data), parallelize=parallelize)
+        for mb, _ in self.model.minibatch_iterator(tensors, device, self._minibatch_size, parallelize=parallelize):
+            yield mb
+
+    @staticmethod
+    def _all_ranks_have(flag: bool, device) -> bool:
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return flag
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def _run_training(self, training_data, epoch, device, optimizer, scheduler, parallelize):
+        nn = self.neural_module
+        nn.train()
+        nn.reset_metrics()
+        it = iter(self._iter_minibatches(training_data, device, parallelize))
+        step, num_graphs, t0 = 0, 0, time.time()
+        while True:
+            mb = next(it, None)
+            if not self._all_ranks_have(mb is not None, device):
+                break
+            optimizer.zero_grad()
+            loss = nn(**mb)
+            loss.backward()
+            B = int(mb["has_bug"].shape[0])
+            optimizer.step(D.global_batch_weight(B, device))
+            if scheduler is not None:
+                scheduler.step(epoch_idx=epoch, epoch_step=step)
+            step += 1
+            num_graphs += B
+        metrics = nn.report_metrics()
+        elapsed = time.time() - t0
+        LOGGER.info("Epoch %s: %s steps, %.1f graphs/s (this rank). Train metrics: %s", epoch, step, num_graphs / max(elapsed, 1e-9), metrics)
+        return metrics
+
+    def _run_validation(self, validation_tensors, epoch, best_target_metric, device, parallelize, show_progress_bar):
+        """-> (target metric, improved?)   (overridden by the reference's detector trainer,
+        trainbugdetector.py:130-143)."""
+        nn = self.neural_module
+        nn.eval()
+        nn.reset_metrics()
+        total, n = torch.zeros((), device=device), 0
+        with torch.no_grad():
+            it = iter(self._iter_minibatches(validation_tensors, device, parallelize))
+            while True:
+                mb = next(it, None)
+                if not self._all_ranks_have(mb is not None, device):
+                    break
+                total += nn(**mb).detach()
+                n += 1
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.stack([total, torch.tensor(float(n), device=device)])
+            dist.all_reduce(t)
+            total, n = t[0], int(t[1].item())
+        metrics = nn.report_metrics()
+        val_loss = float(total) / max(n, 1)
+        for hook in self._validation_epoch_end_hooks:
+            hook(self.model, nn, epoch, metrics)
+        if self._target_metric is not None:
+            target = metrics[self._target_metric]
+            improved = target > best_target_metric if self._target_higher_better else target < best_target_metric
+        else:
+            target, improved = val_loss, val_loss < best_target_metric
+        LOGGER.info("Epoch %s: validation loss %.5f. Metrics: %s", epoch, val_loss, metrics)
+        return target, improved
+
+    def train(self, training_data: Iterable, validation_data: Iterable, *, show_progress_bar: bool = True,
+              initialize_metadata: bool = True, parallelize: bool = True, use_multiprocessing: bool = False, patience: int = 5,
+              device=None):
+        if initialize_metadata:
+            self.load_metadata_and_create_network(training_data, parallelize, show_progress_bar)
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("ModelTrainer.train: no ROCm GPU visible; the BugLab hot path has no CPU fallback")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._nn = self.neural_module.to(device)
+        optimizer = self._optimizer_creator(self._nn.parameters())
+        if self._clip is not None and hasattr(optimizer, "clip"):
+            optimizer.clip = self._clip
+        scheduler = self._scheduler_creator(optimizer) if self._scheduler_creator is not None else None
+        for hook in self._training_start_hooks:
+            hook(self.model, self._nn, optimizer)
+        rank, _ = self._world()
+        best = float("-inf") if (self._target_metric is not None and self._target_higher_better) else float("inf")
+        bad_epochs = 0
+        for epoch in range(self._max_num_epochs):
+            metrics = self._run_training(training_data, epoch, device, optimizer, scheduler, parallelize)
+            for hook in self._train_epoch_end_hooks:
+                hook(self.model, self._nn, epoch, metrics)
+            target, improved = self._run_validation(validation_data, epoch, best, device, parallelize, show_progress_bar)
+            if improved:
+                best, bad_epochs = target, 0
+                if rank == 0:
+                    self.model.save(self._save_location, self._nn)
+            else:
+                bad_epochs += 1
+                if bad_epochs >= patience:
+                    LOGGER.warning("After %s epochs loss has not improved. Stopping.", bad_epochs)
+                    break
+        return best

@@ -1,0 +1,92 @@
+// Shared device/host helpers for libbuglab_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/buglab_hip.h"
+
+#define BL_WAVE 64
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void bl_set_error(const char* fmt, ...);
+#define BL_CHECK_ARG(cond, ...)   \
+  do {                            \
+    if (!(cond)) {                \
+      bl_set_error(__VA_ARGS__);  \
+      return BL_EINVAL;           \
+    }                             \
+  } while (0)
+#define BL_LAUNCH_CHECK(name)                                            \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      bl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return (int)e_;                                                    \
+    }                                                                    \
+  } while (0)
+
+static inline bool bl_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- counter-based dropout: identical to oracle/buglab_oracle.py::dropout_keep_mask -----------
+__host__ __device__ static inline uint32_t bl_lowbias32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+struct bl_drop_dev {  // what kernels receive
+  uint32_t key;
+  uint32_t thresh;  // keep iff (hash >> 8) >= thresh ; thresh == 0 -> dropout off
+  float scale;
+};
+static inline bl_drop_dev bl_make_drop(bl_dropout_t d) {
+  bl_drop_dev r;
+  r.key = bl_lowbias32(d.seed ^ (d.stream * 0x9E3779B9u));
+  r.thresh = (d.p > 0.f) ? (uint32_t)(d.p * 16777216.0f) : 0u;
+  r.scale = (d.p > 0.f) ? 1.0f / (1.0f - d.p) : 1.0f;
+  return r;
+}
+__device__ __forceinline__ bool bl_keep(const bl_drop_dev& d, uint32_t idx) {
+  return (bl_lowbias32(idx + d.key) >> 8) >= d.thresh;
+}
+
+// ---- activations ------------------------------------------------------------------------------
+__device__ __forceinline__ float bl_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float bl_gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float bl_act(int act, float x) {
+  switch (act) {
+    case BL_ACT_RELU: return x > 0.f ? x : 0.f;
+    case BL_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case BL_ACT_TANH: return tanhf(x);
+    case BL_ACT_GELU: return bl_gelu(x);
+    default: return x;
+  }
+}
+// derivative expressed through the OUTPUT y = act(z) (relu / sigmoid / tanh / none)
+__device__ __forceinline__ float bl_act_grad_from_out(int act, float y) {
+  switch (act) {
+    case BL_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case BL_ACT_SIGMOID: return y * (1.f - y);
+    case BL_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+// ---- wave-level reductions (64 lanes) -----------------------------------------------------------
+__device__ __forceinline__ float bl_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float bl_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

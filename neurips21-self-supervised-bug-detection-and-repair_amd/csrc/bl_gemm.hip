@@ -1,0 +1,409 @@
+// Grouped, gathered fp32 GEMMs on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// bitwise an fmaf chain, 157 TF/s chip peak).  Two kernels cover every dense contraction on the
+// BugLab hot path:
+//
+//   gemm_rows_kernel   C[r, :] = act(rows(A)[r, :] . B_g + bias)   one B_g per row group (edge type)
+//                      (forward messages, dense node update, heads; with B used transposed it is
+//                       the input-gradient GEMM)
+//   gemm_wgrad_kernel  gW_g += rows(A)[rows of g]^T . G[rows of g]  (reduction over rows, split
+//                      in chunks, fp32 atomics)
+//
+// Tiling (both): 128 x 128 output tile per 256-thread workgroup = 4 waves in a 2 x 2 grid, each
+// wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs); BK = 32 per LDS stage,
+// register prefetch of the next stage while the current one is multiplied, 2 workgroups per CU.
+// At fp32 one MFMA occupies its SIMD for 64 cycles, so LDS/L2 traffic per flop is tiny compared
+// with a bf16 kernel: the design goal is simply to keep all four matrix pipes issuing.
+//
+// Operand images in LDS:
+//   "MN-major"  [128 rows][36]   (32 k's + 4 pad): rows are gathered global rows (k contiguous);
+//               fragment = ONE ds_read_b128 per lane = 4 MFMA k-steps; stride 36 floats makes both the
+//               b128 writes (8-lane groups) and the b128 reads (rows distinct mod 16) conflict-free.
+//   "K-major"   [32 k][128]      global rows are k-lines (n contiguous); fragment = 4 ds_read_b32,
+//               lanes 0-31 read 32 consecutive floats -> conflict-free.
+// MFMA k-assignment inside a group of 8 k's: lanes 0-31 take k = 8q+s, lanes 32-63 take k = 8q+4+s
+// (s = 0..3 are four consecutive MFMAs); A and B use the same assignment so the contraction is
+// complete whatever the order.
+#include "bl_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDS_MN 36
+#define LDS_K 128
+
+// Row sources are passed as individual scalar kernel parameters (macro below) and selected with
+// value selects: arrays (or select-of-adjacent-fields) inside a by-value kernel argument make hipcc
+// copy the whole argument block to scratch and index it there.
+struct RowsDev {  // host-side staging only
+  const float *x0, *x1, *x2;
+  const int *idx0, *idx1, *idx2;
+  int ld0, ld1, ld2;
+  int koff1, koff2;  // first k of source 1 / 2 (source 0 starts at 0)
+  int nsrc;
+};
+#define ROWS_PARAMS                                                                                         \
+  const float *__restrict__ x0, const float *__restrict__ x1, const float *__restrict__ x2,                \
+      const int *__restrict__ idx0, const int *__restrict__ idx1, const int *__restrict__ idx2, int ld0,   \
+      int ld1, int ld2, int koff1, int koff2, int nsrc
+#define ROWS_ARGS(d) d.x0, d.x1, d.x2, d.idx0, d.idx1, d.idx2, d.ld0, d.ld1, d.ld2, d.koff1, d.koff2, d.nsrc
+
+// locate the (group, first row, row count) of tile `t` when every group is cut in pieces of `piece`
+__device__ __forceinline__ bool find_piece(const int* __restrict__ group_ptr, int G, int M, int piece, int t, int& g,
+                                           int& row0, int& nrows) {
+  if (group_ptr == nullptr) {
+    g = 0;
+    row0 = t * piece;
+    if (row0 >= M) return false;
+    nrows = min(piece, M - row0);
+    return true;
+  }
+  for (g = 0; g < G; ++g) {
+    const int lo = group_ptr[g], hi = group_ptr[g + 1];
+    const int nt = (hi - lo + piece - 1) / piece;
+    if (t < nt) {
+      row0 = lo + t * piece;
+      nrows = min(piece, hi - row0);
+      return true;
+    }
+    t -= nt;
+  }
+  return false;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) { return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// one MFMA k-group (8 k's) for the 2 x 2 tiles of a wave
+__device__ __forceinline__ void mfma_group(const float (&a_)[2][4], const float (&b_)[2][4], f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[ti][s], b_[tj][s], acc[ti][tj], 0, 0, 0);
+}
+
+template <bool B_NK, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(ROWS_PARAMS, const float* __restrict__ b, long long strideB,
+                                                           int ldb, const float* __restrict__ bias,
+                                                           const int* __restrict__ group_ptr,
+                                                           const int* __restrict__ group_w, int G, int M, int N, int K,
+                                                           uint32_t drop_key, uint32_t drop_thresh, float drop_scale,
+                                                           float* __restrict__ c, int ldc) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_MN];
+  __shared__ __attribute__((aligned(16))) float Bs[B_NK ? BN * LDS_MN : BK * LDS_K];
+  __shared__ int rowidx[3][BM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int g, row0, nrows;
+  if (!find_piece(group_ptr, G, M, BM, blockIdx.x, g, row0, nrows)) return;
+  const int n0 = blockIdx.y * BN;
+  const int wsel = group_w ? group_w[g] : g;
+  const float* __restrict__ Bg = b + (long long)wsel * strideB;
+
+  if (tid < BM) {
+    const int r = row0 + min(tid, nrows - 1);  // rows past the group end re-read its last row (never stored)
+    rowidx[0][tid] = idx0 ? idx0[r] : r;
+    if (nsrc > 1) rowidx[1][tid] = idx1 ? idx1[r] : r;
+    if (nsrc > 2) rowidx[2][tid] = idx2 ? idx2[r] : r;
+  }
+  __syncthreads();
+
+  float4 ra[4], rb[4];
+  const int a_c4 = tid & 7, a_line0 = tid >> 3;   // MN-major loader: 8 lanes per 128-byte line
+  const int k_c4 = tid & 31, k_line0 = tid >> 5;  // K-major loader: 32 lanes per 512-byte line
+  const int nk = (K + BK - 1) / BK;
+
+#define ROWS_LOAD_STAGE(k0_)                                                                              \
+  {                                                                                                       \
+    const int k_ = (k0_) + 4 * a_c4;                                                                      \
+    const bool kok_ = k_ < K;                                                                             \
+    const int kc_ = kok_ ? k_ : 0;                                                                        \
+    int j_ = 0;                                                                                           \
+    if (nsrc > 1 && kc_ >= koff1) j_ = 1;                                                                 \
+    if (nsrc > 2 && kc_ >= koff2) j_ = 2;                                                                 \
+    const int kl_ = kc_ - (j_ == 0 ? 0 : (j_ == 1 ? koff1 : koff2));                                      \
+    const float* base_ = j_ == 0 ? x0 : (j_ == 1 ? x1 : x2);                                              \
+    const int ld_ = j_ == 0 ? ld0 : (j_ == 1 ? ld1 : ld2);                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+      const int line_ = a_line0 + 32 * i;                                                                 \
+      ra[i] = sel4(kok_, ld4(base_ + (size_t)rowidx[j_][line_] * ld_ + kl_));                             \
+    }                                                                                                     \
+    if (!B_NK) {                                                                                          \
+      const int n_ = n0 + 4 * k_c4;                                                                       \
+      const int nc_ = n_ < N ? n_ : 0;                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        const int kk_ = (k0_) + k_line0 + 8 * i;                                                          \
+        const int kkc_ = kk_ < K ? kk_ : 0;                                                               \
+        rb[i] = sel4(n_ < N && kk_ < K, ld4(Bg + (size_t)kkc_ * ldb + nc_));                              \
+      }                                                                                                   \
+    } else {                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        const int n_ = n0 + a_line0 + 32 * i;                                                             \
+        const int nc_ = n_ < N ? n_ : 0;                                                                  \
+        rb[i] = sel4(n_ < N && kok_, ld4(Bg + (size_t)nc_ * ldb + kc_));                                  \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+#define ROWS_STORE_STAGE()                                                                   \
+  {                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+      *reinterpret_cast<float4*>(&As[(a_line0 + 32 * i) * LDS_MN + 4 * a_c4]) = ra[i];       \
+      if (!B_NK)                                                                             \
+        *reinterpret_cast<float4*>(&Bs[(k_line0 + 8 * i) * LDS_K + 4 * k_c4]) = rb[i];       \
+      else                                                                                   \
+        *reinterpret_cast<float4*>(&Bs[(a_line0 + 32 * i) * LDS_MN + 4 * a_c4]) = rb[i];     \
+    }                                                                                        \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, half = lane >> 5;
+
+  ROWS_LOAD_STAGE(0)
+  ROWS_STORE_STAGE()
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) ROWS_LOAD_STAGE((kt + 1) * BK)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a_[2][4], b_[2][4];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        const float4 v = *reinterpret_cast<const float4*>(&As[(wm * 64 + ti * 32 + li) * LDS_MN + 8 * q + 4 * half]);
+        a_[ti][0] = v.x; a_[ti][1] = v.y; a_[ti][2] = v.z; a_[ti][3] = v.w;
+      }
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        if (!B_NK) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b_[tj][s] = Bs[(8 * q + 4 * half + s) * LDS_K + wn * 64 + tj * 32 + li];
+        } else {
+          const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + tj * 32 + li) * LDS_MN + 8 * q + 4 * half]);
+          b_[tj][0] = v.x; b_[tj][1] = v.y; b_[tj][2] = v.z; b_[tj][3] = v.w;
+        }
+      }
+      mfma_group(a_, b_, acc);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      ROWS_STORE_STAGE()
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int n = n0 + wn * 64 + tj * 32 + li;
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < nrows) {
+          float v = bl_act(ACT, acc[ti][tj][r] + bv);
+          if (drop_thresh) {
+            const uint32_t idx = (uint32_t)(row0 + m) * (uint32_t)N + (uint32_t)n;
+            v = ((bl_lowbias32(idx + drop_key) >> 8) >= drop_thresh) ? v * drop_scale : 0.f;
+          }
+          c[(size_t)(row0 + m) * ldc + n] = v;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(ROWS_PARAMS, const float* __restrict__ gc, int ldg,
+                                                            const int* __restrict__ group_ptr,
+                                                            const int* __restrict__ group_w, int G, int M, int N, int K,
+                                                            int kchunk, float* __restrict__ gw_base, long long strideW,
+                                                            int ldw, int ntiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDS_K];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_K];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int g, e0, ne;
+  if (!find_piece(group_ptr, G, M, kchunk, blockIdx.x, g, e0, ne)) return;
+  const int e1 = e0 + ne;
+  const int i0 = (blockIdx.y / ntiles_n) * BM;
+  const int n0 = (blockIdx.y % ntiles_n) * BN;
+  const int wsel = group_w ? group_w[g] : g;
+
+  float4 ra[4], rb[4];
+  const int c4 = tid & 31, line0 = tid >> 5;
+  const int fi = i0 + 4 * c4;  // this thread's feature columns of the A rows
+  const int nn = n0 + 4 * c4;  // this thread's columns of the G rows
+  const bool a_ok = fi < K, b_ok = nn < N;
+  const int fic = a_ok ? fi : 0, nnc = b_ok ? nn : 0;
+  int aj = 0;
+  if (nsrc > 1 && fic >= koff1) aj = 1;
+  if (nsrc > 2 && fic >= koff2) aj = 2;
+  const int akl = fic - (aj == 0 ? 0 : (aj == 1 ? koff1 : koff2));
+  const float* __restrict__ abase = aj == 0 ? x0 : (aj == 1 ? x1 : x2);
+  const int* __restrict__ aidx = aj == 0 ? idx0 : (aj == 1 ? idx1 : idx2);
+  const int ald = aj == 0 ? ld0 : (aj == 1 ? ld1 : ld2);
+
+#define WGRAD_LOAD_STAGE(k0_)                                                       \
+  {                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                 \
+      const int e_ = (k0_) + line0 + 8 * i;                                         \
+      const bool eok_ = e_ < e1;                                                    \
+      const int ec_ = eok_ ? e_ : e0;                                               \
+      const int row_ = aidx ? aidx[ec_] : ec_;                                      \
+      ra[i] = sel4(eok_ && a_ok, ld4(abase + (size_t)row_ * ald + akl));            \
+      rb[i] = sel4(eok_ && b_ok, ld4(gc + (size_t)ec_ * ldg + nnc));                \
+    }                                                                               \
+  }
+#define WGRAD_STORE_STAGE()                                                          \
+  {                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
+      *reinterpret_cast<float4*>(&As[(line0 + 8 * i) * LDS_K + 4 * c4]) = ra[i];     \
+      *reinterpret_cast<float4*>(&Bs[(line0 + 8 * i) * LDS_K + 4 * c4]) = rb[i];     \
+    }                                                                                \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, half = lane >> 5;
+  const int nk = (ne + BK - 1) / BK;
+
+  WGRAD_LOAD_STAGE(e0)
+  WGRAD_STORE_STAGE()
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) WGRAD_LOAD_STAGE(e0 + (kt + 1) * BK)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a_[2][4], b_[2][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = 8 * q + 4 * half + s;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) a_[ti][s] = As[kk * LDS_K + wm * 64 + ti * 32 + li];
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) b_[tj][s] = Bs[kk * LDS_K + wn * 64 + tj * 32 + li];
+      }
+      mfma_group(a_, b_, acc);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      WGRAD_STORE_STAGE()
+      __syncthreads();
+    }
+  }
+
+  float* __restrict__ gw = gw_base + (long long)wsel * strideW;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int n = n0 + wn * 64 + tj * 32 + li;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = i0 + wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (f < K) unsafeAtomicAdd(&gw[(size_t)f * ldw + n], acc[ti][tj][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int fill_rows(const bl_rows_t* a, RowsDev& d, int& K, const char* who) {
+  BL_CHECK_ARG(a != nullptr && a->nsrc >= 1 && a->nsrc <= 3, "%s: rows descriptor needs 1..3 sources", who);
+  int off = 0, koff[4] = {0, 0, 0, 0};
+  for (int j = 0; j < a->nsrc; ++j) {
+    BL_CHECK_ARG(a->x[j] != nullptr && bl_aligned16(a->x[j]), "%s: source %d null or not 16-byte aligned", who, j);
+    BL_CHECK_ARG(a->width[j] > 0 && a->width[j] % 4 == 0 && a->ld[j] % 4 == 0 && a->ld[j] >= a->width[j],
+                 "%s: source %d width/ld must be multiples of 4 floats (width %d ld %d)", who, j, a->width[j], a->ld[j]);
+    koff[j] = off;
+    off += a->width[j];
+  }
+  d.x0 = a->x[0];
+  d.idx0 = a->idx[0];
+  d.ld0 = a->ld[0];
+  d.x1 = a->nsrc > 1 ? a->x[1] : nullptr;
+  d.idx1 = a->nsrc > 1 ? a->idx[1] : nullptr;
+  d.ld1 = a->nsrc > 1 ? a->ld[1] : 0;
+  d.x2 = a->nsrc > 2 ? a->x[2] : nullptr;
+  d.idx2 = a->nsrc > 2 ? a->idx[2] : nullptr;
+  d.ld2 = a->nsrc > 2 ? a->ld[2] : 0;
+  d.koff1 = koff[1];
+  d.koff2 = koff[2];
+  d.nsrc = a->nsrc;
+  K = off;
+  return BL_OK;
+}
+
+extern "C" int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_stride, int32_t ldb, int32_t b_is_nk,
+                            const float* bias, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
+                            int32_t N, int32_t K, int32_t act, bl_dropout_t drop, float* c, int32_t ldc, void* stream) {
+  if (M == 0) return BL_OK;
+  RowsDev d;
+  int Ksum = 0;
+  int rc = fill_rows(a, d, Ksum, "bl_gemm_rows");
+  if (rc) return rc;
+  BL_CHECK_ARG(Ksum == K, "bl_gemm_rows: K (%d) != sum of source widths (%d)", K, Ksum);
+  BL_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0, "bl_gemm_rows: M>0, N/ldb/ldc multiples of 4 required");
+  BL_CHECK_ARG(b && c && bl_aligned16(b) && bl_aligned16(c), "bl_gemm_rows: b/c null or misaligned");
+  BL_CHECK_ARG(group_ptr == nullptr || G >= 1, "bl_gemm_rows: G must be >= 1 with group_ptr");
+  BL_CHECK_ARG((uint64_t)M * (uint64_t)N < (1ull << 32) || drop.p <= 0.f, "bl_gemm_rows: dropout index space is 32 bit");
+  const bl_drop_dev dd = bl_make_drop(drop);
+  dim3 grid((M + BM - 1) / BM + (group_ptr ? G : 0), (N + BN - 1) / BN);
+  hipStream_t st = (hipStream_t)stream;
+#define ROWS_LAUNCH ROWS_ARGS(d), b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc
+  if (b_is_nk) {
+    BL_CHECK_ARG(act == BL_ACT_NONE, "bl_gemm_rows: the transposed-B (input gradient) form takes no activation");
+    hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE>), grid, dim3(256), 0, st, ROWS_LAUNCH);
+  } else {
+    switch (act) {
+      case BL_ACT_NONE: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_NONE>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
+      case BL_ACT_RELU: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_RELU>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
+      case BL_ACT_SIGMOID: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_SIGMOID>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
+      case BL_ACT_TANH: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_TANH>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
+      case BL_ACT_GELU: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_GELU>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
+      default: BL_CHECK_ARG(false, "bl_gemm_rows: unknown activation %d", act);
+    }
+  }
+  BL_LAUNCH_CHECK("bl_gemm_rows");
+  return BL_OK;
+}
+
+extern "C" int bl_gemm_wgrad(const bl_rows_t* a, const float* g_c, int32_t ld_g, const int32_t* group_ptr,
+                             const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
+                             int64_t gw_group_stride, int32_t ld_gw, void* stream) {
+  if (M == 0) return BL_OK;
+  RowsDev d;
+  int Ksum = 0;
+  int rc = fill_rows(a, d, Ksum, "bl_gemm_wgrad");
+  if (rc) return rc;
+  BL_CHECK_ARG(Ksum == K, "bl_gemm_wgrad: K (%d) != sum of source widths (%d)", K, Ksum);
+  BL_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && ld_g % 4 == 0, "bl_gemm_wgrad: N/ld_g multiples of 4 required");
+  BL_CHECK_ARG(g_c && gw && bl_aligned16(g_c), "bl_gemm_wgrad: g_c/gw null or misaligned");
+  // chunk of rows reduced by one workgroup: large enough to amortise the 128x128 atomic epilogue,
+  // small enough that >= ~1000 workgroups exist at minibatch sizes
+  int kchunk = 2048;
+  while (kchunk > 256 && (M / kchunk) * ((K + BM - 1) / BM) * ((N + BN - 1) / BN) < 1024) kchunk >>= 1;
+  const int ntiles_n = (N + BN - 1) / BN;
+  dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ((K + BM - 1) / BM) * ntiles_n);
+  hipLaunchKernelGGL(gemm_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, ROWS_ARGS(d), g_c, ld_g, group_ptr,
+                     group_w, G, M, N, K, kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n);
+  BL_LAUNCH_CHECK("bl_gemm_wgrad");
+  return BL_OK;
+}

@@ -1,0 +1,406 @@
+// HBM-bound graph kernels of the message-passing layer: subtoken embedder, segmented max (+argmax,
+// +fused LayerNorm), its gather-form backward, LayerNorm backward, activation/dropout backward and
+// the deterministic segmented sums that turn per-message input gradients into node gradients.
+//
+// Common shape: ONE WAVE (64 lanes) PER SEGMENT / ROW.  A row of D <= 512 floats is spread over the
+// lanes as d = lane + 64 * j (j < NV): every load instruction of the wave covers 256 contiguous
+// bytes, row statistics are wave reductions (no LDS, no barriers), and the CSR item ids of a
+// segment are fetched 64 at a time with one coalesced load and handed out with v_readlane.
+#include "bl_common.h"
+
+#define NEG_INF (-__builtin_huge_valf())
+
+// ------------------------------------------------------------------------------------------------
+// M0 embedder
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, int H,
+                                                        const int* __restrict__ ids, const int* __restrict__ lens,
+                                                        int N, int S, bl_drop_dev drop, float* __restrict__ out,
+                                                        int ld_out, int8_t* __restrict__ argsub) {
+  const int h4n = H >> 2;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * h4n) return;
+  const int n = (int)(t / h4n), h = (int)(t % h4n) * 4;
+  int len = lens[n];
+  len = len < 1 ? 1 : (len > S ? S : len);
+  float4 best = *reinterpret_cast<const float4*>(table + (size_t)ids[(size_t)n * S] * H + h);
+  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int s = 1; s < len; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(table + (size_t)ids[(size_t)n * S + s] * H + h);
+    if (v.x > best.x) { best.x = v.x; a0 = s; }
+    if (v.y > best.y) { best.y = v.y; a1 = s; }
+    if (v.z > best.z) { best.z = v.z; a2 = s; }
+    if (v.w > best.w) { best.w = v.w; a3 = s; }
+  }
+  if (drop.thresh) {
+    const uint32_t i = (uint32_t)n * (uint32_t)H + (uint32_t)h;
+    best.x = bl_keep(drop, i) ? best.x * drop.scale : 0.f;
+    best.y = bl_keep(drop, i + 1) ? best.y * drop.scale : 0.f;
+    best.z = bl_keep(drop, i + 2) ? best.z * drop.scale : 0.f;
+    best.w = bl_keep(drop, i + 3) ? best.w * drop.scale : 0.f;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)n * ld_out + h) = best;
+  char4 a;
+  a.x = (char)a0; a.y = (char)a1; a.z = (char)a2; a.w = (char)a3;
+  *reinterpret_cast<char4*>(argsub + (size_t)n * H + h) = a;
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g_out, int ld_g,
+                                                        const int* __restrict__ ids,
+                                                        const int8_t* __restrict__ argsub, int N, int S, int H,
+                                                        bl_drop_dev drop, float* __restrict__ g_table) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * H) return;
+  const int n = (int)(t / H), h = (int)(t % H);
+  float g = g_out[(size_t)n * ld_g + h];
+  if (drop.thresh) g = bl_keep(drop, (uint32_t)n * (uint32_t)H + (uint32_t)h) ? g * drop.scale : 0.f;
+  if (g != 0.f) {
+    const int s = argsub[(size_t)n * H + h];
+    unsafeAtomicAdd(&g_table[(size_t)ids[(size_t)n * S + s] * H + h], g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// M2 (+ LayerNorm of M3): segmented max with argmax, one wave per segment
+template <int NV, bool HAS_LN>
+__global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ x, int ldx,
+                                                          const int* __restrict__ seg_ptr,
+                                                          const int* __restrict__ seg_items, int nseg, int D, int act,
+                                                          float* __restrict__ out, int* __restrict__ arg,
+                                                          const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                          float eps, float* __restrict__ ln_out,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (seg >= nseg) return;
+  const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
+  float best[NV];
+  int barg[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; }
+
+  for (int base = beg; base < end; base += 64) {
+    const int cnt = min(64, end - base);
+    const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
+#pragma unroll 4
+    for (int i = 0; i < cnt; ++i) {
+      const int e = __shfl(mine, i, 64);
+      const float* __restrict__ row = x + (size_t)e * ldx;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int d = lane + 64 * j;
+        if (d < D) {
+          float v = row[d];
+          if (act == BL_ACT_GELU) v = bl_gelu(v);
+          if (v > best[j]) { best[j] = v; barg[j] = e; }
+        }
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int d = lane + 64 * j;
+    if (barg[j] < 0) best[j] = 0.f;  // empty segment (torch_scatter leaves 0) or padding lane
+    if (d < D) {
+      out[(size_t)seg * D + d] = best[j];
+      arg[(size_t)seg * D + d] = barg[j];
+      s += best[j];
+    }
+  }
+  if (HAS_LN) {
+    const float mean = bl_wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int d = lane + 64 * j;
+      if (d < D) { const float c = best[j] - mean; q += c * c; }
+    }
+    const float rstd = rsqrtf(bl_wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int d = lane + 64 * j;
+      if (d < D) ln_out[(size_t)seg * D + d] = (best[j] - mean) * rstd * ln_g[d] + ln_b[d];
+    }
+    if (lane == 0) { mean_out[seg] = mean; rstd_out[seg] = rstd; }
+  }
+}
+
+// backward of the segmented max in gather form: each item row looks up its segment's argmax
+__global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __restrict__ g_out,
+                                                              const int* __restrict__ arg, const float* x, int ldx,
+                                                              const int* __restrict__ seg_of, long long nitems, int D,
+                                                              int act, float* g_x) {
+  const int d4n = D >> 2;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nitems * d4n) return;
+  const int i = (int)(t / d4n), d = (int)(t % d4n) * 4;
+  const int seg = seg_of[i];
+  const int4 a = *reinterpret_cast<const int4*>(arg + (size_t)seg * D + d);
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.x == i || a.y == i || a.z == i || a.w == i) {
+    const float4 go = *reinterpret_cast<const float4*>(g_out + (size_t)seg * D + d);
+    float4 dv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (act == BL_ACT_GELU) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)i * ldx + d);
+      dv.x = bl_gelu_grad(xv.x); dv.y = bl_gelu_grad(xv.y); dv.z = bl_gelu_grad(xv.z); dv.w = bl_gelu_grad(xv.w);
+    }
+    g.x = a.x == i ? go.x * dv.x : 0.f;
+    g.y = a.y == i ? go.y * dv.y : 0.f;
+    g.z = a.z == i ? go.z * dv.z : 0.f;
+    g.w = a.w == i ? go.w * dv.w : 0.f;
+  }
+  *reinterpret_cast<float4*>(g_x + (size_t)i * ldx + d) = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row (grid-stride), column sums reduced per block then atomics
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g_y, const float* __restrict__ x,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, int nrows, int D,
+                                                            float* __restrict__ g_x, float* __restrict__ g_gamma,
+                                                            float* __restrict__ g_beta) {
+  __shared__ float red[2][4][64 * NV];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = gridDim.x * 4;
+  float dg[NV], db[NV], gam[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    dg[j] = 0.f; db[j] = 0.f;
+    const int d = lane + 64 * j;
+    gam[j] = d < D ? gamma[d] : 0.f;
+  }
+  const float invD = 1.0f / (float)D;
+  for (int r = blockIdx.x * 4 + w; r < nrows; r += nw) {
+    const float mu = mean[r], rs = rstd[r];
+    float gy[NV], xh[NV];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int d = lane + 64 * j;
+      if (d < D) {
+        gy[j] = g_y[(size_t)r * D + d];
+        xh[j] = (x[(size_t)r * D + d] - mu) * rs;
+      } else { gy[j] = 0.f; xh[j] = 0.f; }
+      const float gg = gy[j] * gam[j];
+      a += gg; b += gg * xh[j];
+      dg[j] += gy[j] * xh[j]; db[j] += gy[j];
+    }
+    a = bl_wave_sum(a) * invD;
+    b = bl_wave_sum(b) * invD;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int d = lane + 64 * j;
+      if (d < D) g_x[(size_t)r * D + d] = rs * (gy[j] * gam[j] - a - xh[j] * b);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { red[0][w][lane + 64 * j] = dg[j]; red[1][w][lane + 64 * j] = db[j]; }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    unsafeAtomicAdd(&g_gamma[d], red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
+    unsafeAtomicAdd(&g_beta[d], red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward through y = drop(act(z + bias)) from y; column sums -> g_bias
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const float* __restrict__ y, int nrows, int N,
+                                                      int ld, int act, bl_drop_dev drop, float* g_z,
+                                                      float* __restrict__ g_bias) {
+  __shared__ float4 red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = (blockIdx.y * 64 + tx) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < N) {
+    const int r_end = min(nrows, (int)(blockIdx.x + 1) * 64);
+    for (int r = blockIdx.x * 64 + ty; r < r_end; r += 4) {
+      const size_t o = (size_t)r * ld + c;
+      float4 g = *reinterpret_cast<const float4*>(g_y + o);
+      const float4 yv = *reinterpret_cast<const float4*>(y + o);
+      float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+      float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float yu = yy[u];
+        if (drop.thresh) {
+          const bool keep = bl_keep(drop, (uint32_t)r * (uint32_t)N + (uint32_t)(c + u));
+          gg[u] = keep ? gg[u] * drop.scale : 0.f;
+          yu = yu * (1.0f / drop.scale);  // undo the dropout scale to recover act(z)
+        }
+        gg[u] *= bl_act_grad_from_out(act, yu);
+      }
+      g = make_float4(gg[0], gg[1], gg[2], gg[3]);
+      *reinterpret_cast<float4*>(g_z + o) = g;
+      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    }
+  }
+  if (g_bias) {
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < N) {
+      const float4 a = red[0][tx], b = red[1][tx], cc = red[2][tx], d = red[3][tx];
+      unsafeAtomicAdd(&g_bias[c + 0], a.x + b.x + cc.x + d.x);
+      unsafeAtomicAdd(&g_bias[c + 1], a.y + b.y + cc.y + d.y);
+      unsafeAtomicAdd(&g_bias[c + 2], a.z + b.z + cc.z + d.z);
+      unsafeAtomicAdd(&g_bias[c + 3], a.w + b.w + cc.w + d.w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node gradient = segmented sums of per-message input gradients over the source and target CSRs
+template <int NV>
+__global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __restrict__ g_a, int ld_ga,
+                                                              const int* __restrict__ src_ptr,
+                                                              const int* __restrict__ src_msgs,
+                                                              const int* __restrict__ tgt_ptr,
+                                                              const int* __restrict__ tgt_msgs, int N, int Din,
+                                                              int accumulate, float* __restrict__ g_h, int ld_gh) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int d = lane + 64 * j;
+    acc[j] = (accumulate && d < Din) ? g_h[(size_t)n * ld_gh + d] : 0.f;
+  }
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+    const int* __restrict__ ptr = part == 0 ? src_ptr : tgt_ptr;
+    const int* __restrict__ items = part == 0 ? src_msgs : tgt_msgs;
+    const int coff = part == 0 ? 0 : Din;
+    const int beg = ptr[n], end = ptr[n + 1];
+    for (int base = beg; base < end; base += 64) {
+      const int cnt = min(64, end - base);
+      const int mine = lane < cnt ? items[base + lane] : 0;
+#pragma unroll 4
+      for (int i = 0; i < cnt; ++i) {
+        const int e = __shfl(mine, i, 64);
+        const float* __restrict__ row = g_a + (size_t)e * ld_ga + coff;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int d = lane + 64 * j;
+          if (d < Din) acc[j] += row[d];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int d = lane + 64 * j;
+    if (d < Din) g_h[(size_t)n * ld_gh + d] = acc[j];
+  }
+}
+
+// ================================================================================================
+// C ABI
+#define DISPATCH_NV(D, ...)                                        \
+  if ((D) <= 64) { constexpr int NV = 1; __VA_ARGS__; }            \
+  else if ((D) <= 128) { constexpr int NV = 2; __VA_ARGS__; }      \
+  else if ((D) <= 256) { constexpr int NV = 4; __VA_ARGS__; }      \
+  else { constexpr int NV = 8; __VA_ARGS__; }
+
+extern "C" int bl_embed_subtoken_max_fwd(const float* table, int32_t V, int32_t H, const int32_t* ids,
+                                         const int32_t* lens, int32_t N, int32_t S, bl_dropout_t drop, float* out,
+                                         int32_t ld_out, int8_t* argsub, void* stream) {
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(table && ids && lens && out && argsub, "bl_embed_subtoken_max_fwd: null pointer");
+  BL_CHECK_ARG(H > 0 && H % 4 == 0 && ld_out % 4 == 0 && S >= 1 && S <= 127 && V > 0, "bl_embed_subtoken_max_fwd: H %% 4, 1 <= S <= 127");
+  BL_CHECK_ARG(bl_aligned16(table) && bl_aligned16(out), "bl_embed_subtoken_max_fwd: misaligned");
+  const long long total = (long long)N * (H / 4);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, H,
+                     ids, lens, N, S, bl_make_drop(drop), out, ld_out, argsub);
+  BL_LAUNCH_CHECK("bl_embed_subtoken_max_fwd");
+  return BL_OK;
+}
+
+extern "C" int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const int32_t* ids, const int8_t* argsub,
+                                         int32_t N, int32_t S, int32_t H, int32_t V, bl_dropout_t drop, float* g_table,
+                                         void* stream) {
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(g_out && ids && argsub && g_table && V > 0, "bl_embed_subtoken_max_bwd: null pointer");
+  const long long total = (long long)N * H;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out,
+                     ld_g, ids, argsub, N, S, H, bl_make_drop(drop), g_table);
+  BL_LAUNCH_CHECK("bl_embed_subtoken_max_bwd");
+  return BL_OK;
+}
+
+extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items,
+                                  int32_t nseg, int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g,
+                                  const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, void* stream) {
+  if (nseg == 0) return BL_OK;
+  BL_CHECK_ARG(seg_ptr && out && arg, "bl_segment_max_fwd: null pointer");
+  BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
+  BL_CHECK_ARG(act == BL_ACT_NONE || act == BL_ACT_GELU, "bl_segment_max_fwd: act must be NONE or GELU");
+  const bool has_ln = ln_g != nullptr;
+  BL_CHECK_ARG(!has_ln || (ln_b && ln_out && mean && rstd), "bl_segment_max_fwd: LayerNorm outputs missing");
+  dim3 grid((nseg + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (has_ln) {
+    DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, true>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
+                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd))
+  } else {
+    DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, false>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
+                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd))
+  }
+  BL_LAUNCH_CHECK("bl_segment_max_fwd");
+  return BL_OK;
+}
+
+extern "C" int bl_segment_max_bwd(const float* g_out, const int32_t* arg, const float* x, int32_t ldx,
+                                  const int32_t* seg_of, int32_t nitems, int32_t D, int32_t act, float* g_x,
+                                  void* stream) {
+  if (nitems == 0) return BL_OK;
+  BL_CHECK_ARG(g_out && arg && seg_of && g_x, "bl_segment_max_bwd: null pointer");
+  BL_CHECK_ARG(D > 0 && D % 4 == 0 && ldx % 4 == 0, "bl_segment_max_bwd: D and ldx must be multiples of 4");
+  BL_CHECK_ARG(act == BL_ACT_NONE || (act == BL_ACT_GELU && x), "bl_segment_max_bwd: act must be NONE or GELU (+x)");
+  const long long total = (long long)nitems * (D / 4);
+  hipLaunchKernelGGL(segment_max_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     g_out, arg, x, ldx, seg_of, (long long)nitems, D, act, g_x);
+  BL_LAUNCH_CHECK("bl_segment_max_bwd");
+  return BL_OK;
+}
+
+extern "C" int bl_layernorm_bwd(const float* g_y, const float* x, const float* mean, const float* rstd,
+                                const float* gamma, int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta,
+                                void* stream) {
+  if (nrows == 0) return BL_OK;
+  BL_CHECK_ARG(g_y && x && mean && rstd && gamma && g_x && g_gamma && g_beta, "bl_layernorm_bwd: null pointer");
+  BL_CHECK_ARG(D > 0 && D <= 512, "bl_layernorm_bwd: D must be in 1..512");
+  const int blocks = min((nrows + 3) / 4, 1024);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd,
+                                     gamma, nrows, D, g_x, g_gamma, g_beta))
+  BL_LAUNCH_CHECK("bl_layernorm_bwd");
+  return BL_OK;
+}
+
+extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act,
+                          bl_dropout_t drop, float* g_z, float* g_bias, void* stream) {
+  if (nrows == 0) return BL_OK;
+  BL_CHECK_ARG(g_y && y && g_z, "bl_act_bwd: null pointer");
+  BL_CHECK_ARG(N > 0 && N % 4 == 0 && ld % 4 == 0, "bl_act_bwd: N/ld multiples of 4");
+  BL_CHECK_ARG(act != BL_ACT_GELU, "bl_act_bwd: GELU needs the pre-activation (use bl_segment_max_bwd)");
+  dim3 grid((nrows + 63) / 64, (N / 4 + 63) / 64);
+  hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g_y, y, nrows, N, ld, act,
+                     bl_make_drop(drop), g_z, g_bias);
+  BL_LAUNCH_CHECK("bl_act_bwd");
+  return BL_OK;
+}
+
+extern "C" int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
+                                  const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din,
+                                  int32_t accumulate, float* g_h, int32_t ld_gh, void* stream) {
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(g_a && src_ptr && src_msgs && tgt_ptr && tgt_msgs && g_h, "bl_mp_scatter_grad: null pointer");
+  BL_CHECK_ARG(Din > 0 && Din <= 512 && ld_ga >= 2 * Din, "bl_mp_scatter_grad: Din in 1..512, ld_ga >= 2*Din");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_a, ld_ga,
+                                       src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh))
+  BL_LAUNCH_CHECK("bl_mp_scatter_grad");
+  return BL_OK;
+}

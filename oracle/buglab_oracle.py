@@ -57,7 +57,7 @@ def dropout_keep_mask(seed: int, stream: int, numel: int, p: float) -> np.ndarra
     key = _lowbias32_np(np.array([(seed & _M32) ^ ((stream * 0x9E3779B9) & _M32)], dtype=np.uint64))[0]
     idx = np.arange(numel, dtype=np.uint64)
     h = _lowbias32_np((idx + key) & _M32)
-    thresh = np.uint64(int(p * 16777216.0))
+    thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))  # float32 like the kernel
     return (h >> np.uint64(8)) >= thresh
 
 

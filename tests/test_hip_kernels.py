@@ -1,0 +1,255 @@
+"""GPU: every C-ABI entry point of libbuglab_hip against a plain PyTorch (fp64 where cheap)
+reference of the same op, on seeded inputs chosen to hit the edge cases: empty groups/segments,
+partial tiles, widths that are not multiples of the tile, hub segments longer than one wave batch,
+multiple gathered sources.  Tolerances are written next to each check (fp32 accumulate-order noise)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import buglab_oracle as O
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from buglab.models import hip_ops
+
+    hip_ops.load_library()
+    return hip_ops
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(a)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def _groups(rng, sizes):
+    ptr = np.zeros(len(sizes) + 1, dtype=np.int32)
+    ptr[1:] = np.cumsum(sizes)
+    return ptr
+
+
+@pytest.mark.parametrize("Din,Dm,sizes", [(64, 96, [130, 0, 1, 257, 64]), (32, 128, [5, 300]), (128, 256, [129, 128, 127]), (24, 40, [70, 3])])
+def test_gemm_rows_grouped_gathered(ops, Din, Dm, sizes):
+    rng = np.random.default_rng(0)
+    N, T, E = 211, len(sizes), int(sum(sizes))
+    h = torch.randn(N, Din, dtype=torch.float32)
+    W = torch.randn(T, 2 * Din, Dm) / math.sqrt(2 * Din)
+    src = rng.integers(0, N, E).astype(np.int32)
+    tgt = rng.integers(0, N, E).astype(np.int32)
+    ptr = _groups(rng, sizes)
+    ref = torch.zeros(E, Dm, dtype=torch.float64)
+    for t in range(T):
+        lo, hi = ptr[t], ptr[t + 1]
+        a = torch.cat([h[src[lo:hi]], h[tgt[lo:hi]]], -1).double()
+        ref[lo:hi] = a @ W[t].double()
+    hd, Wd = _dev(h), _dev(W)
+    out = ops.gemm_rows([(hd, _dev(src)), (hd, _dev(tgt))], Wd, E, Dm, b_group_stride=2 * Din * Dm, ldb=Dm,
+                        group_ptr=_dev(ptr), G=T)
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max() < 2e-5  # K <= 256 products of O(1) values
+
+    # transposed-B form (input gradient): dA = G . W_t^T
+    G = torch.randn(E, Dm)
+    ref2 = torch.zeros(E, 2 * Din, dtype=torch.float64)
+    for t in range(T):
+        lo, hi = ptr[t], ptr[t + 1]
+        ref2[lo:hi] = G[lo:hi].double() @ W[t].double().T
+    out2 = ops.gemm_rows([(_dev(G), None)], Wd, E, 2 * Din, b_is_nk=True, b_group_stride=2 * Din * Dm, ldb=Dm,
+                         group_ptr=_dev(ptr), G=T)
+    assert (out2.cpu().double() - ref2).abs().max() < 2e-5
+
+    # weight gradient: gW_t = A_t^T G_t (fp32 atomics across row chunks)
+    gw = torch.zeros(T, 2 * Din, Dm, device="cuda")
+    ops.gemm_wgrad([(hd, _dev(src)), (hd, _dev(tgt))], _dev(G), E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=_dev(ptr), G=T)
+    ref3 = torch.zeros(T, 2 * Din, Dm, dtype=torch.float64)
+    for t in range(T):
+        lo, hi = ptr[t], ptr[t + 1]
+        a = torch.cat([h[src[lo:hi]], h[tgt[lo:hi]]], -1).double()
+        ref3[t] = a.T @ G[lo:hi].double()
+    scale = max(1.0, float(ref3.abs().max()))
+    assert (gw.cpu().double() - ref3).abs().max() < 3e-5 * scale
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "sigmoid", "tanh"])
+def test_gemm_rows_bias_act_dropout_three_sources(ops, act):
+    rng = np.random.default_rng(1)
+    R, H = 333, 48
+    a, b, c = torch.randn(50, H), torch.randn(70, H), torch.randn(20, H)
+    ia, ib, ic = (rng.integers(0, n, R).astype(np.int32) for n in (50, 70, 20))
+    W = torch.randn(3 * H, 52) / math.sqrt(3 * H)
+    bias = torch.randn(52)
+    x = torch.cat([a[ia], b[ib], c[ic]], -1).double()
+    z = x @ W.double() + bias.double()
+    ref = {"none": z, "relu": torch.relu(z), "sigmoid": torch.sigmoid(z), "tanh": torch.tanh(z)}[act]
+    drop = ops.Dropout(0.3, 1234, 7)
+    keep = torch.from_numpy(O.dropout_keep_mask(1234, 7, R * 52, 0.3)).view(R, 52)
+    ref_d = ref * keep / (1 - np.float32(0.3)).astype(np.float64)
+    out = ops.gemm_rows([(_dev(a), _dev(ia)), (_dev(b), _dev(ib)), (_dev(c), _dev(ic))], _dev(W), R, 52, bias=_dev(bias),
+                        act=ops._ACTS[act], drop=drop)
+    assert (out.cpu().double() - ref_d).abs().max() < 3e-5
+    assert ((out.cpu() == 0) == (~keep | (ref_d == 0))).all()  # identical mask, bit for bit
+
+
+@pytest.mark.parametrize("D,act", [(96, "gelu"), (320, "none"), (128, "gelu"), (8, "none")])
+def test_segment_max_layernorm_fwd_bwd(ops, D, act):
+    rng = np.random.default_rng(2)
+    nseg, E = 57, 900
+    seg = rng.integers(0, nseg, E)
+    seg[seg == 5] = 6  # empty segment
+    seg[:200] = 11  # hub: more than one 64-item batch
+    order = np.argsort(seg, kind="stable").astype(np.int32)
+    ptr = np.zeros(nseg + 1, dtype=np.int32)
+    ptr[1:] = np.cumsum(np.bincount(seg, minlength=nseg))
+    x = torch.randn(E, D)
+    x[3] = x[1]  # exact tie inside a segment? force same segment
+    seg[3] = seg[1]
+    order = np.argsort(seg, kind="stable").astype(np.int32)
+    ptr[1:] = np.cumsum(np.bincount(seg, minlength=nseg))
+    g, b = torch.randn(D), torch.randn(D)
+    xa = O._gelu(x.double()) if act == "gelu" else x.double()
+    ref, arg = O.scatter_max_with_arg(xa, torch.from_numpy(seg), nseg)
+    ref_ln = torch.nn.functional.layer_norm(ref, (D,), g.double(), b.double(), eps=1e-5)
+    out, a, ln_out, mean, rstd = ops.segment_max(_dev(x), _dev(ptr), _dev(order), nseg, act=ops._ACTS[act], ln=(_dev(g), _dev(b)))
+    assert (out.cpu().double() - ref).abs().max() < 1e-6
+    a_ref = torch.where(arg == E, torch.full_like(arg, -1), arg)
+    assert (a.cpu().long() == a_ref).all()
+    assert (ln_out.cpu().double() - ref_ln).abs().max() < 2e-5
+    # backward of the max (gather form) against autograd through the oracle
+    if D % 4 == 0:
+        go = torch.randn(nseg, D)
+        xr = x.double().requires_grad_(True)
+        xa = O._gelu(xr) if act == "gelu" else xr
+        O.scatter_max_with_arg(xa, torch.from_numpy(seg), nseg)[0].backward(go.double())
+        gx = ops.segment_max_bwd(_dev(go), a, _dev(x), _dev(seg.astype(np.int32)), act=ops._ACTS[act])
+        assert (gx.cpu().double() - xr.grad).abs().max() < 1e-5
+        # LayerNorm backward
+        gy = torch.randn(nseg, D)
+        rr = ref.clone().float().requires_grad_(True)
+        gg, bb = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        torch.nn.functional.layer_norm(rr, (D,), gg, bb, eps=1e-5).backward(gy)
+        d_g, d_b = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        gxx = ops.layernorm_bwd(_dev(gy), out, mean, rstd, _dev(g), d_g, d_b)
+        # rows with zero variance (the empty segment) have rstd = 1/sqrt(eps) ~ 316: compare relative to the largest entry
+        assert (gxx.cpu() - rr.grad).abs().max() < 5e-5 * max(1.0, float(rr.grad.abs().max()))
+        assert (d_g.cpu() - gg.grad).abs().max() < 1e-4 * max(1.0, float(gg.grad.abs().max()))
+        assert (d_b.cpu() - bb.grad).abs().max() < 1e-4 * max(1.0, float(bb.grad.abs().max()))
+
+
+def test_act_bwd_and_bias(ops):
+    R, N = 301, 72
+    y_pre = torch.randn(R, N)
+    drop = ops.Dropout(0.2, 99, 3)
+    keep = torch.from_numpy(O.dropout_keep_mask(99, 3, R * N, 0.2)).view(R, N)
+    t = torch.tanh(y_pre.double())
+    y = (t * keep / (1 - 0.2)).float()
+    g = torch.randn(R, N)
+    ref = g.double() * keep / (1 - 0.2) * (1 - t * t)
+    gb = torch.zeros(N, device="cuda")
+    gz = ops.act_bwd(_dev(g), _dev(y), ops.ACT_TANH, drop, gb)
+    assert (gz.cpu().double() - ref).abs().max() < 1e-5
+    assert (gb.cpu().double() - ref.sum(0)).abs().max() < 1e-4
+
+
+def test_mp_scatter_grad(ops):
+    rng = np.random.default_rng(3)
+    N, E, Din = 90, 700, 96
+    src, tgt = rng.integers(0, N, E), rng.integers(0, N, E)
+    tgt[:150] = 7
+    ga = torch.randn(E, 2 * Din)
+    ref = torch.zeros(N, Din, dtype=torch.float64)
+    ref.index_add_(0, torch.from_numpy(src), ga[:, :Din].double())
+    ref.index_add_(0, torch.from_numpy(tgt), ga[:, Din:].double())
+    from buglab.data.collate import _csr
+
+    sp, sm = _csr(src, N)
+    tp, tm = _csr(tgt, N)
+    gh = torch.empty(N, Din, device="cuda")
+    lib = ops.load_library()
+    d_ga, d_sp, d_sm, d_tp, d_tm = (_dev(a) for a in (ga, sp, sm, tp, tm))  # keep the device copies alive
+    ops._check(lib.bl_mp_scatter_grad(d_ga.data_ptr(), 2 * Din, d_sp.data_ptr(), d_sm.data_ptr(), d_tp.data_ptr(),
+                                      d_tm.data_ptr(), N, Din, 0, gh.data_ptr(), Din, torch.cuda.current_stream().cuda_stream), "scatter")
+    torch.cuda.synchronize()
+    assert (gh.cpu().double() - ref).abs().max() < 1e-4
+
+
+def test_segment_log_softmax_fwd_bwd(ops):
+    rng = np.random.default_rng(4)
+    K, G = 500, 40
+    idx = rng.integers(0, G, K)
+    idx[idx == 9] = 10
+    idx[:130] = 3
+    x = (torch.randn(K) * 3).requires_grad_(True)
+    ref = O.scatter_log_softmax(x, torch.from_numpy(idx))
+    gy = torch.randn(K)
+    ref.backward(gy)
+    from buglab.data.collate import segments_from_index
+
+    ptr, items = segments_from_index(idx, G)
+    xd = _dev(x.detach()).requires_grad_(True)
+    y = ops.segment_log_softmax(xd, _dev(ptr), _dev(items), G)
+    y.backward(_dev(gy))
+    assert (y.detach().cpu() - ref.detach()).abs().max() < 2e-6
+    assert (xd.grad.cpu() - x.grad).abs().max() < 1e-5
+
+
+def test_rowdot_and_scatter_add(ops):
+    R, H = 77, 96
+    x, w, b = torch.randn(R, H), torch.randn(H), torch.randn(1)
+    xd, wd, bd = (_dev(t).requires_grad_(True) for t in (x, w, b))
+    y = ops.rowdot(xd, wd, bd)
+    gy = torch.randn(R)
+    y.backward(_dev(gy))
+    assert (y.detach().cpu().double() - (x.double() @ w.double() + b.double())).abs().max() < 1e-5
+    assert (xd.grad.cpu() - gy[:, None] * w[None]).abs().max() < 1e-6
+    assert (wd.grad.cpu().double() - (gy.double()[:, None] * x.double()).sum(0)).abs().max() < 1e-4
+    assert abs(float(bd.grad) - float(gy.sum())) < 1e-4
+    idx = np.random.default_rng(5).integers(0, 20, R).astype(np.int32)
+    out = torch.zeros(20, 32, device="cuda")
+    ops.scatter_add_rows(_dev(x), 16, 32, _dev(idx), out)
+    ref = torch.zeros(20, 32, dtype=torch.float64).index_add_(0, torch.from_numpy(idx).long(), x[:, 16:48].double())
+    assert (out.cpu().double() - ref).abs().max() < 1e-5
+
+
+def test_embed_fwd_bwd(ops):
+    rng = np.random.default_rng(6)
+    V, H, N, S = 97, 64, 200, 6
+    table = torch.randn(V, H)
+    ids = rng.integers(0, V, (N, S)).astype(np.int32)
+    lens = rng.integers(1, S + 1, N).astype(np.int32)
+    tr = table.clone().requires_grad_(True)
+    ref = O.embed_nodes(tr, ids, lens, 0.25, 42)
+    go = torch.randn(N, H)
+    ref.backward(go)
+    td = _dev(table).requires_grad_(True)
+    out = ops.embed_subtoken_max(td, _dev(ids), _dev(lens), ops.Dropout(0.25, 42, 0))
+    out.backward(_dev(go))
+    assert (out.detach().cpu() - ref.detach()).abs().max() < 1e-6
+    assert (td.grad.cpu() - tr.grad).abs().max() < 1e-4
+
+
+def test_flat_adam_matches_oracle(ops):
+    from buglab.runtime.optim import FlatAdam
+
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(13, 7, device="cuda")), torch.nn.Parameter(torch.randn(5, device="cuda"))]
+    ref_p = {i: p.detach().cpu().clone() for i, p in enumerate(ps)}
+    m = {i: torch.zeros_like(v) for i, v in ref_p.items()}
+    v = {i: torch.zeros_like(vv) for i, vv in ref_p.items()}
+    opt = FlatAdam(ps, lr=1e-2, clip_gradient_norm=0.5, num_warmup_steps=3)
+    for step in range(1, 6):
+        opt.zero_grad()
+        grads = {i: torch.randn_like(ref_p[i]) * (3.0 if step % 2 else 0.01) for i in ref_p}
+        for i, p in enumerate(ps):
+            p.grad.add_(grads[i].cuda())
+        opt.step()
+        O.adam_clip_step(ref_p, grads, m, v, step, lr=1e-2, clip=0.5, warmup=3)
+        for i, p in enumerate(ps):
+            assert (p.detach().cpu() - ref_p[i]).abs().max() < 2e-6, (step, i)

@@ -1,0 +1,208 @@
+"""GPU: the HIP hot path (through the C ABI) against the CPU oracle on identical seeded
+minibatches and identical weights, and against the golden vectors produced by the reference's own
+head code.  Tolerance is BASELINE.json's: 1e-4 absolute on logits / log-probabilities / loss (fp32);
+parameter gradients within 1e-4 relative to the largest gradient entry of that tensor (+1e-6 abs)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import buglab_oracle as O
+from tests import helpers as Hh
+from tests.refmap import golden_minibatch, head_params_from_golden
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from buglab.models import hip_ops
+
+    hip_ops.load_library()
+
+
+def _run_hip(module, mb_np, seed=None):
+    from buglab.data.collate import to_device
+
+    mb = to_device(mb_np, "cuda")
+    module.zero_grad(set_to_none=True)
+    loss = module(**mb, dropout_seed=seed)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss, mb
+
+
+def _check_against_oracle(cfg, mb_np, seed=None, train=True):
+    params = O.init_params(cfg, seed=0)
+    out, grads = O.forward_backward(params, mb_np, cfg, seed=seed)
+    module = Hh.build_module_like(cfg, params)
+    module.train(train)
+    module.reset_metrics()
+    loss, mb = _run_hip(module, mb_np, seed)
+    assert abs(float(loss) - float(out["loss"])) < TOL, (float(loss), float(out["loss"]))
+    with torch.no_grad():
+        module.eval()
+        ids, loc_lp, gnn_out, _ = module.compute_localization_logprobs(mb["graph_data"]) if seed is None else (None, None, None, None)
+    if seed is None:
+        assert Hh.maxdiff(loc_lp, out["loc_logprobs"]) < TOL
+        assert Hh.maxdiff(gnn_out.output_node_representations, out["node_reprs"]) < TOL
+    g_hip = Hh.module_grads(module)
+    worst = {}
+    for k, g_ref in grads.items():
+        d = Hh.maxdiff(g_hip[k], g_ref)
+        scale = float(g_ref.abs().max())
+        worst[k] = (d, scale)
+        assert d <= 1e-4 * scale + 1e-6, (k, d, scale)
+    return module, out, worst
+
+
+def test_forward_backward_matches_oracle_small():
+    cfg, _, mb = Hh.make_case(B=4, n=80, E=400, T=5, H=64, layers=4)
+    module, out, _ = _check_against_oracle(cfg, mb)
+    m = module.report_metrics()
+    assert abs(m["Localization Accuracy"] - out["loc_stats"]["num_correct"] / 4) < 1e-9
+
+
+def test_forward_backward_matches_oracle_8_layers_h128():
+    cfg, _, mb = Hh.make_case(B=3, n=150, E=800, T=16, H=128, layers=8, C=10, seed=3)
+    _check_against_oracle(cfg, mb)
+
+
+def test_dropout_parity_same_counter_mask():
+    cfg, _, mb = Hh.make_case(B=3, n=60, E=300, T=4, H=64, layers=4, dropout=0.2, seed=5)
+    _check_against_oracle(cfg, mb, seed=777)
+
+
+def test_message_activation_none_and_weighted_loss():
+    cfg, _, mb = Hh.make_case(B=4, n=70, E=350, T=3, H=32, layers=4, msg_act="none", buggy_samples_weight=0.6, seed=7)
+    _check_against_oracle(cfg, mb)
+
+
+def test_power_law_hub_degree_512():
+    """BASELINE config c4 shape (truncated power-law in-degree, hub of degree 512) at a size the
+    oracle finishes in seconds."""
+    cfg, _, mb = Hh.make_case(B=2, n=400, E=2400, T=8, H=64, layers=4, degree="powerlaw", max_degree=512, seed=9)
+    deg = np.diff(mb["graph_data"]["tgt_ptr"])
+    assert deg.max() >= 512
+    _check_against_oracle(cfg, mb)
+
+
+def test_no_buggy_graphs_and_empty_edge_types():
+    """Zero-length repair heads (reference gnn.py:261-293 zero-length branches) and edge types
+    with no edges at all."""
+    from buglab.data.collate import collate_samples
+    from buglab.data.synthetic import make_samples
+
+    cfg = O.OracleConfig(hidden=32, num_layers=4, num_edge_types=6, vocab_size=100)
+    samples = make_samples(3, seed=2, num_nodes=40, num_messages=120, num_edge_types=3, vocab_size=100, num_candidates=5, buggy=False)
+    for s in samples:  # present 6 types, the last 3 empty
+        s.graph_data.adjacency_lists.extend([np.zeros((0, 2), np.int32)] * 3)
+    mb = collate_samples(samples, 6)
+    assert mb["target_rewrites"].shape[0] == 0
+    _check_against_oracle(cfg, mb)
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_heads_match_reference_golden(golden_dir, case):
+    """HIP heads + loss assembly vs. outputs of the REFERENCE's own GnnBugLabModule.forward
+    (tests/golden/make_golden.py), node states injected through a table GNN."""
+    from buglab.data.collate import segments_from_index
+    from buglab.models.gnn import GnnBugLabModule, const_weight_schedule
+    from buglab.models.layers.messagepassing import GnnOutput
+    from functools import partial
+
+    z = np.load(os.path.join(golden_dir, f"heads_forward_{case}.npz"))
+    H, B = int(z["H"]), int(z["B"])
+    mbn = golden_minibatch(z)
+    refs = mbn["graph_data"]["reference_node_ids"]
+    cand_g = mbn["graph_data"]["reference_node_graph_idx"]["candidate_nodes"]
+    I = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32).cuda()
+
+    class TableGnn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.from_numpy(z["node_states"]).cuda())
+            self.input_node_state_dim = self.output_node_state_dim = H
+            self.message_passing_layers = []
+
+        def forward(self, return_all_states=False, dropout_seed=None, **gd):
+            r = {k: I(v) for k, v in refs.items()}
+            pairs = np.asarray(refs["candidate_swapped_node_ids"]).reshape(-1, 2)
+            r["candidate_swapped_a"], r["candidate_swapped_b"] = I(pairs[:, 0]), I(pairs[:, 1])
+            return GnnOutput(self.table, self.table, None, r, {"candidate_nodes": I(cand_g)}, B)
+
+    module = GnnBugLabModule(TableGnn(), 48, buggy_samples_weight_schedule=partial(const_weight_schedule, weight=float(z["buggy_weight"]))).cuda()
+    sd = module.state_dict()
+    prefix = {"loc.": "_localization_module.", "text.": "_text_repair_module.", "var.": "_varmisuse_module.", "swap.": "_argswap_module."}
+    for k, v in head_params_from_golden(z).items():
+        for a, b in prefix.items():
+            if k.startswith(a):
+                sd[b + k[len(a):]].copy_(v.cuda())
+    cand_ptr = np.zeros(B + 1, dtype=np.int32)
+    cand_ptr[1:] = np.cumsum(np.bincount(cand_g, minlength=B))
+    loc_ptr, loc_items = segments_from_index(np.concatenate([cand_g, np.arange(B)]), B)
+    gd = {"candidate_ptr": I(cand_ptr), "loc_group_ptr": I(loc_ptr), "loc_group_items": I(loc_items)}
+    kw = {k: I(mbn[k]) for k in ("correct_candidate_node_idxs", "target_rewrites", "rewrite_to_location_group", "correct_rewrite_idxs",
+                                 "text_rewrite_idxs", "candidate_symbol_to_location_group", "correct_candidate_symbols",
+                                 "candidate_rewrite_idxs", "swapped_pair_to_call_location_group", "correct_swapped_pair",
+                                 "pair_rewrite_idxs", "rewrite_to_graph_id")}
+    module.train()
+    module.reset_metrics()
+    loss = module(graph_data=gd, has_bug=torch.from_numpy(mbn["has_bug"]).cuda(), **kw)
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < TOL
+    with torch.no_grad():
+        _, loc_lp, gout, _ = module.compute_localization_logprobs(gd)
+        swap_lp, text_lp, var_lp, _ = module._compute_repair_logprobs(gout, kw["target_rewrites"], kw["rewrite_to_location_group"],
+                                                                       kw["candidate_symbol_to_location_group"], kw["swapped_pair_to_call_location_group"])
+    assert Hh.maxdiff(loc_lp, z["loc_logprobs"]) < TOL
+    assert Hh.maxdiff(text_lp, z["text_logprobs"]) < TOL
+    assert Hh.maxdiff(var_lp, z["var_logprobs"]) < TOL
+    assert Hh.maxdiff(swap_lp, z["swap_logprobs"]) < TOL
+    g = module._gnn.table.grad
+    assert Hh.maxdiff(g, z["grad_node_states"]) < 1e-4 * float(np.abs(z["grad_node_states"]).max()) + 1e-6
+    assert abs(module.report_metrics()["Localization Accuracy"] - float(z["metrics_loc_accuracy"])) < 1e-9
+
+
+def test_full_size_properties_c2():
+    """BASELINE config c2 (H128, 8 layers, T16, 64 graphs x 2k nodes / 10k messages): too big for the
+    oracle in a test, so size-independent properties: per-graph localization probabilities sum to
+    one (the reference's own sanity comments, basemodel.py:257-258), repair probabilities sum to one
+    per location group, the result is invariant to the order edges are listed in, finite grads."""
+    from buglab.data.collate import collate_samples, to_device
+    from buglab.data.synthetic import make_samples
+    from buglab.models.gnn import build_gnn_mlp_module
+
+    samples = make_samples(64, seed=0)
+    torch.manual_seed(0)
+    module = build_gnn_mlp_module(dropout_rate=0.0).cuda()
+    mb_np = collate_samples(samples, 16)
+    mb = to_device(mb_np, "cuda")
+    loss = module(**mb)
+    loss.backward()
+    assert math.isfinite(float(loss))
+    for p in module.parameters():
+        assert torch.isfinite(p.grad).all()
+    with torch.no_grad():
+        ids, lp, gout, _ = module.compute_localization_logprobs(mb["graph_data"])
+        sums = torch.zeros(64, device="cuda").index_add_(0, ids.long(), lp.exp())
+        assert (sums - 1).abs().max() < 1e-4
+        swap_lp, text_lp, var_lp, _ = module._compute_repair_logprobs(
+            gout, mb["target_rewrites"], mb["rewrite_to_location_group"], mb["candidate_symbol_to_location_group"],
+            mb["swapped_pair_to_call_location_group"], mb["repair_group_ptr"], mb["repair_group_items"])
+        groups = torch.cat([mb["rewrite_to_location_group"], mb["candidate_symbol_to_location_group"], mb["swapped_pair_to_call_location_group"]]).long()
+        gs = torch.zeros(mb["num_repair_groups"], device="cuda").index_add_(0, groups, torch.cat([text_lp, var_lp, swap_lp]).exp())
+        assert (gs[groups] - 1).abs().max() < 1e-4
+        # permute the edge lists of every graph: same minibatch, same answer
+        rng = np.random.default_rng(1)
+        for s in samples:
+            s.graph_data.adjacency_lists[:] = [a[rng.permutation(a.shape[0])] for a in s.graph_data.adjacency_lists]
+        mb2 = to_device(collate_samples(samples, 16), "cuda")
+        loss2 = module(**mb2)
+        assert abs(float(loss2) - float(loss)) < 1e-5
