@@ -140,3 +140,95 @@ def make_samples(num_graphs: int, seed: int = 0, **kw) -> List[BaseTensorizedBug
             kw_b["buggy"] = (b % 2 == 0)  # exactly 50 % buggy, deterministic
         out.append(make_sample(rng, **kw_b))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Synthetic *raw* datapoints (the msgpack dict format, reference buglab/representations/data.py:14-20,
+# 130-137) for exercising the host path: metadata pass, tensorize, rewrite bookkeeping, predict.
+_KINDS = ["Module", "FunctionDef", "Call", "Name", "BinaryOperation", "Assign", "Return", "If", "Attribute"]
+_WORDS = ["get", "set", "value", "index", "count", "name", "path", "file", "data", "item", "key", "node", "size", "max", "min"]
+
+
+def _identifier(rng) -> str:
+    k = int(rng.integers(1, 4))
+    parts = [_WORDS[int(rng.integers(0, len(_WORDS)))] for _ in range(k)]
+    return "_".join(parts) if rng.integers(0, 2) else parts[0] + "".join(p.capitalize() for p in parts[1:])
+
+
+def make_buglab_datapoint(rng: np.random.Generator, num_syntax_nodes: int = 40, num_tokens: int = 30, buggy: bool = True,
+                          package: str = "synthetic"):
+    """One BugLabData dict with Child / NextToken / OccurrenceOf / Sibling edges, Call nodes with
+    `args` children, and candidate rewrites of all three scout families at several locations."""
+    nodes: List[str] = []
+    child, sibling, next_token, occ = [], [], [], []
+    for i in range(num_syntax_nodes):
+        nodes.append(_KINDS[int(rng.integers(0, len(_KINDS)))] if i else "Module")
+        if i:
+            child.append([int(rng.integers(0, i)), i])
+    tok0 = len(nodes)
+    for j in range(num_tokens):
+        nodes.append(_identifier(rng) if rng.integers(0, 3) else ["(", ")", "+", "=", ":"][int(rng.integers(0, 5))])
+        if j:
+            next_token.append([tok0 + j - 1, tok0 + j])
+        child.append([int(rng.integers(0, num_syntax_nodes)), tok0 + j])
+    sym0 = len(nodes)
+    for s in range(5):
+        nodes.append(_identifier(rng))
+        for _ in range(3):
+            occ.append([tok0 + int(rng.integers(0, num_tokens)), sym0 + s])
+    for i in range(1, num_syntax_nodes - 1, 3):
+        sibling.append([i, i + 1])
+    # two Call nodes with >= 2 `args` children each
+    calls = []
+    for c in range(2):
+        call = len(nodes)
+        nodes.append("Call")
+        child.append([0, call])
+        args = []
+        for a in range(3):
+            arg = len(nodes)
+            nodes.append("Name")
+            child.append([call, arg, "args"])
+            args.append(arg)
+        calls.append((call, args))
+
+    reference_nodes, rewrites, metadata, ranges = [], [], [], []
+
+    def add(node, rewrite, meta):
+        reference_nodes.append(int(node))
+        rewrites.append(rewrite)
+        metadata.append(meta)
+        ranges.append(((0, 0), (0, 1)))
+
+    op_node = tok0 + 1
+    for op in ("+", "-", "*", "<="):
+        add(op_node, ("ReplaceText", op), ("BinaryOperatorRewriteScout", None))
+    var_node = tok0 + 3
+    for s in range(4):
+        add(var_node, ("ReplaceText", nodes[sym0 + s]), ("VariableMisuseRewriteScout", sym0 + s))
+    for call, args in calls:
+        add(call, ("ArgSwap", (0, 1)), ("ArgSwapRewriteScout", None))
+        add(call, ("ArgSwap", (1, 2)), ("ArgSwapRewriteScout", None))
+    add(tok0 + 5, ("ReplaceText", "True"), ("LiteralRewriteScout", None))
+    target = int(rng.integers(0, len(rewrites))) if buggy else None
+    return {
+        "graph": {
+            "nodes": nodes,
+            "edges": {"Child": child, "NextToken": next_token, "OccurrenceOf": occ, "Sibling": sibling},
+            "path": f"{package}/f.py",
+            "text": "",
+            "reference_nodes": reference_nodes,
+            "code_range": ((0, 0), (1, 0)),
+        },
+        "candidate_rewrites": rewrites,
+        "candidate_rewrite_metadata": metadata,
+        "candidate_rewrite_ranges": ranges,
+        "target_fix_action_idx": target,
+        "package_name": package,
+    }
+
+
+def make_buglab_dataset(n: int, seed: int = 0):
+    rng = np.random.default_rng(seed)
+    return [make_buglab_datapoint(rng, num_syntax_nodes=int(rng.integers(20, 60)), num_tokens=int(rng.integers(15, 40)),
+                                  buggy=(i % 2 == 0)) for i in range(n)]

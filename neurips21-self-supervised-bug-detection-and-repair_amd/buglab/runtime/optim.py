@@ -52,20 +52,23 @@ class FlatAdam:
             return self.lr
         return self.lr * min(1.0, float(step - 1) / float(max(1, self.warmup)))
 
-    def step(self, grad_weight: float = 1.0):
-        """`grad_weight`: this rank's share of the global minibatch (B_rank / B_total); the flat
-        gradient buffers are summed across ranks, so the result is the full-batch gradient."""
+    def reduce_gradients(self, grad_weight: float = 1.0) -> float:
+        """Data-parallel reduction: ONE all-reduce (sum) of the flat gradient buffer (RCCL over xGMI
+        on GPUs, gloo in the CPU tests).  `grad_weight` = B_rank / B_total, this rank's share of the
+        global minibatch, so that the sum equals the full-minibatch gradient.  Returns the factor
+        still to be applied to the buffer (folded into the fused Adam kernel)."""
         import torch.distributed as dist
 
-        self.step_count += 1
-        prescale = 1.0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             if grad_weight != 1.0:
-                prescale = 1.0  # weights differ per rank: scale locally, then sum
-                self.flat_grad.mul_(grad_weight)
+                self.flat_grad.mul_(grad_weight)  # weights may differ per rank: scale locally, then sum
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
-        elif grad_weight != 1.0:
-            prescale = grad_weight
+            return 1.0
+        return grad_weight
+
+    def step(self, grad_weight: float = 1.0):
+        self.step_count += 1
+        prescale = self.reduce_gradients(grad_weight)
         if self.flat_param.is_cuda:
             hip_ops.sqnorm(self.flat_grad, self.sqnorm)
             hip_ops.adam_clip_step(self.flat_param, self.flat_grad, self.m, self.v, self.sqnorm, prescale=prescale,

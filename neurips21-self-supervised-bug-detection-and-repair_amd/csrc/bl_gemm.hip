@@ -9,29 +9,29 @@
 //                      in chunks, fp32 atomics)
 //
 // Tiling (both): 128 x 128 output tile per 256-thread workgroup = 4 waves in a 2 x 2 grid, each
-// wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs); BK = 32 per LDS stage,
-// register prefetch of the next stage while the current one is multiplied, 2 workgroups per CU.
+// wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs); BK k's per LDS stage with a
+// register prefetch of the next stage while the current one is multiplied.  NBUF = 1: one LDS
+// buffer, two barriers per stage; NBUF = 2: two LDS buffers, ONE barrier per stage.
 // At fp32 one MFMA occupies its SIMD for 64 cycles, so LDS/L2 traffic per flop is tiny compared
 // with a bf16 kernel: the design goal is simply to keep all four matrix pipes issuing.
 //
 // Operand images in LDS:
-//   "MN-major"  [128 rows][36]   (32 k's + 4 pad): rows are gathered global rows (k contiguous);
-//               fragment = ONE ds_read_b128 per lane = 4 MFMA k-steps; stride 36 floats makes both the
-//               b128 writes (8-lane groups) and the b128 reads (rows distinct mod 16) conflict-free.
-//   "K-major"   [32 k][128]      global rows are k-lines (n contiguous); fragment = 4 ds_read_b32,
+//   "MN-major"  [128 rows][BK + 4]: rows are gathered global rows (k contiguous); fragment = ONE
+//               ds_read_b128 per lane = 4 MFMA k-steps; the +4 pad makes both the b128 writes
+//               (contiguous lane groups) and the b128 reads (rows distinct mod 16) conflict-free.
+//   "K-major"   [BK k][128]: global rows are k-lines (n contiguous); fragment = 4 ds_read_b32,
 //               lanes 0-31 read 32 consecutive floats -> conflict-free.
 // MFMA k-assignment inside a group of 8 k's: lanes 0-31 take k = 8q+s, lanes 32-63 take k = 8q+4+s
 // (s = 0..3 are four consecutive MFMAs); A and B use the same assignment so the contraction is
 // complete whatever the order.
+#include <stdlib.h>
+
 #include "bl_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BM 128
 #define BN 128
-#define BK 32
-#define LDS_MN 36
-#define LDS_K 128
 
 // Row sources are passed as individual scalar kernel parameters (macro below) and selected with
 // value selects: arrays (or select-of-adjacent-fields) inside a by-value kernel argument make hipcc
@@ -49,7 +49,9 @@ struct RowsDev {  // host-side staging only
       int ld1, int ld2, int koff1, int koff2, int nsrc
 #define ROWS_ARGS(d) d.x0, d.x1, d.x2, d.idx0, d.idx1, d.idx2, d.ld0, d.ld1, d.ld2, d.koff1, d.koff2, d.nsrc
 
-// locate the (group, first row, row count) of tile `t` when every group is cut in pieces of `piece`
+// Locate the (group, first row, row count) of piece `t` when every group is cut in pieces of
+// `piece` rows.  Wave-cooperative: 64 group extents per load + a shuffle prefix sum, so the cost is
+// one memory latency instead of G dependent scalar loads.
 __device__ __forceinline__ bool find_piece(const int* __restrict__ group_ptr, int G, int M, int piece, int t, int& g,
                                            int& row0, int& nrows) {
   if (group_ptr == nullptr) {
@@ -59,15 +61,30 @@ __device__ __forceinline__ bool find_piece(const int* __restrict__ group_ptr, in
     nrows = min(piece, M - row0);
     return true;
   }
-  for (g = 0; g < G; ++g) {
-    const int lo = group_ptr[g], hi = group_ptr[g + 1];
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  for (int g0 = 0; g0 < G; g0 += 64) {
+    const int gi = g0 + lane;
+    const int lo = gi < G ? group_ptr[gi] : 0;
+    const int hi = gi < G ? group_ptr[gi + 1] : 0;
     const int nt = (hi - lo + piece - 1) / piece;
-    if (t < nt) {
-      row0 = lo + t * piece;
-      nrows = min(piece, hi - row0);
+    int incl = nt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    const int excl = base + incl - nt;
+    const unsigned long long hit = __ballot(t >= excl && t < excl + nt);
+    if (hit) {
+      const int src = __ffsll((long long)hit) - 1;
+      g = g0 + src;
+      const int lo_s = __shfl(lo, src, 64), hi_s = __shfl(hi, src, 64), ex_s = __shfl(excl, src, 64);
+      row0 = lo_s + (t - ex_s) * piece;
+      nrows = min(piece, hi_s - row0);
       return true;
     }
-    t -= nt;
+    base += __shfl(incl, 63, 64);
   }
   return false;
 }
@@ -86,15 +103,23 @@ __device__ __forceinline__ void mfma_group(const float (&a_)[2][4], const float 
         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[ti][s], b_[tj][s], acc[ti][tj], 0, 0, 0);
 }
 
-template <bool B_NK, int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(ROWS_PARAMS, const float* __restrict__ b, long long strideB,
-                                                           int ldb, const float* __restrict__ bias,
-                                                           const int* __restrict__ group_ptr,
-                                                           const int* __restrict__ group_w, int G, int M, int N, int K,
-                                                           uint32_t drop_key, uint32_t drop_thresh, float drop_scale,
-                                                           float* __restrict__ c, int ldc) {
-  __shared__ __attribute__((aligned(16))) float As[BM * LDS_MN];
-  __shared__ __attribute__((aligned(16))) float Bs[B_NK ? BN * LDS_MN : BK * LDS_K];
+template <bool B_NK, int ACT, int BK, int NBUF, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const float* __restrict__ b,
+                                                              long long strideB, int ldb,
+                                                              const float* __restrict__ bias,
+                                                              const int* __restrict__ group_ptr,
+                                                              const int* __restrict__ group_w, int G, int M, int N,
+                                                              int K, uint32_t drop_key, uint32_t drop_thresh,
+                                                              float drop_scale, float* __restrict__ c, int ldc) {
+  constexpr int LDS_MN = BK + 4;        // row stride of an MN-major image
+  constexpr int LDS_K = 128;            // row stride of a K-major image
+  constexpr int A_SZ = BM * LDS_MN;     // floats per A buffer
+  constexpr int B_SZ = B_NK ? BN * LDS_MN : BK * LDS_K;
+  constexpr int NLD = BK / 8;           // float4 loads per thread per operand per stage
+  constexpr int A_LPR = BK / 4;         // lanes per MN-major line
+  constexpr int A_LSTEP = 256 / A_LPR;  // MN-major lines covered by one pass of the block
+  __shared__ __attribute__((aligned(16))) float As[NBUF * A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF * B_SZ];
   __shared__ int rowidx[3][BM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,9 +137,9 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(ROWS_PARAMS, const fl
   }
   __syncthreads();
 
-  float4 ra[4], rb[4];
-  const int a_c4 = tid & 7, a_line0 = tid >> 3;   // MN-major loader: 8 lanes per 128-byte line
-  const int k_c4 = tid & 31, k_line0 = tid >> 5;  // K-major loader: 32 lanes per 512-byte line
+  float4 ra[NLD], rb[NLD];
+  const int a_c4 = tid % A_LPR, a_line0 = tid / A_LPR;  // MN-major loader
+  const int k_c4 = tid & 31, k_line0 = tid >> 5;         // K-major loader: 32 lanes per 512-byte line
   const int nk = (K + BK - 1) / BK;
 
 #define ROWS_LOAD_STAGE(k0_)                                                                              \
@@ -128,35 +153,42 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(ROWS_PARAMS, const fl
     const int kl_ = kc_ - (j_ == 0 ? 0 : (j_ == 1 ? koff1 : koff2));                                      \
     const float* base_ = j_ == 0 ? x0 : (j_ == 1 ? x1 : x2);                                              \
     const int ld_ = j_ == 0 ? ld0 : (j_ == 1 ? ld1 : ld2);                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-      const int line_ = a_line0 + 32 * i;                                                                 \
-      ra[i] = sel4(kok_, ld4(base_ + (size_t)rowidx[j_][line_] * ld_ + kl_));                             \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                     \
+      const int line_ = a_line0 + A_LSTEP * i;                                                            \
+      ra[i] = ld4(base_ + (size_t)rowidx[j_][line_] * ld_ + kl_);                                         \
     }                                                                                                     \
     if (!B_NK) {                                                                                          \
       const int n_ = n0 + 4 * k_c4;                                                                       \
       const int nc_ = n_ < N ? n_ : 0;                                                                    \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+      _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                   \
         const int kk_ = (k0_) + k_line0 + 8 * i;                                                          \
         const int kkc_ = kk_ < K ? kk_ : 0;                                                               \
-        rb[i] = sel4(n_ < N && kk_ < K, ld4(Bg + (size_t)kkc_ * ldb + nc_));                              \
+        rb[i] = ld4(Bg + (size_t)kkc_ * ldb + nc_);                                                       \
       }                                                                                                   \
     } else {                                                                                              \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
-        const int n_ = n0 + a_line0 + 32 * i;                                                             \
+      _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                   \
+        const int n_ = n0 + a_line0 + A_LSTEP * i;                                                        \
         const int nc_ = n_ < N ? n_ : 0;                                                                  \
-        rb[i] = sel4(n_ < N && kok_, ld4(Bg + (size_t)nc_ * ldb + kc_));                                  \
+        rb[i] = ld4(Bg + (size_t)nc_ * ldb + kc_);                                                        \
       }                                                                                                   \
     }                                                                                                     \
   }
-#define ROWS_STORE_STAGE()                                                                   \
-  {                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
-      *reinterpret_cast<float4*>(&As[(a_line0 + 32 * i) * LDS_MN + 4 * a_c4]) = ra[i];       \
-      if (!B_NK)                                                                             \
-        *reinterpret_cast<float4*>(&Bs[(k_line0 + 8 * i) * LDS_K + 4 * k_c4]) = rb[i];       \
-      else                                                                                   \
-        *reinterpret_cast<float4*>(&Bs[(a_line0 + 32 * i) * LDS_MN + 4 * a_c4]) = rb[i];     \
-    }                                                                                        \
+// The zero-fill predicates are applied HERE, not at the load: a select right behind the load makes
+// hipcc wait vmcnt(0) before the MFMAs of the current stage and serialises load latency with compute.
+#define ROWS_STORE_STAGE(buf_, k0_)                                                                          \
+  {                                                                                                          \
+    float* As_w = As + (buf_) * A_SZ;                                                                        \
+    float* Bs_w = Bs + (buf_) * B_SZ;                                                                        \
+    const bool kok_ = (k0_) + 4 * a_c4 < K;                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
+      *reinterpret_cast<float4*>(&As_w[(a_line0 + A_LSTEP * i) * LDS_MN + 4 * a_c4]) = sel4(kok_, ra[i]);    \
+      if (!B_NK)                                                                                             \
+        *reinterpret_cast<float4*>(&Bs_w[(k_line0 + 8 * i) * LDS_K + 4 * k_c4]) =                             \
+            sel4(n0 + 4 * k_c4 < N && (k0_) + k_line0 + 8 * i < K, rb[i]);                                    \
+      else                                                                                                   \
+        *reinterpret_cast<float4*>(&Bs_w[(a_line0 + A_LSTEP * i) * LDS_MN + 4 * a_c4]) =                     \
+            sel4(n0 + a_line0 + A_LSTEP * i < N && kok_, rb[i]);                                              \
+    }                                                                                                        \
   }
 
   f32x16 acc[2][2];
@@ -170,33 +202,46 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(ROWS_PARAMS, const fl
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, half = lane >> 5;
 
   ROWS_LOAD_STAGE(0)
-  ROWS_STORE_STAGE()
+  ROWS_STORE_STAGE(0, 0)
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
+    const int cur = NBUF == 2 ? (kt & 1) : 0;
     if (kt + 1 < nk) ROWS_LOAD_STAGE((kt + 1) * BK)
+    const float* As_ = As + cur * A_SZ;
+    const float* Bs_ = Bs + cur * B_SZ;
+    // fragments of k-group q+1 are read from LDS while the 16 MFMAs of group q issue
+    float fa[2][2][4], fb[2][2][4];
+#define ROWS_READ_FRAGS(q_, slot_)                                                                                      \
+  {                                                                                                                     \
+    _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) {                                                                  \
+      const float4 v = *reinterpret_cast<const float4*>(&As_[(wm * 64 + ti * 32 + li) * LDS_MN + 8 * (q_) + 4 * half]);  \
+      fa[slot_][ti][0] = v.x; fa[slot_][ti][1] = v.y; fa[slot_][ti][2] = v.z; fa[slot_][ti][3] = v.w;                   \
+    }                                                                                                                   \
+    _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) {                                                                  \
+      if (!B_NK) {                                                                                                      \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                   \
+            fb[slot_][tj][s] = Bs_[(8 * (q_) + 4 * half + s) * LDS_K + wn * 64 + tj * 32 + li];                         \
+      } else {                                                                                                          \
+        const float4 v = *reinterpret_cast<const float4*>(&Bs_[(wn * 64 + tj * 32 + li) * LDS_MN + 8 * (q_) + 4 * half]); \
+        fb[slot_][tj][0] = v.x; fb[slot_][tj][1] = v.y; fb[slot_][tj][2] = v.z; fb[slot_][tj][3] = v.w;                  \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  }
+    ROWS_READ_FRAGS(0, 0)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float a_[2][4], b_[2][4];
-#pragma unroll
-      for (int ti = 0; ti < 2; ++ti) {
-        const float4 v = *reinterpret_cast<const float4*>(&As[(wm * 64 + ti * 32 + li) * LDS_MN + 8 * q + 4 * half]);
-        a_[ti][0] = v.x; a_[ti][1] = v.y; a_[ti][2] = v.z; a_[ti][3] = v.w;
-      }
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj) {
-        if (!B_NK) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) b_[tj][s] = Bs[(8 * q + 4 * half + s) * LDS_K + wn * 64 + tj * 32 + li];
-        } else {
-          const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + tj * 32 + li) * LDS_MN + 8 * q + 4 * half]);
-          b_[tj][0] = v.x; b_[tj][1] = v.y; b_[tj][2] = v.z; b_[tj][3] = v.w;
-        }
-      }
-      mfma_group(a_, b_, acc);
+    for (int q = 0; q < BK / 8; ++q) {
+      if (q + 1 < BK / 8) ROWS_READ_FRAGS(q + 1, (q + 1) & 1)
+      mfma_group(fa[q & 1], fb[q & 1], acc);
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      ROWS_STORE_STAGE()
+    if (NBUF == 1) {
+      __syncthreads();
+      if (kt + 1 < nk) {
+        ROWS_STORE_STAGE(0, (kt + 1) * BK)
+        __syncthreads();
+      }
+    } else {
+      // the other buffer was last read in stage kt-1, before the barrier that ended it
+      if (kt + 1 < nk) ROWS_STORE_STAGE(cur ^ 1, (kt + 1) * BK)
       __syncthreads();
     }
   }
@@ -224,13 +269,17 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(ROWS_PARAMS, const fl
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(ROWS_PARAMS, const float* __restrict__ gc, int ldg,
-                                                            const int* __restrict__ group_ptr,
-                                                            const int* __restrict__ group_w, int G, int M, int N, int K,
-                                                            int kchunk, float* __restrict__ gw_base, long long strideW,
-                                                            int ldw, int ntiles_n) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDS_K];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_K];
+template <int BK, int NBUF, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, const float* __restrict__ gc, int ldg,
+                                                               const int* __restrict__ group_ptr,
+                                                               const int* __restrict__ group_w, int G, int M, int N,
+                                                               int K, int kchunk, float* __restrict__ gw_base,
+                                                               long long strideW, int ldw, int ntiles_n) {
+  constexpr int LDS_K = 128;
+  constexpr int T_SZ = BK * LDS_K;
+  constexpr int NLD = BK / 8;
+  __shared__ __attribute__((aligned(16))) float As[NBUF * T_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF * T_SZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g, e0, ne;
@@ -240,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(ROWS_PARAMS, const f
   const int n0 = (blockIdx.y % ntiles_n) * BN;
   const int wsel = group_w ? group_w[g] : g;
 
-  float4 ra[4], rb[4];
+  float4 ra[NLD], rb[NLD];
   const int c4 = tid & 31, line0 = tid >> 5;
   const int fi = i0 + 4 * c4;  // this thread's feature columns of the A rows
   const int nn = n0 + 4 * c4;  // this thread's columns of the G rows
@@ -256,21 +305,22 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(ROWS_PARAMS, const f
 
 #define WGRAD_LOAD_STAGE(k0_)                                                       \
   {                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                 \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                               \
       const int e_ = (k0_) + line0 + 8 * i;                                         \
       const bool eok_ = e_ < e1;                                                    \
       const int ec_ = eok_ ? e_ : e0;                                               \
       const int row_ = aidx ? aidx[ec_] : ec_;                                      \
-      ra[i] = sel4(eok_ && a_ok, ld4(abase + (size_t)row_ * ald + akl));            \
-      rb[i] = sel4(eok_ && b_ok, ld4(gc + (size_t)ec_ * ldg + nnc));                \
+      ra[i] = ld4(abase + (size_t)row_ * ald + akl);                                \
+      rb[i] = ld4(gc + (size_t)ec_ * ldg + nnc);                                    \
     }                                                                               \
   }
-#define WGRAD_STORE_STAGE()                                                          \
-  {                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
-      *reinterpret_cast<float4*>(&As[(line0 + 8 * i) * LDS_K + 4 * c4]) = ra[i];     \
-      *reinterpret_cast<float4*>(&Bs[(line0 + 8 * i) * LDS_K + 4 * c4]) = rb[i];     \
-    }                                                                                \
+#define WGRAD_STORE_STAGE(buf_, k0_)                                                                               \
+  {                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                              \
+      const bool eok_ = (k0_) + line0 + 8 * i < e1;                                                                \
+      *reinterpret_cast<float4*>(&As[(buf_) * T_SZ + (line0 + 8 * i) * LDS_K + 4 * c4]) = sel4(eok_ && a_ok, ra[i]); \
+      *reinterpret_cast<float4*>(&Bs[(buf_) * T_SZ + (line0 + 8 * i) * LDS_K + 4 * c4]) = sel4(eok_ && b_ok, rb[i]); \
+    }                                                                                                              \
   }
 
   f32x16 acc[2][2];
@@ -285,26 +335,36 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(ROWS_PARAMS, const f
   const int nk = (ne + BK - 1) / BK;
 
   WGRAD_LOAD_STAGE(e0)
-  WGRAD_STORE_STAGE()
+  WGRAD_STORE_STAGE(0, e0)
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
+    const int cur = NBUF == 2 ? (kt & 1) : 0;
     if (kt + 1 < nk) WGRAD_LOAD_STAGE(e0 + (kt + 1) * BK)
+    const float* As_ = As + cur * T_SZ;
+    const float* Bs_ = Bs + cur * T_SZ;
+    float fa[2][2][4], fb[2][2][4];
+#define WGRAD_READ_FRAGS(q_, slot_)                                                                     \
+  {                                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                     \
+      const int kk = 8 * (q_) + 4 * half + s;                                                           \
+      _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) fa[slot_][ti][s] = As_[kk * LDS_K + wm * 64 + ti * 32 + li]; \
+      _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) fb[slot_][tj][s] = Bs_[kk * LDS_K + wn * 64 + tj * 32 + li]; \
+    }                                                                                                   \
+  }
+    WGRAD_READ_FRAGS(0, 0)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float a_[2][4], b_[2][4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kk = 8 * q + 4 * half + s;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) a_[ti][s] = As[kk * LDS_K + wm * 64 + ti * 32 + li];
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) b_[tj][s] = Bs[kk * LDS_K + wn * 64 + tj * 32 + li];
-      }
-      mfma_group(a_, b_, acc);
+    for (int q = 0; q < BK / 8; ++q) {
+      if (q + 1 < BK / 8) WGRAD_READ_FRAGS(q + 1, (q + 1) & 1)
+      mfma_group(fa[q & 1], fb[q & 1], acc);
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      WGRAD_STORE_STAGE()
+    if (NBUF == 1) {
+      __syncthreads();
+      if (kt + 1 < nk) {
+        WGRAD_STORE_STAGE(0, e0 + (kt + 1) * BK)
+        __syncthreads();
+      }
+    } else {
+      if (kt + 1 < nk) WGRAD_STORE_STAGE(cur ^ 1, e0 + (kt + 1) * BK)
       __syncthreads();
     }
   }
@@ -351,6 +411,18 @@ static int fill_rows(const bl_rows_t* a, RowsDev& d, int& K, const char* who) {
   return BL_OK;
 }
 
+// Tuning hook (tools/gemm_bench.py only): BL_GEMM_VARIANT selects an alternative tile pipeline.
+static int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("BL_GEMM_VARIANT");
+    v = s ? atoi(s) : 0;
+  }
+  return v;
+}
+
+#define ROWS_CFG_DEFAULT 32, 1, 2
+
 extern "C" int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_stride, int32_t ldb, int32_t b_is_nk,
                             const float* bias, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
                             int32_t N, int32_t K, int32_t act, bl_dropout_t drop, float* c, int32_t ldc, void* stream) {
@@ -368,16 +440,33 @@ extern "C" int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_
   dim3 grid((M + BM - 1) / BM + (group_ptr ? G : 0), (N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
 #define ROWS_LAUNCH ROWS_ARGS(d), b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc
+#define ROWS_GO(NK_, ACT_, ...) hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, __VA_ARGS__>), grid, dim3(256), 0, st, ROWS_LAUNCH)
   if (b_is_nk) {
     BL_CHECK_ARG(act == BL_ACT_NONE, "bl_gemm_rows: the transposed-B (input gradient) form takes no activation");
-    hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE>), grid, dim3(256), 0, st, ROWS_LAUNCH);
+    switch (gemm_variant()) {
+      case 1: ROWS_GO(true, BL_ACT_NONE, 32, 1, 4); break;
+      case 2: ROWS_GO(true, BL_ACT_NONE, 32, 2, 2); break;
+      case 3: ROWS_GO(true, BL_ACT_NONE, 64, 1, 2); break;
+      case 4: ROWS_GO(true, BL_ACT_NONE, 16, 2, 4); break;
+      case 5: ROWS_GO(true, BL_ACT_NONE, 16, 2, 2); break;
+      default: ROWS_GO(true, BL_ACT_NONE, ROWS_CFG_DEFAULT); break;
+    }
   } else {
     switch (act) {
-      case BL_ACT_NONE: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_NONE>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
-      case BL_ACT_RELU: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_RELU>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
-      case BL_ACT_SIGMOID: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_SIGMOID>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
-      case BL_ACT_TANH: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_TANH>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
-      case BL_ACT_GELU: hipLaunchKernelGGL((gemm_rows_kernel<false, BL_ACT_GELU>), grid, dim3(256), 0, st, ROWS_LAUNCH); break;
+      case BL_ACT_NONE:
+        switch (gemm_variant()) {
+          case 1: ROWS_GO(false, BL_ACT_NONE, 32, 1, 4); break;
+          case 2: ROWS_GO(false, BL_ACT_NONE, 32, 2, 2); break;
+          case 3: ROWS_GO(false, BL_ACT_NONE, 64, 1, 2); break;
+          case 4: ROWS_GO(false, BL_ACT_NONE, 16, 2, 4); break;
+          case 5: ROWS_GO(false, BL_ACT_NONE, 16, 2, 2); break;
+          default: ROWS_GO(false, BL_ACT_NONE, ROWS_CFG_DEFAULT); break;
+        }
+        break;
+      case BL_ACT_RELU: ROWS_GO(false, BL_ACT_RELU, ROWS_CFG_DEFAULT); break;
+      case BL_ACT_SIGMOID: ROWS_GO(false, BL_ACT_SIGMOID, ROWS_CFG_DEFAULT); break;
+      case BL_ACT_TANH: ROWS_GO(false, BL_ACT_TANH, ROWS_CFG_DEFAULT); break;
+      case BL_ACT_GELU: ROWS_GO(false, BL_ACT_GELU, ROWS_CFG_DEFAULT); break;
       default: BL_CHECK_ARG(false, "bl_gemm_rows: unknown activation %d", act);
     }
   }
@@ -402,8 +491,17 @@ extern "C" int bl_gemm_wgrad(const bl_rows_t* a, const float* g_c, int32_t ld_g,
   while (kchunk > 256 && (M / kchunk) * ((K + BM - 1) / BM) * ((N + BN - 1) / BN) < 1024) kchunk >>= 1;
   const int ntiles_n = (N + BN - 1) / BN;
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ((K + BM - 1) / BM) * ntiles_n);
-  hipLaunchKernelGGL(gemm_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, ROWS_ARGS(d), g_c, ld_g, group_ptr,
-                     group_w, G, M, N, K, kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n);
+#define WGRAD_GO(...)                                                                                                  \
+  hipLaunchKernelGGL((gemm_wgrad_kernel<__VA_ARGS__>), grid, dim3(256), 0, (hipStream_t)stream, ROWS_ARGS(d), g_c, ld_g, \
+                     group_ptr, group_w, G, M, N, K, kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n)
+  switch (gemm_variant()) {
+    case 1: WGRAD_GO(32, 1, 4); break;
+    case 2: WGRAD_GO(32, 2, 2); break;
+    case 3: WGRAD_GO(64, 1, 2); break;
+    case 4: WGRAD_GO(16, 2, 4); break;
+    case 5: WGRAD_GO(16, 2, 2); break;
+    default: WGRAD_GO(32, 1, 2); break;
+  }
   BL_LAUNCH_CHECK("bl_gemm_wgrad");
   return BL_OK;
 }

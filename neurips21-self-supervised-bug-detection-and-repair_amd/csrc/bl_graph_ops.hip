@@ -206,16 +206,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------
 // backward through y = drop(act(z + bias)) from y; column sums -> g_bias
+// 256 threads = (256 / tpr) rows x tpr float4-columns (tpr = power of two >= N/4), 128 rows per block
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const float* __restrict__ y, int nrows, int N,
                                                       int ld, int act, bl_drop_dev drop, float* g_z,
-                                                      float* __restrict__ g_bias) {
-  __shared__ float4 red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = (blockIdx.y * 64 + tx) * 4;
+                                                      float* __restrict__ g_bias, int tpr_log2) {
+  __shared__ float4 red[256];
+  const int tpr = 1 << tpr_log2;
+  const int tx = threadIdx.x & (tpr - 1), ty = threadIdx.x >> tpr_log2;
+  const int rows_per_iter = 256 >> tpr_log2;
+  const int c = (blockIdx.y * tpr + tx) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < N) {
-    const int r_end = min(nrows, (int)(blockIdx.x + 1) * 64);
-    for (int r = blockIdx.x * 64 + ty; r < r_end; r += 4) {
+    const int r_end = min(nrows, (int)(blockIdx.x + 1) * 128);
+    for (int r = blockIdx.x * 128 + ty; r < r_end; r += rows_per_iter) {
       const size_t o = (size_t)r * ld + c;
       float4 g = *reinterpret_cast<const float4*>(g_y + o);
       const float4 yv = *reinterpret_cast<const float4*>(y + o);
@@ -237,14 +240,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const fl
     }
   }
   if (g_bias) {
-    red[ty][tx] = acc;
+    red[threadIdx.x] = acc;
     __syncthreads();
     if (ty == 0 && c < N) {
-      const float4 a = red[0][tx], b = red[1][tx], cc = red[2][tx], d = red[3][tx];
-      unsafeAtomicAdd(&g_bias[c + 0], a.x + b.x + cc.x + d.x);
-      unsafeAtomicAdd(&g_bias[c + 1], a.y + b.y + cc.y + d.y);
-      unsafeAtomicAdd(&g_bias[c + 2], a.z + b.z + cc.z + d.z);
-      unsafeAtomicAdd(&g_bias[c + 3], a.w + b.w + cc.w + d.w);
+      float4 t = red[tx];
+      for (int k = 1; k < rows_per_iter; ++k) {
+        const float4 o = red[k * tpr + tx];
+        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+      }
+      unsafeAtomicAdd(&g_bias[c + 0], t.x);
+      unsafeAtomicAdd(&g_bias[c + 1], t.y);
+      unsafeAtomicAdd(&g_bias[c + 2], t.z);
+      unsafeAtomicAdd(&g_bias[c + 3], t.w);
     }
   }
 }
@@ -385,9 +392,11 @@ extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32
   BL_CHECK_ARG(g_y && y && g_z, "bl_act_bwd: null pointer");
   BL_CHECK_ARG(N > 0 && N % 4 == 0 && ld % 4 == 0, "bl_act_bwd: N/ld multiples of 4");
   BL_CHECK_ARG(act != BL_ACT_GELU, "bl_act_bwd: GELU needs the pre-activation (use bl_segment_max_bwd)");
-  dim3 grid((nrows + 63) / 64, (N / 4 + 63) / 64);
+  int tpr_log2 = 0;
+  while ((1 << tpr_log2) < N / 4 && tpr_log2 < 8) ++tpr_log2;
+  dim3 grid((nrows + 127) / 128, (N / 4 + (1 << tpr_log2) - 1) >> tpr_log2);
   hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g_y, y, nrows, N, ld, act,
-                     bl_make_drop(drop), g_z, g_bias);
+                     bl_make_drop(drop), g_z, g_bias, tpr_log2);
   BL_LAUNCH_CHECK("bl_act_bwd");
   return BL_OK;
 }

@@ -1,0 +1,206 @@
+"""CPU: collator, rewrite bookkeeping, registry / model API, persistence -- the host half of the
+drop-in boundary."""
+import copy
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from buglab.data import collate as C
+from buglab.data.synthetic import make_buglab_dataset, make_samples
+
+
+def _reference_style_minibatch(samples):
+    """Element-by-element re-enactment of the reference's extend_minibatch_with offsets
+    (buglab/models/gnn.py:463-542), independent of the vectorised collator."""
+    mb = {k: [] for k in ("has_bug", "correct_candidate_node_idxs", "target_rewrites", "rewrite_to_location_group", "correct_rewrite_idxs",
+                          "text_rewrite_idxs", "candidate_symbol_to_location_group", "correct_candidate_symbols", "candidate_rewrite_idxs",
+                          "swapped_pair_to_call_location_group", "correct_swapped_pair", "pair_rewrite_idxs", "rewrite_to_graph_id")}
+    n_target_nodes = n_rewrites = n_groups = 0
+    for g, s in enumerate(samples):
+        if s.target_location_node_idx is None:
+            mb["has_bug"].append(False); mb["correct_candidate_node_idxs"].append(0)
+        else:
+            mb["has_bug"].append(True); mb["correct_candidate_node_idxs"].append(s.target_location_node_idx + n_target_nodes)
+        n_target_nodes += len(s.graph_data.reference_nodes["candidate_nodes"])
+        in_dp = 0
+        if s.correct_rewrite_target is not None:
+            mb["correct_rewrite_idxs"].append(s.correct_rewrite_target + len(mb["target_rewrites"]))
+        mb["target_rewrites"].extend(s.target_rewrites)
+        mb["rewrite_to_location_group"].extend(t + n_groups for t in s.target_rewrite_to_location_group)
+        mb["text_rewrite_idxs"].extend(t + n_rewrites for t in s.text_rewrite_original_idx)
+        in_dp += len(s.text_rewrite_original_idx)
+        if s.correct_candidate_symbol_node is not None:
+            mb["correct_candidate_symbols"].append(s.correct_candidate_symbol_node + len(mb["candidate_symbol_to_location_group"]))
+        mb["candidate_symbol_to_location_group"].extend(t + n_groups for t in s.candidate_symbol_to_varmisused_node)
+        mb["candidate_rewrite_idxs"].extend(t + n_rewrites for t in s.candidate_rewrite_original_idx)
+        in_dp += len(s.candidate_rewrite_original_idx)
+        if s.correct_swapped_pair is not None:
+            mb["correct_swapped_pair"].append(s.correct_swapped_pair + len(mb["swapped_pair_to_call_location_group"]))
+        mb["swapped_pair_to_call_location_group"].extend(t + n_groups for t in s.swapped_pair_to_call)
+        mb["pair_rewrite_idxs"].extend(t + n_rewrites for t in s.pair_rewrite_original_idx)
+        in_dp += len(s.pair_rewrite_original_idx)
+        n_rewrites += in_dp
+        n_groups += s.num_rewrite_locations_considered
+        mb["rewrite_to_graph_id"].extend([g] * in_dp)
+    return mb
+
+
+def test_collate_matches_reference_offsets_and_csr_invariants():
+    samples = make_samples(7, seed=3, num_nodes=50, num_messages=230, num_edge_types=6, vocab_size=99, num_candidates=7)
+    mb = C.collate_samples(samples, 6)
+    ref = _reference_style_minibatch(samples)
+    for k, v in ref.items():
+        np.testing.assert_array_equal(np.asarray(mb[k]).astype(np.int64), np.asarray(v, dtype=np.int64), err_msg=k)
+    gd = mb["graph_data"]
+    N, E = gd["token_ids"].shape[0], gd["msg_src"].shape[0]
+    assert N == 7 * 50 and E == 7 * 230 and gd["type_ptr"][-1] == E
+    for t in range(6):  # type-major, target-sorted inside a type
+        seg = gd["msg_tgt"][gd["type_ptr"][t]:gd["type_ptr"][t + 1]]
+        assert (np.diff(seg) >= 0).all()
+    # the multiset of (type, src, tgt) triples is preserved
+    want = sorted((t, int(a[0]) + 50 * b, int(a[1]) + 50 * b) for b, s in enumerate(samples) for t, adj in enumerate(s.graph_data.adjacency_lists) for a in adj)
+    types = np.repeat(np.arange(6), np.diff(gd["type_ptr"]))
+    got = sorted(zip(types.tolist(), gd["msg_src"].tolist(), gd["msg_tgt"].tolist()))
+    assert want == got
+    for ptr, items, key in ((gd["tgt_ptr"], gd["tgt_msgs"], gd["msg_tgt"]), (gd["src_ptr"], gd["src_msgs"], gd["msg_src"])):
+        assert ptr[0] == 0 and ptr[-1] == E and sorted(items.tolist()) == list(range(E))
+        for n in (0, 17, N - 1):
+            seg = items[ptr[n]:ptr[n + 1]]
+            assert (key[seg] == n).all() and (np.diff(seg) > 0).all()  # ascending ids -> lowest-id tie rule
+    # every graph's nodes stay inside the graph
+    g_of = gd["node_to_graph"]
+    assert (g_of[gd["msg_src"]] == g_of[gd["msg_tgt"]]).all()
+    assert gd["loc_group_ptr"][-1] == gd["reference_node_ids"]["candidate_nodes"].shape[0] + 7
+
+
+def test_to_device_single_blob_roundtrip():
+    mb = C.collate_samples(make_samples(3, seed=1, num_nodes=30, num_messages=90, num_edge_types=4, vocab_size=50, num_candidates=5), 4)
+    d = C.to_device(mb, "cpu")
+    np.testing.assert_array_equal(d["graph_data"]["msg_src"].numpy(), mb["graph_data"]["msg_src"])
+    np.testing.assert_array_equal(d["graph_data"]["reference_node_ids"]["candidate_swapped_node_ids"].numpy(), mb["graph_data"]["reference_node_ids"]["candidate_swapped_node_ids"])
+    assert d["has_bug"].dtype == torch.bool and d["graph_data"]["msg_src"].dtype == torch.int32
+    assert d["graph_data"]["msg_src"].data_ptr() % 16 == 0 and d["graph_data"]["tgt_ptr"].data_ptr() % 16 == 0
+    # all index tensors are views of ONE allocation
+    base = d["graph_data"]["_blob"]
+    lo, hi = base.data_ptr(), base.data_ptr() + base.numel() * 4
+    assert lo <= d["target_rewrites"].data_ptr() < hi and lo <= d["graph_data"]["src_msgs"].data_ptr() < hi
+
+
+def test_empty_and_ragged_minibatches():
+    from buglab.data.collate import TensorizedGraphData, collate_graphs
+
+    g0 = TensorizedGraphData(np.zeros((3, 2), np.int32), np.ones(3, np.int32), [np.zeros((0, 2), np.int32)] * 2, {"candidate_nodes": np.array([1], np.int32)})
+    g1 = TensorizedGraphData(np.zeros((1, 4), np.int32), np.ones(1, np.int32), [np.array([[0, 0]], np.int32), np.zeros((0, 2), np.int32)], {"candidate_nodes": np.zeros(0, np.int32)})
+    gd = collate_graphs([g0, g1], 2)
+    assert gd["token_ids"].shape == (4, 4) and gd["msg_src"].tolist() == [3] and gd["type_ptr"].tolist() == [0, 1, 1]
+    assert gd["tgt_ptr"].tolist() == [0, 0, 0, 0, 1] and gd["candidate_ptr"].tolist() == [0, 1, 1]
+
+
+def _model(hidden=32, **kw):
+    from buglab.models.modelregistry import load_model
+
+    return load_model({"modelName": "gnn-mlp", "hidden_state_size": hidden, "num_layers": 4, **kw}, Path("/tmp/_bl_test.pkl.gz"))[0]
+
+
+def test_registry_contract():
+    from buglab.models import modelregistry as R
+
+    names = set(R.construct_model_dict(R.gnn, R.seq_transformer))
+    assert names == {"gnn-mlp", "ggnn", "seq-great", "seq-rat", "seq-transformer", "seq-gru"}  # reference :129-137
+    with pytest.raises(ValueError):
+        R.load_model({"modelName": "nope"}, Path("/tmp/x.pkl.gz"))
+    with pytest.raises(AssertionError):
+        R.load_model({"modelName": "gnn-mlp"}, Path("/tmp/x.pt"))  # reference :147
+    assert R.buggy_sample_weight_schedule(0.5)(3) == 0.5
+    assert R.buggy_sample_weight_schedule("warmdown(10, 0.2)")(5) == pytest.approx(0.6)
+    model, nn, init = R.load_model({"modelName": "gnn-mlp"}, Path("/tmp/x.pkl.gz"))
+    assert nn is None and init is True
+    assert model.gnn_model.node_representation_model.vocabulary_size == 15000 and model.gnn_model.max_nodes_per_graph == 35000
+
+
+def test_tensorize_rewrite_bookkeeping_and_drop_rule():
+    data = make_buglab_dataset(10, seed=4)
+    model = _model()
+    model.compute_metadata(copy.deepcopy(data))
+    # 4 forward kinds + HasSubtoken, reversed, + self loops (gnn-mlp: add_self_edge=True)
+    assert model.gnn_model.edge_types == ["Child", "HasSubtoken", "NextToken", "OccurrenceOf", "Sibling"]
+    assert model.gnn_model.num_presented_edge_types == 11
+    d = copy.deepcopy(data[0])
+    t = model.tensorize(d)
+    target = d["target_fix_action_idx"]
+    scout = d["candidate_rewrite_metadata"][target][0]
+    n_correct = sum(x is not None for x in (t.correct_rewrite_target, t.correct_candidate_symbol_node, t.correct_swapped_pair))
+    assert n_correct == 1
+    # training keeps only rewrites at the target location (reference basemodel.py:119-121)
+    tnode = d["graph"]["reference_nodes"][target]
+    kept = sorted(list(t.text_rewrite_original_idx) + list(t.candidate_rewrite_original_idx) + list(t.pair_rewrite_original_idx))
+    assert kept == [i for i, n in enumerate(d["graph"]["reference_nodes"]) if n == tnode]
+    if scout == "ArgSwapRewriteScout":
+        assert t.correct_swapped_pair is not None
+    with model._tensorize_all_location_rewrites():
+        t_all = model.tensorize(copy.deepcopy(data[0]))
+    assert len(t_all.text_rewrite_original_idx) + len(t_all.candidate_rewrite_original_idx) + len(t_all.pair_rewrite_original_idx) == len(d["candidate_rewrites"])
+    model.gnn_model.max_nodes_per_graph = 10
+    assert model.tensorize(copy.deepcopy(data[1])) is None  # reference gnn.py:404-405
+    # self-loop type is last and has one edge per node
+    model.gnn_model.max_nodes_per_graph = 35000
+    assert t.graph_data.adjacency_lists[-1].shape[0] == t.graph_data.num_nodes
+
+
+def test_minibatch_iterator_save_restore_and_unbatching(tmp_path):
+    data = make_buglab_dataset(9, seed=5)
+    model = _model()
+    model.compute_metadata(copy.deepcopy(data))
+    nn = model.build_neural_module()
+    assert nn._gnn.mp[0].W.shape == (11, 64, 32) and nn._gnn.mp[3].W.shape == (11, 128, 64)
+    mbs = list(model.minibatch_iterator(model.tensorize_dataset(copy.deepcopy(data), return_input_data=True), "cpu", max_minibatch_size=4))
+    assert [len(o) for _, o in mbs] == [4, 4, 1]
+    path = tmp_path / "m.pkl.gz"
+    model.save(path, nn)
+    m2, nn2 = type(model).restore_model(path, "cpu")
+    assert all(torch.equal(a, b) for a, b in zip(nn.state_dict().values(), nn2.state_dict().values()))
+    assert m2.gnn_model.edge_types == model.gnn_model.edge_types
+    # un-batching (reference basemodel.py:240-346) with fabricated log-probabilities
+    with model._tensorize_all_location_rewrites():
+        mb, originals = next(iter(model.minibatch_iterator(model.tensorize_dataset(copy.deepcopy(data[:3]), return_input_data=True), "cpu", 50)))
+    C_ = mb["graph_data"]["reference_node_ids"]["candidate_nodes"].shape[0]
+    ids = torch.cat([mb["graph_data"]["reference_node_graph_idx"]["candidate_nodes"], torch.arange(3, dtype=torch.int32)])
+    loc = torch.arange(C_ + 3, dtype=torch.float32) * -0.01
+    text, var, swap = (torch.arange(mb[k].shape[0], dtype=torch.float32) + o for k, o in (("rewrite_to_location_group", 100.0), ("candidate_symbol_to_location_group", 200.0), ("swapped_pair_to_call_location_group", 300.0)))
+    res = list(model._iter_per_sample_results(mb, ids, loc, swap, 3, originals, text, var))
+    assert len(res) == 3
+    for point, loc_lp, rewrite_lp in res:
+        assert len(rewrite_lp) == len(point["candidate_rewrites"]) and -1 in loc_lp
+        assert set(k for k in loc_lp if k >= 0) == set(point["graph"]["reference_nodes"])
+        for (scout, _), lp in zip(point["candidate_rewrite_metadata"], rewrite_lp):
+            assert (300 <= lp < 400) if scout == "ArgSwapRewriteScout" else ((200 <= lp < 300) if scout == "VariableMisuseRewriteScout" else (100 <= lp < 200))
+
+
+def test_msgpack_roundtrip_and_split_identifier(tmp_path):
+    from buglab.runtime.vocabulary import Vocabulary, split_identifier_into_parts
+    from buglab.utils.msgpackutils import load_all_msgpack_l_gz, save_msgpack_l_gz
+
+    data = make_buglab_dataset(3, seed=6)
+    save_msgpack_l_gz(data, tmp_path / "a.msgpack.l.gz")
+    back = list(load_all_msgpack_l_gz(str(tmp_path)))
+    assert len(back) == 3 and back[0]["graph"]["nodes"] == data[0]["graph"]["nodes"]
+    assert split_identifier_into_parts("getHTTPResponse_code2") == ["get", "http", "response", "code", "2"]
+    assert split_identifier_into_parts("__") == ["__"]
+    v = Vocabulary.create_vocabulary(["a", "a", "b"], max_size=10, count_threshold=2, add_unk=True)
+    assert v.get_id_or_unk("a") != v.get_id_or_unk("zzz") == v.get_id_or_unk("b")
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a ROCm device the module must raise, not compute."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from buglab.models import hip_ops
+    from buglab.models.gnn import build_gnn_mlp_module
+
+    m = build_gnn_mlp_module(32, 4, 3, 50)
+    mb = C.to_device(C.collate_samples(make_samples(2, num_nodes=20, num_messages=50, num_edge_types=3, vocab_size=50, num_candidates=4), 3), "cpu")
+    with pytest.raises(hip_ops.HipOpsUnavailable):
+        m(**mb)

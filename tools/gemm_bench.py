@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the three MFMA GEMM forms at BASELINE config c2 shapes (one MP layer's
+message GEMM, input-gradient GEMM and weight-gradient GEMM).  Used to tune csrc/bl_gemm.hip."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "neurips21-self-supervised-bug-detection-and-repair_amd"))
+import numpy as np
+import torch
+
+from buglab.models import hip_ops as ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=128000)
+    ap.add_argument("--msgs", type=int, default=640000)
+    ap.add_argument("--din", type=int, default=128)
+    ap.add_argument("--dm", type=int, default=128)
+    ap.add_argument("--types", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--which", default="fwd,nk,wgrad")
+    a = ap.parse_args()
+    rng = np.random.default_rng(0)
+    N, E, Din, Dm, T = a.nodes, a.msgs, a.din, a.dm, a.types
+    w = 1.0 / np.arange(1, T + 1)
+    sizes = np.floor(w / w.sum() * E).astype(np.int64)
+    sizes[0] += E - sizes.sum()
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).cuda()
+    # graph-local sources like the real collator: messages of a type sorted by target
+    tgt = np.concatenate([np.sort(rng.integers(0, N, s)) for s in sizes]).astype(np.int32)
+    src = (tgt // 2000 * 2000 + rng.integers(0, 2000, E)).clip(0, N - 1).astype(np.int32)
+    h = torch.randn(N, Din, device="cuda")
+    W = torch.randn(T, 2 * Din, Dm, device="cuda") / np.sqrt(2 * Din)
+    G = torch.randn(E, Dm, device="cuda")
+    src, tgt = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    out = torch.empty(E, Dm, device="cuda")
+    ga = torch.empty(E, 2 * Din, device="cuda")
+    gw = torch.zeros_like(W)
+    flop = 2.0 * E * 2 * Din * Dm
+    fns = {
+        "fwd": lambda: ops.gemm_rows([(h, src), (h, tgt)], W, E, Dm, b_group_stride=2 * Din * Dm, ldb=Dm, group_ptr=ptr, G=T, out=out),
+        "nk": lambda: ops.gemm_rows([(G, None)], W, E, 2 * Din, b_is_nk=True, b_group_stride=2 * Din * Dm, ldb=Dm, group_ptr=ptr, G=T, out=ga),
+        "wgrad": lambda: ops.gemm_wgrad([(h, src), (h, tgt)], G, E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T),
+    }
+    for name in a.which.split(","):
+        f = fns[name]
+        for _ in range(2):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        print(f"{name:6s} E={E} Din={Din} Dm={Dm}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s  ({flop / ms / 1e9 / 157.3:.1%} of fp32 MFMA peak)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
