@@ -79,6 +79,16 @@ int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_stride, int
                  const float* bias, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M, int32_t N,
                  int32_t K, int32_t act, bl_dropout_t drop, float* c, int32_t ldc, void* stream);
 
+/* Input-gradient GEMM with the max-aggregation ROUTING folded into the operand load:
+ *   row r of the left operand is  G[r, k] = (winner[idx[r], k] == r) ? a.x[0][idx[r], k] : 0
+ * (a has exactly one gathered source: a.x[0] = d loss / d aggregate per node [N, K], idx = target node
+ * of message r; `winner` = the arg-max table of bl_segment_max_fwd), then C = G . B_g^T as in
+ * bl_gemm_rows with b_is_nk = 1.  Replaces torch_scatter's scatter_max backward (a gather of the
+ * gradient at arg) + the autograd of the per-type Linear, without materialising the [E, Dm] gradient. */
+int bl_gemm_rows_routed(const bl_rows_t* a, const int32_t* winner, int32_t ld_winner, const float* b,
+                        int64_t b_group_stride, int32_t ldb, const int32_t* group_ptr, const int32_t* group_w, int32_t G,
+                        int32_t M, int32_t N, int32_t K, float* c, int32_t ldc, void* stream);
+
 /* Weight-gradient GEMM (reduction over rows, split across row chunks, fp32 atomics):
  *   gw[group_w[g]][0:K, 0:N] += rows(a)[rows of g, 0:K]^T . g_c[rows of g, 0:N]
  * gw must be zeroed (or hold the running gradient) by the caller.  autograd equivalent:
@@ -86,26 +96,35 @@ int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_stride, int
 int bl_gemm_wgrad(const bl_rows_t* a, const float* g_c, int32_t ld_g, const int32_t* group_ptr,
                   const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
                   int64_t gw_group_stride, int32_t ld_gw, void* stream);
+/* the same with the routed right operand  g_c[r, n] = (winner[g_idx[r], n] == r) ? g_node[g_idx[r], n] : 0 */
+int bl_gemm_wgrad_routed(const bl_rows_t* a, const float* g_node, int32_t ld_g, const int32_t* g_idx,
+                         const int32_t* winner, int32_t ld_winner, const int32_t* group_ptr, const int32_t* group_w,
+                         int32_t G, int32_t M, int32_t N, int32_t K, float* gw, int64_t gw_group_stride, int32_t ld_gw,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * M2(+M3a)  segmented max with argmax, optional fused LayerNorm.
  *   out[v, d] = max_{i in seg_ptr[v]..seg_ptr[v+1]} act(x[item(i), d]),  item(i) = seg_items ? seg_items[i] : i
  *   arg[v, d] = that item (ties: first in segment order), -1 and out = 0 for an empty segment;
- *   if ln_g != NULL also  ln_out[v,:] = LayerNorm(out[v,:]; ln_g, ln_b, eps), mean[v], rstd[v].
+ *   if ln_g != NULL also  ln_out[v,:] = LayerNorm(out[v,:]; ln_g, ln_b, eps), mean[v], rstd[v];
+ *   if dact != NULL also  dact[v, d] = act'(x[arg[v, d], d]) (0 for an empty segment): with it the
+ *   backward pass needs only [nseg, D] arrays, never the [items, D] pre-activations again.
  * Replaces torch_scatter.scatter_max at ptgnn's "max" aggregation (gnnlayerdefs.py:11,21) and at
  * buglab/models/layers/localizationmodule.py:56-58, plus ptgnn's nn.LayerNorm. */
 int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg,
                        int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g, const float* ln_b,
-                       float eps, float* ln_out, float* mean, float* rstd, void* stream);
+                       float eps, float* ln_out, float* mean, float* rstd, float* dact, void* stream);
 
 /* backward of the segmented max, gather form (deterministic, no atomics):
  *   g_x[i, d] = (arg[seg_of[i], d] == i) ? g_out[seg_of[i], d] * act'(x[i, d]) : 0      (g_x may alias x) */
 int bl_segment_max_bwd(const float* g_out, const int32_t* arg, const float* x, int32_t ldx, const int32_t* seg_of,
                        int32_t nitems, int32_t D, int32_t act, float* g_x, void* stream);
 
-/* LayerNorm backward (rows of D <= 512):  g_x, and g_gamma/g_beta ACCUMULATED with fp32 atomics. */
+/* LayerNorm backward (rows of D <= 512):  g_x (times post_scale elementwise if not NULL -- used to
+ * fold the message activation's derivative `dact` in), and g_gamma/g_beta ACCUMULATED with fp32 atomics. */
 int bl_layernorm_bwd(const float* g_y, const float* x, const float* mean, const float* rstd, const float* gamma,
-                     int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta, void* stream);
+                     int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta, const float* post_scale,
+                     void* stream);
 
 /* activation(+dropout) backward from the OUTPUT y of y = drop(act(z + bias)); g_bias (if not NULL)
  * accumulates column sums of g_z with fp32 atomics.  g_z may alias g_y.  (GELU is not supported

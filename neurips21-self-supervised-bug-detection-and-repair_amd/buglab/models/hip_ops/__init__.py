@@ -40,10 +40,12 @@ _SIGNATURES = {
     "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows": ([POINTER(bl_rows_t), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gemm_rows_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
-    "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
+    "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_segment_log_softmax_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p], ctypes.c_int),
@@ -209,6 +211,35 @@ def gemm_rows(sources, b, M, N, *, b_is_nk=False, b_group_stride=0, ldb=None, bi
     return out
 
 
+def gemm_rows_routed(g_node, node_of_row, winner, b, M, N, *, b_group_stride=0, ldb=None, group_ptr=None, group_w=None, G=1):
+    """C[r, :] = (g_node[node_of_row[r]] masked to the entries row r won) . B_g^T  (include/buglab_hip.h)."""
+    rows, K = _rows([(g_node, node_of_row)])
+    out = torch.empty((M, N), dtype=torch.float32, device=b.device)
+    if M == 0:
+        return out
+    with _timed("gemm_rows_nk_routed", 2.0 * M * N * K):
+        _check(
+            load_library().bl_gemm_rows_routed(ctypes.byref(rows), _i32(winner).data_ptr(), winner.stride(0), _f32(b).data_ptr(),
+                                               int(b_group_stride), int(ldb if ldb is not None else b.shape[-1]), _p(group_ptr),
+                                               _p(group_w), int(G), int(M), int(N), int(K), out.data_ptr(), out.stride(0), _stream()),
+            "bl_gemm_rows_routed")
+    return out
+
+
+def gemm_wgrad_routed(sources, g_node, node_of_row, winner, M, N, gw, *, gw_group_stride=0, group_ptr=None, group_w=None, G=1):
+    rows, K = _rows(sources)
+    if M == 0:
+        return gw
+    with _timed("gemm_wgrad_routed", 2.0 * M * N * K):
+        _check(
+            load_library().bl_gemm_wgrad_routed(ctypes.byref(rows), _f32(g_node).data_ptr(), g_node.stride(0),
+                                                _i32(node_of_row).data_ptr(), _i32(winner).data_ptr(), winner.stride(0),
+                                                _p(group_ptr), _p(group_w), int(G), int(M), int(N), int(K), _f32(gw).data_ptr(),
+                                                int(gw_group_stride), int(gw.shape[-1]), _stream()),
+            "bl_gemm_wgrad_routed")
+    return gw
+
+
 def gemm_wgrad(sources, g_c, M, N, gw, *, gw_group_stride=0, group_ptr=None, group_w=None, G=1):
     rows, K = _rows(sources)
     _f32(g_c, "g_c")
@@ -223,8 +254,8 @@ def gemm_wgrad(sources, g_c, M, N, gw, *, gw_group_stride=0, group_ptr=None, gro
     return gw
 
 
-def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5):
-    """-> (out [nseg, D], arg int32 [nseg, D], ln_out | None, mean | None, rstd | None)"""
+def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5, want_dact=False):
+    """-> (out [nseg, D], arg int32 [nseg, D], ln_out | None, mean | None, rstd | None[, dact])"""
     _f32(x, "x")
     D = x.shape[1]
     dev = x.device
@@ -235,11 +266,14 @@ def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5):
         ln_out = torch.empty((nseg, D), dtype=torch.float32, device=dev)
         mean = torch.empty((nseg,), dtype=torch.float32, device=dev)
         rstd = torch.empty((nseg,), dtype=torch.float32, device=dev)
+    dact = torch.empty((nseg, D), dtype=torch.float32, device=dev) if want_dact else None
     _check(
         load_library().bl_segment_max_fwd(x.data_ptr(), x.stride(0), _i32(seg_ptr).data_ptr(), _p(seg_items), int(nseg), int(D),
                                           int(act), out.data_ptr(), arg.data_ptr(), _p(ln[0]) if ln else None,
-                                          _p(ln[1]) if ln else None, float(eps), _p(ln_out), _p(mean), _p(rstd), _stream()),
+                                          _p(ln[1]) if ln else None, float(eps), _p(ln_out), _p(mean), _p(rstd), _p(dact), _stream()),
         "bl_segment_max_fwd")
+    if want_dact:
+        return out, arg, ln_out, mean, rstd, dact
     return out, arg, ln_out, mean, rstd
 
 
@@ -254,13 +288,13 @@ def segment_max_bwd(g_out, arg, x, seg_of, act=ACT_NONE, out=None):
     return out
 
 
-def layernorm_bwd(g_y, x, mean, rstd, gamma, g_gamma, g_beta):
+def layernorm_bwd(g_y, x, mean, rstd, gamma, g_gamma, g_beta, post_scale=None):
     n, D = x.shape
     g_x = torch.empty_like(x)
     _check(
         load_library().bl_layernorm_bwd(_f32(g_y).data_ptr(), _f32(x).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                         _f32(gamma).data_ptr(), int(n), int(D), g_x.data_ptr(), g_gamma.data_ptr(),
-                                        g_beta.data_ptr(), _stream()),
+                                        g_beta.data_ptr(), _p(post_scale), _stream()),
         "bl_layernorm_bwd")
     return g_x
 
@@ -336,9 +370,11 @@ def embed_subtoken_max(table, ids, lens, drop: Dropout = NO_DROPOUT):
 class _MpLayer(torch.autograd.Function):
     """One MlpMessagePassingLayer: message GEMM -> segmented max(+GELU) + LayerNorm -> dense+tanh+dropout.
 
-    Saved for backward: the pre-activation messages [E, Dm] (overwritten in place by their own
-    gradient during backward), argmax [N, Dm] int32, the aggregate, LayerNorm statistics/output and
-    the layer output.  Single backward only (buffers are recycled)."""
+    Saved for backward: only per-NODE arrays -- argmax [N, Dm] int32, the message activation's
+    derivative at the winner `dact` [N, Dm], the aggregate, LayerNorm statistics/output and the layer
+    output.  The [E, Dm] messages are dropped right after the segmented max: backward re-creates the
+    (80 % zero) message gradient on the fly inside the two GEMMs' operand loads
+    (bl_gemm_rows_routed / bl_gemm_wgrad_routed) from the node gradient and the winner table."""
 
     @staticmethod
     def forward(ctx, h, W, ln_g, ln_b, Wd, bd, g: GraphIndex, msg_act: int, drop: Dropout):
@@ -350,14 +386,18 @@ class _MpLayer(torch.autograd.Function):
         assert K2 == 2 * Din and T == g.num_types and N == g.num_nodes
         pre = gemm_rows([(h, g.msg_src), (h, g.msg_tgt)], _f32(W, "W"), E, Dm, b_group_stride=K2 * Dm, ldb=Dm,
                         group_ptr=g.type_ptr, G=T)
-        agg, arg, ln_out, mean, rstd = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)))
+        agg, arg, ln_out, mean, rstd, dact = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)),
+                                                         want_dact=True)
+        del pre
+        if msg_act == ACT_NONE:
+            dact = None  # derivative is identically 1
         out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
-        ctx.saved = (h, W, ln_g, Wd, pre, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop)
+        ctx.saved = (h, W, ln_g, Wd, dact, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        h, W, ln_g, Wd, pre, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
+        h, W, ln_g, Wd, dact, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
         ctx.saved = None
         N, Din = h.shape
         T, K2, Dm = W.shape
@@ -374,14 +414,14 @@ class _MpLayer(torch.autograd.Function):
         # LayerNorm
         g_lng = torch.zeros((Dm,), dtype=torch.float32, device=dev)
         g_lnb = torch.zeros((Dm,), dtype=torch.float32, device=dev)
-        g_agg = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb)
-        # max aggregation (+ message activation): route to the winning message, in place over `pre`
-        g_pre = segment_max_bwd(g_agg, arg, pre, g.msg_tgt, act=msg_act, out=pre)
-        # per-edge-type weights
+        # LayerNorm (+ the message activation's derivative at each winner): d loss / d (winning pre-activation) per node
+        gq = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact)
+        # per-edge-type weights; message m's gradient row = gq[tgt(m)] masked to the channels m won
         g_W = torch.zeros_like(W)
-        gemm_wgrad([(h, g.msg_src), (h, g.msg_tgt)], g_pre, E, Dm, g_W, gw_group_stride=K2 * Dm, group_ptr=g.type_ptr, G=T)
+        gemm_wgrad_routed([(h, g.msg_src), (h, g.msg_tgt)], gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K2 * Dm,
+                          group_ptr=g.type_ptr, G=T)
         # node states: per-message input gradients, then segmented sums over the src / tgt CSRs
-        g_a = gemm_rows([(g_pre, None)], W, E, K2, b_is_nk=True, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
+        g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K2, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
         g_h = torch.empty((N, Din), dtype=torch.float32, device=dev)
         _check(
             load_library().bl_mp_scatter_grad(g_a.data_ptr(), g_a.stride(0), g.src_ptr.data_ptr(), g.src_msgs.data_ptr(),

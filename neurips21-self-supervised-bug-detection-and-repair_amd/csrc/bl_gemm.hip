@@ -111,8 +111,9 @@ __device__ __forceinline__ void mfma_group(const float (&a_)[2][4], const float 
                            : __builtin_amdgcn_mfma_f32_32x32x2f32(a_[ti][s], b_[tj][s], acc[ti][tj], 0, 0, 0);
 }
 
-template <bool B_NK, int ACT, int BK, int NBUF, int MINW>
-__global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const float* __restrict__ b,
+template <bool B_NK, int ACT, int BK, int NBUF, int MINW, bool MASKED>
+__global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const int* __restrict__ mask_arg,
+                                                              int mask_ld, const float* __restrict__ b,
                                                               long long strideB, int ldb,
                                                               const float* __restrict__ bias,
                                                               const int* __restrict__ group_ptr,
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
   __syncthreads();
 
   float4 ra[NLD], rb[NLD];
+  int4 ia[MASKED ? NLD : 1];  // winner ids of the routing mask (source 0), compared at LDS-store time
   const int a_c4 = tid % A_LPR, a_line0 = tid / A_LPR;  // MN-major loader
   const int k_c4 = tid & 31, k_line0 = tid >> 5;         // K-major loader: 32 lanes per 512-byte line
   const int nk = (K + BK - 1) / BK;
@@ -164,6 +166,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                     \
       const int line_ = a_line0 + A_LSTEP * i;                                                            \
       ra[i] = ld4(base_ + (size_t)rowidx[j_][line_] * ld_ + kl_);                                         \
+      if (MASKED)                                                                                         \
+        ia[i] = *reinterpret_cast<const int4*>(mask_arg + (size_t)rowidx[0][line_] * mask_ld + kc_);      \
     }                                                                                                     \
     if (!B_NK) {                                                                                          \
       const int n_ = n0 + 4 * k_c4;                                                                       \
@@ -189,7 +193,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
     float* Bs_w = Bs + (buf_) * B_SZ;                                                                        \
     const bool kok_ = (k0_) + 4 * a_c4 < K;                                                                  \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
-      *reinterpret_cast<float4*>(&As_w[(a_line0 + A_LSTEP * i) * LDS_MN + 4 * a_c4]) = sel4(kok_, ra[i]);    \
+      float4 av_ = ra[i];                                                                                    \
+      if (MASKED) { /* routing mask: keep element k of row r only where r is the recorded winner */          \
+        const int rid_ = row0 + a_line0 + A_LSTEP * i;                                                       \
+        av_.x = ia[i].x == rid_ ? av_.x : 0.f; av_.y = ia[i].y == rid_ ? av_.y : 0.f;                        \
+        av_.z = ia[i].z == rid_ ? av_.z : 0.f; av_.w = ia[i].w == rid_ ? av_.w : 0.f;                        \
+      }                                                                                                      \
+      *reinterpret_cast<float4*>(&As_w[(a_line0 + A_LSTEP * i) * LDS_MN + 4 * a_c4]) = sel4(kok_, av_);      \
       if (!B_NK)                                                                                             \
         *reinterpret_cast<float4*>(&Bs_w[(k_line0 + 8 * i) * LDS_K + 4 * k_c4]) =                             \
             sel4(n0 + 4 * k_c4 < N && (k0_) + k_line0 + 8 * i < K, rb[i]);                                    \
@@ -284,8 +294,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
   }
 }
 
-template <int BK, int NBUF, int MINW>
+template <int BK, int NBUF, int MINW, bool GMASK>
 __global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, const float* __restrict__ gc, int ldg,
+                                                               const int* __restrict__ g_idx,
+                                                               const int* __restrict__ g_mask, int ld_mask,
                                                                const int* __restrict__ group_ptr,
                                                                const int* __restrict__ group_w, int G, int M, int N,
                                                                int K, int kchunk, float* __restrict__ gw_base,
@@ -305,6 +317,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, cons
   const int wsel = group_w ? group_w[g] : g;
 
   float4 ra[NLD], rb[NLD];
+  int4 ib[GMASK ? NLD : 1];
   const int c4 = tid & 31, line0 = tid >> 5;
   const int fi = i0 + 4 * c4;  // this thread's feature columns of the A rows
   const int nn = n0 + 4 * c4;  // this thread's columns of the G rows
@@ -326,7 +339,9 @@ __global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, cons
       const int ec_ = eok_ ? e_ : e0;                                               \
       const int row_ = aidx ? aidx[ec_] : ec_;                                      \
       ra[i] = ld4(abase + (size_t)row_ * ald + akl);                                \
-      rb[i] = ld4(gc + (size_t)ec_ * ldg + nnc);                                    \
+      const int grow_ = g_idx ? g_idx[ec_] : ec_;                                   \
+      rb[i] = ld4(gc + (size_t)grow_ * ldg + nnc);                                  \
+      if (GMASK) ib[i] = *reinterpret_cast<const int4*>(g_mask + (size_t)grow_ * ld_mask + nnc); \
     }                                                                               \
   }
 #define WGRAD_STORE_STAGE(buf_, k0_)                                                                               \
@@ -334,7 +349,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, cons
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                              \
       const bool eok_ = (k0_) + line0 + 8 * i < e1;                                                                \
       *reinterpret_cast<float4*>(&As[(buf_) * T_SZ + (line0 + 8 * i) * LDS_K + 4 * c4]) = sel4(eok_ && a_ok, ra[i]); \
-      *reinterpret_cast<float4*>(&Bs[(buf_) * T_SZ + (line0 + 8 * i) * LDS_K + 4 * c4]) = sel4(eok_ && b_ok, rb[i]); \
+      float4 bv_ = rb[i];                                                                                          \
+      if (GMASK) {                                                                                                 \
+        const int eid_ = (k0_) + line0 + 8 * i;                                                                    \
+        bv_.x = ib[i].x == eid_ ? bv_.x : 0.f; bv_.y = ib[i].y == eid_ ? bv_.y : 0.f;                              \
+        bv_.z = ib[i].z == eid_ ? bv_.z : 0.f; bv_.w = ib[i].w == eid_ ? bv_.w : 0.f;                              \
+      }                                                                                                            \
+      *reinterpret_cast<float4*>(&Bs[(buf_) * T_SZ + (line0 + 8 * i) * LDS_K + 4 * c4]) = sel4(eok_ && b_ok, bv_);  \
     }                                                                                                              \
   }
 
@@ -438,7 +459,7 @@ static int gemm_variant() {
 
 #define ROWS_CFG_DEFAULT 32, 1, 2
 
-extern "C" int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_stride, int32_t ldb, int32_t b_is_nk,
+static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t mask_ld, const float* b, int64_t b_group_stride, int32_t ldb, int32_t b_is_nk,
                             const float* bias, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
                             int32_t N, int32_t K, int32_t act, bl_dropout_t drop, float* c, int32_t ldc, void* stream) {
   if (M == 0) return BL_OK;
@@ -454,10 +475,13 @@ extern "C" int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_
   const bl_drop_dev dd = bl_make_drop(drop);
   dim3 grid((M + BM - 1) / BM + (group_ptr ? G : 0), (N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
-#define ROWS_LAUNCH ROWS_ARGS(d), b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc
-#define ROWS_GO(NK_, ACT_, ...) hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, __VA_ARGS__>), grid, dim3(256), 0, st, ROWS_LAUNCH)
+#define ROWS_LAUNCH ROWS_ARGS(d), mask_arg, mask_ld, b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc
+#define ROWS_GO(NK_, ACT_, ...) hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, __VA_ARGS__, false>), grid, dim3(256), 0, st, ROWS_LAUNCH)
   if (b_is_nk) {
     BL_CHECK_ARG(act == BL_ACT_NONE, "bl_gemm_rows: the transposed-B (input gradient) form takes no activation");
+    if (mask_arg) {
+      hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, 32, 1, 2, true>), grid, dim3(256), 0, st, ROWS_LAUNCH);
+    } else
     switch (gemm_variant()) {
       case 1: ROWS_GO(true, BL_ACT_NONE, 32, 1, 4); break;
       case 2: ROWS_GO(true, BL_ACT_NONE, 32, 2, 2); break;
@@ -467,6 +491,7 @@ extern "C" int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_
       default: ROWS_GO(true, BL_ACT_NONE, ROWS_CFG_DEFAULT); break;
     }
   } else {
+    BL_CHECK_ARG(mask_arg == nullptr, "bl_gemm_rows_masked: only the transposed-B (input gradient) form takes a routing mask");
     switch (act) {
       case BL_ACT_NONE:
         switch (gemm_variant()) {
@@ -489,7 +514,25 @@ extern "C" int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_
   return BL_OK;
 }
 
-extern "C" int bl_gemm_wgrad(const bl_rows_t* a, const float* g_c, int32_t ld_g, const int32_t* group_ptr,
+extern "C" int bl_gemm_rows(const bl_rows_t* a, const float* b, int64_t b_group_stride, int32_t ldb, int32_t b_is_nk,
+                            const float* bias, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
+                            int32_t N, int32_t K, int32_t act, bl_dropout_t drop, float* c, int32_t ldc, void* stream) {
+  return gemm_rows_impl(a, nullptr, 0, b, b_group_stride, ldb, b_is_nk, bias, group_ptr, group_w, G, M, N, K, act, drop, c,
+                        ldc, stream);
+}
+
+extern "C" int bl_gemm_rows_routed(const bl_rows_t* a, const int32_t* winner, int32_t ld_winner, const float* b,
+                                   int64_t b_group_stride, int32_t ldb, const int32_t* group_ptr, const int32_t* group_w,
+                                   int32_t G, int32_t M, int32_t N, int32_t K, float* c, int32_t ldc, void* stream) {
+  BL_CHECK_ARG(a && a->nsrc == 1 && a->idx[0] != nullptr && winner != nullptr && ld_winner % 4 == 0,
+               "bl_gemm_rows_routed: needs exactly one gathered source and a winner table");
+  bl_dropout_t nodrop = {0.f, 0u, 0u};
+  return gemm_rows_impl(a, winner, ld_winner, b, b_group_stride, ldb, 1, nullptr, group_ptr, group_w, G, M, N, K,
+                        BL_ACT_NONE, nodrop, c, ldc, stream);
+}
+
+static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, const int32_t* g_idx,
+                           const int32_t* g_mask, int32_t ld_mask, const int32_t* group_ptr,
                              const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
                              int64_t gw_group_stride, int32_t ld_gw, void* stream) {
   if (M == 0) return BL_OK;
@@ -506,9 +549,17 @@ extern "C" int bl_gemm_wgrad(const bl_rows_t* a, const float* g_c, int32_t ld_g,
   while (kchunk > 256 && (M / kchunk) * ((K + BM - 1) / BM) * ((N + BN - 1) / BN) < 1024) kchunk >>= 1;
   const int ntiles_n = (N + BN - 1) / BN;
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ((K + BM - 1) / BM) * ntiles_n);
-#define WGRAD_GO(...)                                                                                                  \
-  hipLaunchKernelGGL((gemm_wgrad_kernel<__VA_ARGS__>), grid, dim3(256), 0, (hipStream_t)stream, ROWS_ARGS(d), g_c, ld_g, \
-                     group_ptr, group_w, G, M, N, K, kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n)
+#define WGRAD_GO(...)                                                                                                      \
+  {                                                                                                                        \
+    if (g_mask)                                                                                                            \
+      hipLaunchKernelGGL((gemm_wgrad_kernel<__VA_ARGS__, true>), grid, dim3(256), 0, (hipStream_t)stream, ROWS_ARGS(d), g_c, \
+                         ld_g, g_idx, g_mask, ld_mask, group_ptr, group_w, G, M, N, K, kchunk, gw,                           \
+                         (long long)gw_group_stride, ld_gw, ntiles_n);                                                       \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((gemm_wgrad_kernel<__VA_ARGS__, false>), grid, dim3(256), 0, (hipStream_t)stream, ROWS_ARGS(d),   \
+                         g_c, ld_g, g_idx, g_mask, ld_mask, group_ptr, group_w, G, M, N, K, kchunk, gw,                      \
+                         (long long)gw_group_stride, ld_gw, ntiles_n);                                                       \
+  }
   switch (gemm_variant()) {
     case 1: WGRAD_GO(32, 1, 4); break;
     case 2: WGRAD_GO(32, 2, 2); break;
@@ -519,4 +570,19 @@ extern "C" int bl_gemm_wgrad(const bl_rows_t* a, const float* g_c, int32_t ld_g,
   }
   BL_LAUNCH_CHECK("bl_gemm_wgrad");
   return BL_OK;
+}
+
+extern "C" int bl_gemm_wgrad(const bl_rows_t* a, const float* g_c, int32_t ld_g, const int32_t* group_ptr,
+                             const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
+                             int64_t gw_group_stride, int32_t ld_gw, void* stream) {
+  return gemm_wgrad_impl(a, g_c, ld_g, nullptr, nullptr, 0, group_ptr, group_w, G, M, N, K, gw, gw_group_stride, ld_gw, stream);
+}
+
+extern "C" int bl_gemm_wgrad_routed(const bl_rows_t* a, const float* g_node, int32_t ld_g, const int32_t* g_idx,
+                                    const int32_t* winner, int32_t ld_winner, const int32_t* group_ptr,
+                                    const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
+                                    int64_t gw_group_stride, int32_t ld_gw, void* stream) {
+  BL_CHECK_ARG(g_idx != nullptr && winner != nullptr && ld_winner % 4 == 0, "bl_gemm_wgrad_routed: needs g_idx and a winner table");
+  return gemm_wgrad_impl(a, g_node, ld_g, g_idx, winner, ld_winner, group_ptr, group_w, G, M, N, K, gw, gw_group_stride, ld_gw,
+                         stream);
 }

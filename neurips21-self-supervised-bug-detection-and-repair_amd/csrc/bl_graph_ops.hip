@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
                                                           float* __restrict__ out, int* __restrict__ arg,
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           float eps, float* __restrict__ ln_out,
-                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          float* __restrict__ dact) {
   const int lane = threadIdx.x & 63;
   const int seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (seg >= nseg) return;
@@ -81,17 +82,40 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
   for (int base = beg; base < end; base += 64) {
     const int cnt = min(64, end - base);
     const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
-#pragma unroll 4
-    for (int i = 0; i < cnt; ++i) {
+    int i = 0;
+    // four rows in flight per step (independent loads), compared in item order (ties -> first item)
+    for (; i + 4 <= cnt; i += 4) {
+      int e[4];
+      float v[4][NV];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        e[u] = __shfl(mine, i + u, 64);
+        const float* __restrict__ row = x + (size_t)e[u] * ldx;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int d = lane + 64 * j;
+          v[u][j] = d < D ? row[d] : NEG_INF;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          float t = v[u][j];
+          if (act == BL_ACT_GELU) t = bl_gelu(t);
+          if (t > best[j]) { best[j] = t; barg[j] = e[u]; }
+        }
+    }
+    for (; i < cnt; ++i) {
       const int e = __shfl(mine, i, 64);
       const float* __restrict__ row = x + (size_t)e * ldx;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int d = lane + 64 * j;
         if (d < D) {
-          float v = row[d];
-          if (act == BL_ACT_GELU) v = bl_gelu(v);
-          if (v > best[j]) { best[j] = v; barg[j] = e; }
+          float t = row[d];
+          if (act == BL_ACT_GELU) t = bl_gelu(t);
+          if (t > best[j]) { best[j] = t; barg[j] = e; }
         }
       }
     }
@@ -105,6 +129,11 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
       out[(size_t)seg * D + d] = best[j];
       arg[(size_t)seg * D + d] = barg[j];
       s += best[j];
+      if (dact) {  // d act / d pre at the winner, so that backward never needs the [E, D] messages again
+        float dv = 1.f;
+        if (act == BL_ACT_GELU) dv = barg[j] >= 0 ? bl_gelu_grad(x[(size_t)barg[j] * ldx + d]) : 0.f;
+        dact[(size_t)seg * D + d] = dv;
+      }
     }
   }
   if (HAS_LN) {
@@ -160,7 +189,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int nrows, int D,
                                                             float* __restrict__ g_x, float* __restrict__ g_gamma,
-                                                            float* __restrict__ g_beta) {
+                                                            float* __restrict__ g_beta,
+                                                            const float* __restrict__ post_scale) {
   __shared__ float red[2][4][64 * NV];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nw = gridDim.x * 4;
@@ -192,7 +222,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int d = lane + 64 * j;
-      if (d < D) g_x[(size_t)r * D + d] = rs * (gy[j] * gam[j] - a - xh[j] * b);
+      if (d < D) {
+        float gx = rs * (gy[j] * gam[j] - a - xh[j] * b);
+        if (post_scale) gx *= post_scale[(size_t)r * D + d];
+        g_x[(size_t)r * D + d] = gx;
+      }
     }
   }
 #pragma unroll
@@ -283,8 +317,25 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
     for (int base = beg; base < end; base += 64) {
       const int cnt = min(64, end - base);
       const int mine = lane < cnt ? items[base + lane] : 0;
-#pragma unroll 4
-      for (int i = 0; i < cnt; ++i) {
+      int i = 0;
+      for (; i + 4 <= cnt; i += 4) {  // four independent row loads in flight, summed in item order
+        float v[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = __shfl(mine, i + u, 64);
+          const float* __restrict__ row = g_a + (size_t)e * ld_ga + coff;
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            const int d = lane + 64 * j;
+            v[u][j] = d < Din ? row[d] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < NV; ++j) acc[j] += v[u][j];
+      }
+      for (; i < cnt; ++i) {
         const int e = __shfl(mine, i, 64);
         const float* __restrict__ row = g_a + (size_t)e * ld_ga + coff;
 #pragma unroll
@@ -338,7 +389,8 @@ extern "C" int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const
 
 extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items,
                                   int32_t nseg, int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g,
-                                  const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, void* stream) {
+                                  const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, float* dact,
+                                  void* stream) {
   if (nseg == 0) return BL_OK;
   BL_CHECK_ARG(seg_ptr && out && arg, "bl_segment_max_fwd: null pointer");
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
@@ -349,10 +401,10 @@ extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* se
   hipStream_t st = (hipStream_t)stream;
   if (has_ln) {
     DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, true>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
-                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd))
+                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact))
   } else {
     DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, false>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
-                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd))
+                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact))
   }
   BL_LAUNCH_CHECK("bl_segment_max_fwd");
   return BL_OK;
@@ -374,14 +426,14 @@ extern "C" int bl_segment_max_bwd(const float* g_out, const int32_t* arg, const 
 
 extern "C" int bl_layernorm_bwd(const float* g_y, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta,
-                                void* stream) {
+                                const float* post_scale, void* stream) {
   if (nrows == 0) return BL_OK;
   BL_CHECK_ARG(g_y && x && mean && rstd && gamma && g_x && g_gamma && g_beta, "bl_layernorm_bwd: null pointer");
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_layernorm_bwd: D must be in 1..512");
   const int blocks = min((nrows + 3) / 4, 1024);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd,
-                                     gamma, nrows, D, g_x, g_gamma, g_beta))
+                                     gamma, nrows, D, g_x, g_gamma, g_beta, post_scale))
   BL_LAUNCH_CHECK("bl_layernorm_bwd");
   return BL_OK;
 }

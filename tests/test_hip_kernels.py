@@ -117,7 +117,7 @@ def test_segment_max_layernorm_fwd_bwd(ops, D, act):
     xa = O._gelu(x.double()) if act == "gelu" else x.double()
     ref, arg = O.scatter_max_with_arg(xa, torch.from_numpy(seg), nseg)
     ref_ln = torch.nn.functional.layer_norm(ref, (D,), g.double(), b.double(), eps=1e-5)
-    out, a, ln_out, mean, rstd = ops.segment_max(_dev(x), _dev(ptr), _dev(order), nseg, act=ops._ACTS[act], ln=(_dev(g), _dev(b)))
+    out, a, ln_out, mean, rstd, dact = ops.segment_max(_dev(x), _dev(ptr), _dev(order), nseg, act=ops._ACTS[act], ln=(_dev(g), _dev(b)), want_dact=True)
     assert (out.cpu().double() - ref).abs().max() < 1e-6
     a_ref = torch.where(arg == E, torch.full_like(arg, -1), arg)
     assert (a.cpu().long() == a_ref).all()
@@ -130,6 +130,25 @@ def test_segment_max_layernorm_fwd_bwd(ops, D, act):
         O.scatter_max_with_arg(xa, torch.from_numpy(seg), nseg)[0].backward(go.double())
         gx = ops.segment_max_bwd(_dev(go), a, _dev(x), _dev(seg.astype(np.int32)), act=ops._ACTS[act])
         assert (gx.cpu().double() - xr.grad).abs().max() < 1e-5
+        # routed GEMMs: the same gradient, never materialised: G[i,:] = (go * dact)[seg[i]] masked to i's wins
+        gq = (_dev(go) * dact).contiguous()
+        W = torch.randn(3, 40, D) / math.sqrt(D)          # [groups, N_out, K=D] used transposed
+        gptr = np.array([0, 300, 300, E], dtype=np.int32)
+        dA = ops.gemm_rows_routed(gq, _dev(seg.astype(np.int32)), a, _dev(W), E, 40, b_group_stride=40 * D, ldb=D, group_ptr=_dev(gptr), G=3)
+        ref_dA = torch.zeros(E, 40, dtype=torch.float64)
+        for t in range(3):
+            lo, hi = gptr[t], gptr[t + 1]
+            ref_dA[lo:hi] = xr.grad[lo:hi] @ W[t].double().T
+        assert (dA.cpu().double() - ref_dA).abs().max() < 3e-5 * max(1.0, float(ref_dA.abs().max()))
+        hfeat = torch.randn(77, 24)
+        hidx = np.random.default_rng(9).integers(0, 77, E).astype(np.int32)
+        gw = torch.zeros(3, 24, D, device="cuda")
+        ops.gemm_wgrad_routed([(_dev(hfeat), _dev(hidx))], gq, _dev(seg.astype(np.int32)), a, E, D, gw, gw_group_stride=24 * D, group_ptr=_dev(gptr), G=3)
+        ref_gw = torch.zeros(3, 24, D, dtype=torch.float64)
+        for t in range(3):
+            lo, hi = gptr[t], gptr[t + 1]
+            ref_gw[t] = hfeat[hidx[lo:hi]].double().T @ xr.grad[lo:hi]
+        assert (gw.cpu().double() - ref_gw).abs().max() < 3e-5 * max(1.0, float(ref_gw.abs().max()))
         # LayerNorm backward
         gy = torch.randn(nseg, D)
         rr = ref.clone().float().requires_grad_(True)
