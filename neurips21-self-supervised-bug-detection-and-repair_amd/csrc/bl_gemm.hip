@@ -545,8 +545,36 @@ static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, c
   BL_CHECK_ARG(g_c && gw && bl_aligned16(g_c), "bl_gemm_wgrad: g_c/gw null or misaligned");
   // chunk of rows reduced by one workgroup: large enough to amortise the 128x128 atomic epilogue,
   // small enough that >= ~1000 workgroups exist at minibatch sizes
-  int kchunk = 2048;
-  while (kchunk > 256 && (M / kchunk) * ((K + BM - 1) / BM) * ((N + BN - 1) / BN) < 1024) kchunk >>= 1;
+  // Rows reduced by one workgroup.  The workgroup count should fill an INTEGER number of rounds of
+  // resident workgroups (1.24 rounds at the old fixed chunk cost 38 % of this kernel in tail), while
+  // staying >= 256 rows so that the 128x128 atomic flush is amortised.
+  static int resident_plain = 0, resident_masked = 0;
+  int& resident = g_mask ? resident_masked : resident_plain;
+  if (resident == 0) {
+    int per_cu = 0;
+    hipError_t oe = g_mask ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_kernel<32, 1, 2, true>, 256, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_kernel<32, 1, 2, false>, 256, 0);
+    if (oe != hipSuccess || per_cu <= 0) per_cu = 3;
+    int dev = 0, ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+    resident = per_cu * ncu;
+    if (getenv("BL_DEBUG")) fprintf(stderr, "[buglab_hip] wgrad(masked=%d): %d workgroups/CU x %d CUs\n", g_mask ? 1 : 0, per_cu, ncu);
+  }
+  const int ntiles_all = ((K + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int extra = (group_ptr ? G : 0) * ntiles_all;  // partial last pieces of the groups
+  int kchunk = 256;
+  for (int rounds = 1; rounds <= 64; ++rounds) {
+    const long long slots = (long long)resident * rounds - extra;
+    if (slots <= 0) continue;
+    const long long kc = ((long long)M * ntiles_all + slots - 1) / slots;
+    if (kc <= 1024 || rounds == 64) {
+      kchunk = (int)((kc + 31) / 32 * 32);
+      break;
+    }
+  }
+  if (kchunk < 256) kchunk = 256;
   const int ntiles_n = (N + BN - 1) / BN;
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ((K + BM - 1) / BM) * ntiles_n);
 #define WGRAD_GO(...)                                                                                                      \
