@@ -164,19 +164,25 @@ class KernelTimer:
         KernelTimer.active = None
 
     def summary(self):
+        """{kind: {launches, ms, flop, overlapped}}.  `overlapped` kinds were launched while a kernel
+        of the same layer ran on the side stream: their event spans share the GPU and must not be
+        read as exclusive kernel time (the enclosing "*_pair" span is the exclusive one)."""
         out = {}
-        for kind, flop, e0, e1 in self.records:
-            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flop": 0.0})
+        for kind, flop, e0, e1, overlapped in self.records:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flop": 0.0, "overlapped": overlapped})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flop"] += flop
         return out
 
 
+_overlap_depth = 0
+
+
 class _timed:
-    def __init__(self, kind, flop):
+    def __init__(self, kind, flop, span=False):
         self.t = KernelTimer.active
-        self.kind, self.flop = kind, flop
+        self.kind, self.flop, self.span = kind, flop, span
 
     def __enter__(self):
         if self.t is not None:
@@ -187,7 +193,7 @@ class _timed:
         if self.t is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.t.records.append((self.kind, self.flop, self.e0, e1))
+            self.t.records.append((self.kind, self.flop, self.e0, e1, (not self.span) and _overlap_depth > 0))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -319,6 +325,44 @@ def scatter_add_rows(src, col_off, width, idx, out):
 
 
 # ------------------------------------------------------------------------------------------------
+# side stream: weight-gradient GEMMs run next to the input-gradient chain of the same layer (both
+# only read the node gradient), so one kernel's prologue / epilogue / last-round tail is filled by
+# the other kernel's workgroups.  BL_SIDE_STREAM=0 disables.
+_side_streams = {}
+USE_SIDE_STREAM = os.environ.get("BL_SIDE_STREAM", "1") != "0"
+
+
+class _on_side_stream:
+    def __init__(self, device):
+        self.enabled = USE_SIDE_STREAM
+        if self.enabled:
+            key = torch.cuda.current_device()
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream()
+            self.side = _side_streams[key]
+            self.main = torch.cuda.current_stream()
+
+    def __enter__(self):
+        global _overlap_depth
+        if self.enabled:
+            _overlap_depth += 1
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+
+    def join(self):
+        global _overlap_depth
+        if self.enabled:
+            self.main.wait_stream(self.side)
+            _overlap_depth -= 1
+
+
+# ------------------------------------------------------------------------------------------------
 # autograd wrappers
 class GraphIndex(NamedTuple):
     """Device-side index arrays of one minibatch (buglab.data.collate.to_device)."""
@@ -409,7 +453,10 @@ class _MpLayer(torch.autograd.Function):
         g_bd = torch.zeros((Dout,), dtype=torch.float32, device=dev)
         g_z = act_bwd(g_out, out, ACT_TANH, drop, g_bd)
         g_Wd = torch.zeros_like(Wd)
-        gemm_wgrad([(ln_out, None)], g_z, N, Dout, g_Wd)
+        g_W = torch.zeros_like(W)
+        side1 = _on_side_stream(dev)
+        with side1:
+            gemm_wgrad([(ln_out, None)], g_z, N, Dout, g_Wd)
         g_ln = gemm_rows([(g_z, None)], Wd, N, Dm, b_is_nk=True, ldb=Dout)
         # LayerNorm
         g_lng = torch.zeros((Dm,), dtype=torch.float32, device=dev)
@@ -417,9 +464,12 @@ class _MpLayer(torch.autograd.Function):
         # LayerNorm (+ the message activation's derivative at each winner): d loss / d (winning pre-activation) per node
         gq = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact)
         # per-edge-type weights; message m's gradient row = gq[tgt(m)] masked to the channels m won
-        g_W = torch.zeros_like(W)
-        gemm_wgrad_routed([(h, g.msg_src), (h, g.msg_tgt)], gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K2 * Dm,
-                          group_ptr=g.type_ptr, G=T)
+        pair = _timed("mp_bwd_gemm_pair(wgrad||dgrad+node-sums)", 2.0 * (2.0 * E * K2 * Dm), span=True)
+        pair.__enter__()
+        side2 = _on_side_stream(dev)
+        with side2:
+            gemm_wgrad_routed([(h, g.msg_src), (h, g.msg_tgt)], gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K2 * Dm,
+                              group_ptr=g.type_ptr, G=T)
         # node states: per-message input gradients, then segmented sums over the src / tgt CSRs
         g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K2, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
         g_h = torch.empty((N, Din), dtype=torch.float32, device=dev)
@@ -428,6 +478,9 @@ class _MpLayer(torch.autograd.Function):
                                               g.tgt_ptr.data_ptr(), g.tgt_msgs.data_ptr(), N, Din, 0, g_h.data_ptr(),
                                               g_h.stride(0), _stream()),
             "bl_mp_scatter_grad")
+        side2.join()
+        side1.join()
+        pair.__exit__(None, None, None)
         return g_h, g_W, g_lng, g_lnb, g_Wd, g_bd, None, None, None
 
 
