@@ -574,7 +574,8 @@ static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, c
       break;
     }
   }
-  if (kchunk < 256) kchunk = 256;
+  static const int min_chunk = getenv("BL_WGRAD_MIN_CHUNK") ? atoi(getenv("BL_WGRAD_MIN_CHUNK")) : 256;
+  if (kchunk < min_chunk) kchunk = min_chunk;
   const int ntiles_n = (N + BN - 1) / BN;
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ((K + BM - 1) / BM) * ntiles_n);
 #define WGRAD_GO(...)                                                                                                      \
