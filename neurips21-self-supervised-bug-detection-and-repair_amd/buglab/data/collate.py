@@ -242,6 +242,13 @@ def collate_samples(samples: Sequence[BaseTensorizedBugLabGnn], num_edge_types: 
         lp = [np.asarray(s.rewrite_logprobs[:-1], dtype=np.float32) for s in samples if s.rewrite_logprobs is not None]
         nb = [np.float32(s.rewrite_logprobs[-1]) for s in samples if s.rewrite_logprobs is not None]
         mb["rewrite_logprobs"] = np.concatenate(lp + [np.asarray(nb, dtype=np.float32)])
+        # selector loss (reference utils.py:136-137): CSR, by graph, over the OBSERVED entries (finite
+        # detection log-probabilities) of [all rewrites..., one NO_BUG slot per graph]
+        index = np.concatenate([mb["rewrite_to_graph_id"].astype(np.int64), np.arange(B, dtype=np.int64)])
+        observed = np.flatnonzero(~np.isinf(mb["rewrite_logprobs"]))
+        ng = int(index[observed].max()) + 1 if observed.size else 0
+        ptr, order = _csr(index[observed], ng)
+        mb["gen_group_ptr"], mb["gen_group_items"], mb["gen_num_groups"] = ptr, observed[order].astype(I32), ng
     return mb
 
 
@@ -279,7 +286,7 @@ def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
         arrays.append(("ref", k, np.ascontiguousarray(v, dtype=I32)))
     for k, v in gd["reference_node_graph_idx"].items():
         arrays.append(("refg", k, np.ascontiguousarray(v, dtype=I32)))
-    for k in _INT_KEYS_MB:
+    for k in _INT_KEYS_MB + (("gen_group_ptr", "gen_group_items") if "gen_group_ptr" in mb else ()):
         arrays.append(("mb", k, np.ascontiguousarray(mb[k], dtype=I32)))
     arrays.append(("mb", "has_bug", np.ascontiguousarray(mb["has_bug"], dtype=I32)))
     # 16-byte align every array inside the blob
@@ -319,4 +326,5 @@ def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
         out[k] = mb[k]
     if "rewrite_logprobs" in mb:
         out["rewrite_logprobs"] = torch.from_numpy(np.asarray(mb["rewrite_logprobs"], dtype=np.float32)).to(dev)
+        out["gen_num_groups"] = int(mb["gen_num_groups"])
     return out

@@ -156,7 +156,8 @@ class GnnBugLabModule(ModuleWithMetrics):
                 candidate_symbol_to_location_group, correct_candidate_symbols, candidate_rewrite_idxs,
                 swapped_pair_to_call_location_group, correct_swapped_pair, pair_rewrite_idxs, rewrite_to_graph_id,
                 rewrite_logprobs: Optional[torch.Tensor] = None, repair_group_ptr=None, repair_group_items=None,
-                num_repair_groups=None, dropout_seed: Optional[int] = None, **kwargs):
+                num_repair_groups=None, gen_group_ptr=None, gen_group_items=None, gen_num_groups=None,
+                dropout_seed: Optional[int] = None, **kwargs):
         """reference :144-251 (keyword-only arguments, visualisation extras ignored)."""
         if dropout_seed is None:
             dropout_seed = self._next_dropout_seed()
@@ -164,9 +165,22 @@ class GnnBugLabModule(ModuleWithMetrics):
         swap_lp, text_lp, var_lp, (swap_sel, text_sel, var_sel) = self._compute_repair_logprobs(
             gnn_output, target_rewrites, rewrite_to_location_group, candidate_symbol_to_location_group,
             swapped_pair_to_call_location_group, repair_group_ptr, repair_group_items, num_repair_groups)
-        if rewrite_logprobs is not None:
-            raise NotImplementedError("selector (generator) loss -- reference gnn.py:189-219, utils.py:101-179 -- is a "
-                                      "SURVEY section 8f 'next' row")
+        if rewrite_logprobs is not None:  # selector / generator branch, reference :189-219
+            from buglab.models.utils import compute_generator_loss
+
+            _, loc_lp, arange = self._localization_module.compute_localization_logprobs(
+                gnn_output.output_node_representations, gnn_output.node_idx_references["candidate_nodes"],
+                gnn_output.node_graph_idx_reference["candidate_nodes"], has_bug.shape[0],
+                graph_data["candidate_ptr"], graph_data["loc_group_ptr"], graph_data["loc_group_items"])
+            loss = compute_generator_loss(
+                swap_lp, arange, candidate_rewrite_idxs, candidate_symbol_to_location_group, loc_lp, self._generator_loss_type,
+                pair_rewrite_idxs, rewrite_logprobs, rewrite_to_graph_id, rewrite_to_location_group,
+                swapped_pair_to_call_location_group, text_lp, text_rewrite_idxs, var_lp, gen_group_ptr, gen_group_items, gen_num_groups)
+            with torch.no_grad():  # :214-217
+                acc = torch.stack([loss.detach(), torch.zeros((), device=loss.device), torch.zeros((), device=loss.device),
+                                   torch.ones((), device=loss.device)])
+                self._acc = acc if self._acc is None else self._acc + acc
+            return loss
         loc_loss = self._localization_module(
             gnn_output.output_node_representations,
             gnn_output.node_idx_references["candidate_nodes"],

@@ -420,6 +420,68 @@ def forward_loss(params, mb, cfg: OracleConfig, seed=None, trace=None):
     }
 
 
+# ----------------------------------------------------------------------------
+# Selector ("generator") loss: reference buglab/models/utils.py:101-179, called from
+# GnnBugLabModule.forward when `rewrite_logprobs` is given (gnn.py:189-219).  PINNED by
+# tests/golden/heads_generator_*.npz (the reference function run on seeded inputs).
+# ----------------------------------------------------------------------------
+def scatter_sum(src, index, dim_size):
+    return torch.zeros(dim_size, dtype=src.dtype).index_add(0, index, src)
+
+
+def compute_generator_loss(arg_swap_logprobs, arrange, candidate_rewrite_idxs, candidate_symbol_to_location_group,
+                           localization_logprobs, loss_type, pair_rewrite_idxs, rewrite_logprobs, rewrite_to_graph_id,
+                           rewrite_to_location_group, swapped_pair_to_call_location_group, text_repair_logprobs,
+                           text_rewrite_idxs, varmisuse_logprobs):
+    L = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
+    rewrite_logprobs = torch.as_tensor(rewrite_logprobs)
+    generation_logprobs = torch.zeros_like(rewrite_logprobs)  # :117
+    num_graphs = arrange.shape[0]
+    generation_logprobs = torch.cat([generation_logprobs[:-num_graphs], localization_logprobs[-num_graphs:]])  # :119-121
+    add = lambda v, idx, x: v.index_add(0, L(idx), x)
+    generation_logprobs = add(generation_logprobs, text_rewrite_idxs, localization_logprobs[L(rewrite_to_location_group)] + text_repair_logprobs)  # :123-125
+    generation_logprobs = add(generation_logprobs, candidate_rewrite_idxs, localization_logprobs[L(candidate_symbol_to_location_group)] + varmisuse_logprobs)  # :127-129
+    generation_logprobs = add(generation_logprobs, pair_rewrite_idxs, localization_logprobs[L(swapped_pair_to_call_location_group)] + arg_swap_logprobs)  # :131-133
+    observed = torch.isinf(rewrite_logprobs).logical_not()  # :136
+    index = torch.cat((L(rewrite_to_graph_id), L(arrange)))[observed]  # :137
+    det = rewrite_logprobs[observed]
+    gen = generation_logprobs[observed]
+    ng = int(index.max()) + 1
+    if loss_type in ("norm-kl", "norm-rmse", "classify-max-loss"):
+        gen = scatter_log_softmax(gen, index)  # :143-146
+        if loss_type == "norm-rmse":
+            renorm = scatter_log_softmax(det, index)
+            return (torch.logaddexp(renorm, gen) ** 2).mean()  # :148-152
+        if loss_type == "norm-kl":
+            failed = torch.log(torch.max(1.0 - det.exp(), torch.full_like(det, 1e-30)))  # :154-159
+            renorm_failed = scatter_log_softmax(failed, index)
+            kl = failed.exp() * (renorm_failed - gen)  # :163-165
+            return scatter_sum(kl, index, ng).mean()
+        # classify-max-loss :167-169 (scatter_min arg = first minimum)
+        neg_max, arg = scatter_max_with_arg(-det, index, ng)
+        return -gen[arg].mean()
+    if loss_type == "expectation":
+        return scatter_sum(gen.exp() * det, index, ng).mean()  # :172-176
+    raise ValueError(f"Unknown loss type `{loss_type}`")
+
+
+def generator_forward_loss(params, mb, cfg: OracleConfig, loss_type: str, node_reprs=None):
+    """GnnBugLabModule.forward, generator branch (gnn.py:168-219).  `node_reprs` overrides the GNN
+    (golden tests inject node states)."""
+    gd = mb["graph_data"]
+    L = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
+    h = node_reprs if node_reprs is not None else gnn_forward(params, gd, cfg)
+    refs = gd["reference_node_ids"]
+    swap_lp, text_lp, var_lp, _, _ = repair_logprobs(params, h, refs, mb["target_rewrites"], mb["rewrite_to_location_group"],
+                                                     mb["candidate_symbol_to_location_group"], mb["swapped_pair_to_call_location_group"])
+    B = len(mb["has_bug"])
+    _, loc_lp, arange = localization_logprobs(params, h[L(refs["candidate_nodes"])], gd["reference_node_graph_idx"]["candidate_nodes"], B)
+    return compute_generator_loss(swap_lp, arange, mb["candidate_rewrite_idxs"], mb["candidate_symbol_to_location_group"], loc_lp,
+                                  loss_type, mb["pair_rewrite_idxs"], mb["rewrite_logprobs"], mb["rewrite_to_graph_id"],
+                                  mb["rewrite_to_location_group"], mb["swapped_pair_to_call_location_group"], text_lp,
+                                  mb["text_rewrite_idxs"], var_lp)
+
+
 def forward_backward(params, mb, cfg: OracleConfig, seed=None):
     """loss + grads for every parameter (dict, same names)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}

@@ -254,5 +254,81 @@ def main():
         print(case, float(loss), sorted(k for k in save if k.startswith("w_")))
 
 
+def generator_cases():
+    """Selector (generator) branch of the reference's GnnBugLabModule.forward (gnn.py:189-219 ->
+    utils.py:101-179) for all four loss types: rewrites at SEVERAL locations per graph, some detection
+    log-probabilities unobserved (-inf)."""
+    from buglab.models.gnn import GnnBugLabModule  # noqa: reference code
+
+    H, B, n, C, seed = 16, 4, 24, 5, 21
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    node_states = torch.randn(B * n, H, generator=g)
+    cand, cand_g = [], []
+    tr_nodes, tr_ids, tr_grp, tr_orig = [], [], [], []
+    vm_nodes, vm_cands, vm_grp, vm_orig = [], [], [], []
+    cn_nodes, sw_pairs, sw_grp, sw_orig = [], [], [], []
+    rw_graph, det_lp = [], []
+    grp_off = rw_off = 0
+    for b in range(B):
+        c = np.sort(rng.choice(n, size=C, replace=False)) + b * n
+        cand += c.tolist()
+        cand_g += [b] * C
+        k = 0
+        for loc in rng.choice(C, size=3, replace=False):  # three locations with rewrites
+            node = int(c[loc])
+            kind = int(rng.integers(0, 3))
+            m = int(rng.integers(2, 5))
+            for _ in range(m):
+                if kind == 0:
+                    tr_nodes.append(node); tr_ids.append(int(rng.integers(0, 48))); tr_grp.append(grp_off + int(loc)); tr_orig.append(rw_off + k)
+                elif kind == 1:
+                    vm_nodes.append(node); vm_cands.append(int(rng.integers(0, n)) + b * n); vm_grp.append(grp_off + int(loc)); vm_orig.append(rw_off + k)
+                else:
+                    cn_nodes.append(node); sw_pairs.append((rng.integers(0, n, size=2) + b * n).tolist()); sw_grp.append(grp_off + int(loc)); sw_orig.append(rw_off + k)
+                k += 1
+        lp = np.log(rng.uniform(0.02, 0.9, size=k))
+        lp[rng.uniform(size=k) < 0.25] = -np.inf  # unobserved
+        det_lp += lp.tolist()
+        rw_graph += [b] * k
+        grp_off += C
+        rw_off += k
+    no_bug_lp = np.log(rng.uniform(0.05, 0.9, size=B)).tolist()
+    L = lambda a: torch.tensor(a, dtype=torch.int64)
+    refs = {"candidate_nodes": L(cand), "target_rewrite_nodes": L(tr_nodes), "varmisused_node_ids": L(vm_nodes),
+            "candidate_symbol_node_ids": L(vm_cands), "call_node_ids": L(cn_nodes), "candidate_swapped_node_ids": L(sw_pairs).view(-1, 2)}
+    ref_graph = {"candidate_nodes": L(cand_g)}
+    rewrite_logprobs = torch.tensor(det_lp + no_bug_lp, dtype=torch.float32)
+    mb = dict(graph_data={}, correct_candidate_node_idxs=L([0] * B), has_bug=torch.tensor([False] * B), target_rewrites=L(tr_ids),
+              rewrite_to_location_group=L(tr_grp), correct_rewrite_idxs=L([]), text_rewrite_idxs=L(tr_orig),
+              candidate_symbol_to_location_group=L(vm_grp), correct_candidate_symbols=L([]), candidate_rewrite_idxs=L(vm_orig),
+              swapped_pair_to_call_location_group=L(sw_grp), correct_swapped_pair=L([]), pair_rewrite_idxs=L(sw_orig),
+              rewrite_to_graph_id=L(rw_graph), rewrite_logprobs=rewrite_logprobs)
+    save = {"H": H, "B": B, "node_states": node_states.numpy(), "refg_candidate_nodes": ref_graph["candidate_nodes"].numpy()}
+    for k_, v in refs.items():
+        save["ref_" + k_] = v.numpy()
+    for k_, v in mb.items():
+        if isinstance(v, torch.Tensor):
+            save["mb_" + k_] = v.numpy()
+    for loss_type in ("norm-kl", "norm-rmse", "classify-max-loss", "expectation"):
+        torch.manual_seed(seed)
+        module = GnnBugLabModule(TableGnn(node_states, refs, ref_graph, B), rewrite_vocabulary_size=48, generator_loss_type=loss_type)
+        module._argswap_module._input_dim = H
+        for m in module.modules():
+            if hasattr(m, "_reset_module_metrics"):
+                m._reset_module_metrics()
+        loss = module(**mb)
+        loss.backward()
+        save["loss_" + loss_type] = loss.detach().numpy()
+        save["grad_node_states_" + loss_type] = module._gnn.table.grad.numpy().copy()
+        if loss_type == "norm-kl":
+            for k_, v in module.state_dict().items():
+                if not k_.startswith("_gnn."):
+                    save["w_" + k_] = v.numpy()
+        print("generator", loss_type, float(loss))
+    np.savez(os.path.join(OUT, "heads_generator.npz"), **save)
+
+
 if __name__ == "__main__":
     main()
+    generator_cases()

@@ -206,3 +206,81 @@ def test_full_size_properties_c2():
         mb2 = to_device(collate_samples(samples, 16), "cuda")
         loss2 = module(**mb2)
         assert abs(float(loss2) - float(loss)) < 1e-5
+
+
+@pytest.mark.parametrize("loss_type", ["norm-kl", "norm-rmse", "classify-max-loss", "expectation"])
+def test_generator_loss_matches_reference_golden(golden_dir, loss_type):
+    """Selector branch of forward (reference gnn.py:189-219, utils.py:101-179) through the HIP heads,
+    against the loss and node-state gradient the reference's own code produced."""
+    from buglab.data.collate import segments_from_index
+    from buglab.models.gnn import GnnBugLabModule
+    from buglab.models.layers.messagepassing import GnnOutput
+
+    z = np.load(os.path.join(golden_dir, "heads_generator.npz"))
+    H, B = int(z["H"]), int(z["B"])
+    mbn = golden_minibatch(z)
+    refs = mbn["graph_data"]["reference_node_ids"]
+    cand_g = mbn["graph_data"]["reference_node_graph_idx"]["candidate_nodes"]
+    I = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32).cuda()
+
+    class TableGnn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.from_numpy(z["node_states"]).cuda())
+            self.input_node_state_dim = self.output_node_state_dim = H
+            self.message_passing_layers = []
+
+        def forward(self, return_all_states=False, dropout_seed=None, **gd):
+            r = {k: I(v) for k, v in refs.items()}
+            pairs = np.asarray(refs["candidate_swapped_node_ids"]).reshape(-1, 2)
+            r["candidate_swapped_a"], r["candidate_swapped_b"] = I(pairs[:, 0]), I(pairs[:, 1])
+            return GnnOutput(self.table, self.table, None, r, {"candidate_nodes": I(cand_g)}, B)
+
+    module = GnnBugLabModule(TableGnn(), 48, generator_loss_type=loss_type).cuda()
+    sd = module.state_dict()
+    prefix = {"loc.": "_localization_module.", "text.": "_text_repair_module.", "var.": "_varmisuse_module.", "swap.": "_argswap_module."}
+    for k, v in head_params_from_golden(z).items():
+        for a, b in prefix.items():
+            if k.startswith(a):
+                sd[b + k[len(a):]].copy_(v.cuda())
+    cand_ptr = np.zeros(B + 1, dtype=np.int32)
+    cand_ptr[1:] = np.cumsum(np.bincount(cand_g, minlength=B))
+    loc_ptr, loc_items = segments_from_index(np.concatenate([cand_g, np.arange(B)]), B)
+    gd = {"candidate_ptr": I(cand_ptr), "loc_group_ptr": I(loc_ptr), "loc_group_items": I(loc_items)}
+    kw = {k: I(mbn[k]) for k in ("correct_candidate_node_idxs", "target_rewrites", "rewrite_to_location_group", "correct_rewrite_idxs",
+                                 "text_rewrite_idxs", "candidate_symbol_to_location_group", "correct_candidate_symbols",
+                                 "candidate_rewrite_idxs", "swapped_pair_to_call_location_group", "correct_swapped_pair",
+                                 "pair_rewrite_idxs", "rewrite_to_graph_id")}
+    module.train()
+    module.reset_metrics()
+    loss = module(graph_data=gd, has_bug=torch.from_numpy(mbn["has_bug"]).cuda(),
+                  rewrite_logprobs=torch.from_numpy(mbn["rewrite_logprobs"]).cuda(), **kw)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(z["loss_" + loss_type])) < TOL
+    ref_g = z["grad_node_states_" + loss_type]
+    assert Hh.maxdiff(module._gnn.table.grad, ref_g) < 1e-4 * float(np.abs(ref_g).max()) + 1e-6
+
+
+def test_generator_loss_through_collator_matches_oracle():
+    """Same branch end to end (GNN included), with the observed-entry CSR built by the collator."""
+    from buglab.data.collate import collate_samples, to_device
+    from buglab.data.synthetic import make_samples
+
+    cfg = O.OracleConfig(hidden=32, num_layers=4, num_edge_types=4, vocab_size=100)
+    rng = np.random.default_rng(3)
+    samples = []
+    for s in make_samples(4, seed=8, num_nodes=50, num_messages=200, num_edge_types=4, vocab_size=100, num_candidates=6, buggy=True):
+        k = len(s.target_rewrites) + len(s.candidate_symbol_to_varmisused_node) + len(s.swapped_pair_to_call)
+        lp = np.log(rng.uniform(0.05, 0.9, size=k + 1))
+        lp[rng.uniform(size=k + 1) < 0.3] = -np.inf
+        lp[-1] = np.log(0.4)
+        samples.append(s._replace(rewrite_logprobs=lp.tolist()))
+    mb_np = collate_samples(samples, 4)
+    params = O.init_params(cfg, seed=0)
+    for loss_type in ("norm-kl", "classify-max-loss"):
+        ref = O.generator_forward_loss(params, mb_np, cfg, loss_type)
+        module = Hh.build_module_like(cfg, params)
+        module._generator_loss_type = loss_type
+        module.eval()
+        loss = module(**to_device(mb_np, "cuda"))
+        assert abs(float(loss.detach()) - float(ref)) < TOL, loss_type

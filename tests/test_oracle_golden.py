@@ -58,3 +58,17 @@ def test_logprobs_normalise():
     idx = np.concatenate([mb["graph_data"]["reference_node_graph_idx"]["candidate_nodes"], np.arange(3)])
     for b in range(3):
         assert abs(float(torch.logsumexp(out["loc_logprobs"][torch.from_numpy(idx == b)], 0))) < 1e-5
+
+
+@pytest.mark.parametrize("loss_type", ["norm-kl", "norm-rmse", "classify-max-loss", "expectation"])
+def test_generator_loss_matches_reference(golden_dir, loss_type):
+    """Selector branch (reference gnn.py:189-219 + utils.py:101-179) -- SURVEY section 8f rank 2."""
+    z = np.load(os.path.join(golden_dir, "heads_generator.npz"))
+    params = head_params_from_golden(z)
+    h = torch.from_numpy(z["node_states"]).requires_grad_(True)
+    mb = golden_minibatch(z)
+    cfg = O.OracleConfig(hidden=int(z["H"]))
+    loss = O.generator_forward_loss(params, mb, cfg, loss_type, node_reprs=h)
+    assert abs(float(loss.detach()) - float(z["loss_" + loss_type])) < 2e-6
+    loss.backward()
+    np.testing.assert_allclose(h.grad.numpy(), z["grad_node_states_" + loss_type], atol=2e-6, rtol=1e-4)
