@@ -134,10 +134,21 @@ int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32_t N, int32
 
 /* M1 backward, last step: gradient w.r.t. node states from the per-message input gradients
  *   g_h[n, 0:Din] (+)= sum_{e in src CSR of n} g_a[e, 0:Din] + sum_{e in tgt CSR of n} g_a[e, Din:2Din]
- * (deterministic segmented sums; replaces autograd's index_add of the two h[...] gathers). */
+ * (deterministic segmented sums; replaces autograd's index_add of the two h[...] gathers).
+ * tgt_ptr == tgt_msgs == NULL: source half only (messages built from h[src] alone, `ggnn`). */
 int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
                        const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din, int32_t accumulate,
                        float* g_h, int32_t ld_gh, void* stream);
+
+/* GRU cell of the gated (`ggnn`) node update -- the elementwise part of torch.nn.GRUCell (gate order
+ * r | z | n) after gi = x W_i + b_i and gh = h W_h + b_h [N, 3D] were produced by bl_gemm_rows:
+ *   h' = drop((1 - z) * tanh(gi_n + r * gh_n) + z * h).  Replaces ptgnn GatedMessagePassingLayer's
+ * nn.GRUCell state update (reference call site buglab/models/gnnlayerdefs.py:42-68).
+ * bwd writes g_gi, g_gh [N, 3D] and the direct part of g_h (z * g_out) [N, D]. */
+int bl_gru_cell_fwd(const float* gi, const float* gh, const float* h, int32_t ld_h, int32_t N, int32_t D,
+                    bl_dropout_t drop, float* out, void* stream);
+int bl_gru_cell_bwd(const float* g_out, const float* gi, const float* gh, const float* h, int32_t ld_h, int32_t N,
+                    int32_t D, bl_dropout_t drop, float* g_gi, float* g_gh, float* g_h, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Heads.

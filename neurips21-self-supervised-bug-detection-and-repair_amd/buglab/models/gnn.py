@@ -207,7 +207,7 @@ def const_weight_schedule(_epoch_idx: int, weight: float = 1.0) -> float:
 def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_edge_types: int = 16,
                          vocabulary_size: int = 15000, max_num_subtokens: int = 6, rewrite_vocabulary_size: int = 48,
                          dropout_rate: float = 0.2, message_activation: str = "gelu",
-                         buggy_samples_weight: float = 1.0, dropout_base_seed: int = 0) -> GnnBugLabModule:
+                         buggy_samples_weight: float = 1.0, dropout_base_seed: int = 0, model: str = "gnn-mlp") -> GnnBugLabModule:
     """Device module for given hyper-parameters without a metadata pass (bench / tests / synthetic
     runs).  `GnnBugLabModel.build_neural_module()` goes through the same constructors."""
     from functools import partial
@@ -216,8 +216,13 @@ def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_
     from buglab.models.layers.messagepassing import SubtokenEmbedder
 
     embed = SubtokenEmbedder(vocabulary_size, hidden_state_size, max_num_subtokens, dropout_rate)
-    recipe = create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edge_types, num_layers=num_layers,
-                                  message_activation=message_activation)
+    if model == "ggnn":
+        from buglab.models.gnnlayerdefs import create_ggnn_mp_layers
+
+        recipe = create_ggnn_mp_layers(hidden_state_size, dropout_rate, num_edge_types)
+    else:
+        recipe = create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edge_types, num_layers=num_layers,
+                                      message_activation=message_activation)
     return GnnBugLabModule(GraphNeuralNetwork(embed, recipe), rewrite_vocabulary_size,
                            buggy_samples_weight_schedule=partial(const_weight_schedule, weight=buggy_samples_weight),
                            dropout_base_seed=dropout_base_seed)

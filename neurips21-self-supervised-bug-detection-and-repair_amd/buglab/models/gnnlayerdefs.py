@@ -1,5 +1,5 @@
 """Layer-stack recipes, same function names/kwargs as reference buglab/models/gnnlayerdefs.py."""
-from buglab.models.layers.messagepassing import ConcatResidualLayer, MlpMessagePassingLayer
+from buglab.models.layers.messagepassing import ConcatResidualLayer, GatedMessagePassingLayer, MlpMessagePassingLayer
 
 
 def create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edges: int, features_dimension: int = 0,
@@ -21,6 +21,15 @@ def create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edges: int, featur
     return layers
 
 
-def create_ggnn_mp_layers(hidden_state_size, dropout_rate, num_edges: int):
-    raise NotImplementedError("`ggnn` (GatedMessagePassingLayer, reference gnnlayerdefs.py:42-68) is a SURVEY section 8f "
-                              "'next' row; only `gnn-mlp` runs on the HIP path so far")
+def create_ggnn_mp_layers(hidden_state_size, dropout_rate, num_edges: int, features_dimension: int = 0):
+    """Reference gnnlayerdefs.py:42-68: ONE gated layer applied seven times (weights shared), a concat
+    residual with the input states, then a gated layer over the 2H-wide states (message dimension H)."""
+    assert features_dimension == 0
+    ggnn_mp = GatedMessagePassingLayer(state_dimension=hidden_state_size, message_dimension=hidden_state_size,
+                                       num_edge_types=num_edges, message_aggregation_function="max", dropout_rate=dropout_rate)
+    r1 = ConcatResidualLayer(hidden_state_size)
+    return [r1.pass_through_dummy_layer()] + [ggnn_mp] * 7 + [
+        r1,
+        GatedMessagePassingLayer(state_dimension=2 * hidden_state_size, message_dimension=hidden_state_size,
+                                 num_edge_types=num_edges, message_aggregation_function="max", dropout_rate=dropout_rate),
+    ]

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gru_cell_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gru_cell_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_log_softmax_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_log_softmax_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_rowdot_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
@@ -482,6 +484,66 @@ class _MpLayer(torch.autograd.Function):
         side1.join()
         pair.__exit__(None, None, None)
         return g_h, g_W, g_lng, g_lnb, g_Wd, g_bd, None, None, None
+
+
+class _GatedMpLayer(torch.autograd.Function):
+    """One GatedMessagePassingLayer (GGNN): m_e = h[src] @ W[type] -> segmented max -> GRU cell(+dropout).
+    Backward keeps per-node arrays only (winner table + GRU gate pre-activations)."""
+
+    @staticmethod
+    def forward(ctx, h, W, Wi, bi, Wh, bh, g: GraphIndex, drop: Dropout):
+        _f32(h, "node states")
+        N, D = h.shape
+        T, Din, Dm = W.shape
+        E = g.num_messages
+        assert Din == D and Wi.shape == (Dm, 3 * D) and Wh.shape == (D, 3 * D)
+        msgs = gemm_rows([(h, g.msg_src)], _f32(W, "W"), E, Dm, b_group_stride=D * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
+        agg, arg, _, _, _ = segment_max(msgs, g.tgt_ptr, g.tgt_msgs, N)
+        del msgs
+        gi = gemm_rows([(agg, None)], _f32(Wi), N, 3 * D, bias=_f32(bi))
+        gh = gemm_rows([(h, None)], _f32(Wh), N, 3 * D, bias=_f32(bh))
+        out = torch.empty((N, D), dtype=torch.float32, device=h.device)
+        _check(load_library().bl_gru_cell_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), h.stride(0), N, D, drop.c(), out.data_ptr(), _stream()),
+               "bl_gru_cell_fwd")
+        ctx.saved = (h, W, Wi, Wh, agg, arg, gi, gh, g, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        h, W, Wi, Wh, agg, arg, gi, gh, g, drop = ctx.saved
+        ctx.saved = None
+        N, D = h.shape
+        T, _, Dm = W.shape
+        E = g.num_messages
+        dev = h.device
+        g_out = g_out.contiguous()
+        g_gi = torch.empty_like(gi)
+        g_gh = torch.empty_like(gh)
+        g_h = torch.empty_like(h)
+        _check(load_library().bl_gru_cell_bwd(g_out.data_ptr(), gi.data_ptr(), gh.data_ptr(), h.data_ptr(), h.stride(0), N, D, drop.c(),
+                                              g_gi.data_ptr(), g_gh.data_ptr(), g_h.data_ptr(), _stream()), "bl_gru_cell_bwd")
+        g_bi, g_bh = g_gi.sum(0), g_gh.sum(0)
+        g_Wi, g_Wh, g_W = torch.zeros_like(Wi), torch.zeros_like(Wh), torch.zeros_like(W)
+        side = _on_side_stream(dev)
+        with side:
+            gemm_wgrad([(agg, None)], g_gi, N, 3 * D, g_Wi)
+            gemm_wgrad([(h, None)], g_gh, N, 3 * D, g_Wh)
+        g_h += gemm_rows([(g_gh, None)], Wh, N, D, b_is_nk=True, ldb=3 * D)
+        gq = gemm_rows([(g_gi, None)], Wi, N, Dm, b_is_nk=True, ldb=3 * D)  # d loss / d aggregate
+        with side:
+            gemm_wgrad_routed([(h, g.msg_src)], gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=D * Dm, group_ptr=g.type_ptr, G=T)
+        g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, D, b_group_stride=D * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
+        _check(
+            load_library().bl_mp_scatter_grad(g_a.data_ptr(), g_a.stride(0), g.src_ptr.data_ptr(), g.src_msgs.data_ptr(), None, None,
+                                              N, D, 1, g_h.data_ptr(), g_h.stride(0), _stream()),
+            "bl_mp_scatter_grad")
+        side.join()
+        side.join()
+        return g_h, g_W, g_Wi, g_bi, g_Wh, g_bh, None, None
+
+
+def gated_mp_layer(h, W, Wi, bi, Wh, bh, graph: GraphIndex, drop: Dropout = NO_DROPOUT):
+    return _GatedMpLayer.apply(h.contiguous(), W, Wi, bi, Wh, bh, graph, drop)
 
 
 def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu", drop: Dropout = NO_DROPOUT):

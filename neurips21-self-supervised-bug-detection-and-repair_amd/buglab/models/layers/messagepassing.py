@@ -74,6 +74,30 @@ class MlpMessagePassingLayer(nn.Module):
                                 self.message_activation, drop)
 
 
+class GatedMessagePassingLayer(nn.Module):
+    """GGNN layer, kwargs as at the reference call site gnnlayerdefs.py:43-67.  Frozen spec (ptgnn's
+    source is unavailable): m_e = h[src] @ W[type(e)] (no bias), max-aggregate
+    (0 if none), h' = Dropout(GRUCell(input = aggregate, hidden = h)), torch.nn.GRUCell gate order."""
+
+    def __init__(self, state_dimension: int, message_dimension: int, num_edge_types: int,
+                 message_aggregation_function: str = "max", dropout_rate: float = 0.0):
+        super().__init__()
+        if message_aggregation_function != "max":
+            raise NotImplementedError("the HIP path implements the reference's `max` aggregation (gnnlayerdefs.py:47,63)")
+        D, Dm, T = state_dimension, message_dimension, num_edge_types
+        self.state_dimension, self.message_dimension, self.output_state_dimension = D, Dm, D
+        self.num_edge_types, self.dropout_rate = T, dropout_rate
+        k = 1.0 / math.sqrt(D)
+        self.W = nn.Parameter(_uniform_(torch.empty(T, D, Dm), 1.0 / math.sqrt(D)))
+        self.Wi = nn.Parameter(_uniform_(torch.empty(Dm, 3 * D), k))  # nn.GRUCell init: U(-1/sqrt(hidden), +)
+        self.bi = nn.Parameter(_uniform_(torch.empty(3 * D), k))
+        self.Wh = nn.Parameter(_uniform_(torch.empty(D, 3 * D), k))
+        self.bh = nn.Parameter(_uniform_(torch.empty(3 * D), k))
+
+    def forward(self, node_states, graph: GraphIndex, drop: Dropout):
+        return hip_ops.gated_mp_layer(node_states, self.W, self.Wi, self.bi, self.Wh, self.bh, graph, drop)
+
+
 class ConcatResidualLayer:
     """Stateless marker pair (gnnlayerdefs.py:24-38): `pass_through_dummy_layer()` stashes the
     current node states, the layer itself returns [stash ; current]."""
@@ -101,9 +125,14 @@ class GraphNeuralNetwork(nn.Module):
         super().__init__()
         self.embed = node_embedder
         self._recipe = layer_recipe
-        self.mp = nn.ModuleList([l for l in layer_recipe if isinstance(l, MlpMessagePassingLayer)])
+        mp, seen = [], set()
+        for l in layer_recipe:  # a layer object may appear several times (weight sharing, ggnn recipe)
+            if isinstance(l, (MlpMessagePassingLayer, GatedMessagePassingLayer)) and id(l) not in seen:
+                seen.add(id(l))
+                mp.append(l)
+        self.mp = nn.ModuleList(mp)
         self.input_node_state_dim = node_embedder.embedding_size
-        self.output_node_state_dim = self.mp[-1].output_state_dimension
+        self.output_node_state_dim = [l for l in layer_recipe if isinstance(l, nn.Module)][-1].output_state_dimension
 
     @property
     def message_passing_layers(self):

@@ -38,6 +38,8 @@ def buggy_sample_weight_schedule(weight_spec: Union[str, int, float]) -> Callabl
 
 
 def _mp_layers(mp_layer, hidden_state_size, dropout_rate, edge_feature_size, extra, n_edges):
+    if mp_layer is create_ggnn_mp_layers:
+        extra = {}  # the ggnn recipe has no layer-count / activation knobs (reference gnnlayerdefs.py:42-68)
     return mp_layer(hidden_state_size, dropout_rate, n_edges, features_dimension=edge_feature_size, **extra)
 
 

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
   }
 #pragma unroll
   for (int part = 0; part < 2; ++part) {
+    if (part == 1 && tgt_ptr == nullptr) continue;  // source-only messages (GGNN)
     const int* __restrict__ ptr = part == 0 ? src_ptr : tgt_ptr;
     const int* __restrict__ items = part == 0 ? src_msgs : tgt_msgs;
     const int coff = part == 0 ? 0 : Din;
@@ -351,6 +352,62 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
     const int d = lane + 64 * j;
     if (d < Din) g_h[(size_t)n * ld_gh + d] = acc[j];
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GRU cell of the gated (GGNN) node update, torch.nn.GRUCell gate order [r | z | n]:
+//   r = sig(gi_r + gh_r), z = sig(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = drop((1 - z) * n + z * h)
+// gi = x W_i + b_i and gh = h W_h + b_h come from the MFMA GEMM; this kernel is the elementwise part.
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                           const float* __restrict__ h, int ld_h, long long N, int D,
+                                                           bl_drop_dev drop, float* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * D) return;
+  const long long n = t / D;
+  const int d = (int)(t % D);
+  const float* a = gi + n * 3 * D;
+  const float* b = gh + n * 3 * D;
+  const float r = 1.f / (1.f + expf(-(a[d] + b[d])));
+  const float z = 1.f / (1.f + expf(-(a[D + d] + b[D + d])));
+  const float nn = tanhf(a[2 * D + d] + r * b[2 * D + d]);
+  float v = (1.f - z) * nn + z * h[n * ld_h + d];
+  if (drop.thresh) v = bl_keep(drop, (uint32_t)t) ? v * drop.scale : 0.f;
+  out[t] = v;
+}
+
+__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ gi,
+                                                           const float* __restrict__ gh, const float* __restrict__ h,
+                                                           int ld_h, long long N, int D, bl_drop_dev drop,
+                                                           float* __restrict__ g_gi, float* __restrict__ g_gh,
+                                                           float* __restrict__ g_h) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * D) return;
+  const long long n = t / D;
+  const int d = (int)(t % D);
+  const float* a = gi + n * 3 * D;
+  const float* b = gh + n * 3 * D;
+  const float r = 1.f / (1.f + expf(-(a[d] + b[d])));
+  const float z = 1.f / (1.f + expf(-(a[D + d] + b[D + d])));
+  const float bn = b[2 * D + d];
+  const float nn = tanhf(a[2 * D + d] + r * bn);
+  const float hv = h[n * ld_h + d];
+  float g = g_out[t];
+  if (drop.thresh) g = bl_keep(drop, (uint32_t)t) ? g * drop.scale : 0.f;
+  const float g_n = g * (1.f - z);
+  const float g_z = g * (hv - nn);
+  const float g_npre = g_n * (1.f - nn * nn);
+  const float g_r = g_npre * bn;
+  const float g_rpre = g_r * r * (1.f - r);
+  const float g_zpre = g_z * z * (1.f - z);
+  float* ga = g_gi + n * 3 * D;
+  float* gb = g_gh + n * 3 * D;
+  ga[d] = g_rpre;
+  gb[d] = g_rpre;
+  ga[D + d] = g_zpre;
+  gb[D + d] = g_zpre;
+  ga[2 * D + d] = g_npre;
+  gb[2 * D + d] = g_npre * r;
+  g_h[t] = g * z;
 }
 
 // ================================================================================================
@@ -457,11 +514,34 @@ extern "C" int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t
                                   const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din,
                                   int32_t accumulate, float* g_h, int32_t ld_gh, void* stream) {
   if (N == 0) return BL_OK;
-  BL_CHECK_ARG(g_a && src_ptr && src_msgs && tgt_ptr && tgt_msgs && g_h, "bl_mp_scatter_grad: null pointer");
-  BL_CHECK_ARG(Din > 0 && Din <= 512 && ld_ga >= 2 * Din, "bl_mp_scatter_grad: Din in 1..512, ld_ga >= 2*Din");
+  BL_CHECK_ARG(g_a && src_ptr && src_msgs && g_h && (tgt_ptr == nullptr) == (tgt_msgs == nullptr), "bl_mp_scatter_grad: null pointer");
+  BL_CHECK_ARG(Din > 0 && Din <= 512 && ld_ga >= (tgt_ptr ? 2 : 1) * Din, "bl_mp_scatter_grad: Din in 1..512, ld_ga >= (1 or 2)*Din");
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_a, ld_ga,
                                        src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh))
   BL_LAUNCH_CHECK("bl_mp_scatter_grad");
+  return BL_OK;
+}
+
+extern "C" int bl_gru_cell_fwd(const float* gi, const float* gh, const float* h, int32_t ld_h, int32_t N, int32_t D,
+                               bl_dropout_t drop, float* out, void* stream) {
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(gi && gh && h && out && D > 0, "bl_gru_cell_fwd: null pointer");
+  const long long total = (long long)N * D;
+  hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gi, gh, h,
+                     ld_h, (long long)N, D, bl_make_drop(drop), out);
+  BL_LAUNCH_CHECK("bl_gru_cell_fwd");
+  return BL_OK;
+}
+
+extern "C" int bl_gru_cell_bwd(const float* g_out, const float* gi, const float* gh, const float* h, int32_t ld_h,
+                               int32_t N, int32_t D, bl_dropout_t drop, float* g_gi, float* g_gh, float* g_h,
+                               void* stream) {
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(g_out && gi && gh && h && g_gi && g_gh && g_h && D > 0, "bl_gru_cell_bwd: null pointer");
+  const long long total = (long long)N * D;
+  hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out, gi,
+                     gh, h, ld_h, (long long)N, D, bl_make_drop(drop), g_gi, g_gh, g_h);
+  BL_LAUNCH_CHECK("bl_gru_cell_bwd");
   return BL_OK;
 }

@@ -105,8 +105,14 @@ def gnn_mlp_stack(hidden: int, num_layers: int = 8) -> List[Tuple]:
     return ops
 
 
+def ggnn_stack(hidden: int) -> List[Tuple]:
+    """gnnlayerdefs.py:42-68: one shared gated layer x7, concat residual, one gated layer on 2H states."""
+    return [("stash", 0)] + [("gg", 0, hidden, hidden)] * 7 + [("concat", 0), ("gg", 1, 2 * hidden, hidden)]
+
+
 @dataclass
 class OracleConfig:
+    model: str = "gnn-mlp"  # or "ggnn"
     hidden: int = 128
     num_layers: int = 8
     num_edge_types: int = 16
@@ -130,7 +136,16 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32) -> Dict[s
 
     p: Dict[str, torch.Tensor] = {}
     p["embed.table"] = torch.randn((cfg.vocab_size, H), generator=g, dtype=torch.float64).to(dtype)
-    for op in gnn_mlp_stack(H, cfg.num_layers):
+    if cfg.model == "ggnn":
+        for li, (D, Dm) in enumerate(((H, H), (2 * H, H))):
+            k = 1.0 / math.sqrt(D)
+            p[f"mp.{li}.W"] = uni((cfg.num_edge_types, D, Dm), k)
+            p[f"mp.{li}.Wi"] = uni((Dm, 3 * D), k)
+            p[f"mp.{li}.bi"] = uni((3 * D,), k)
+            p[f"mp.{li}.Wh"] = uni((D, 3 * D), k)
+            p[f"mp.{li}.bh"] = uni((3 * D,), k)
+        H = 2 * H  # ggnn's output states are 2H wide (the last gated layer keeps its state dimension)
+    for op in (gnn_mlp_stack(cfg.hidden, cfg.num_layers) if cfg.model != "ggnn" else []):
         if op[0] != "mp":
             continue
         _, li, din, dm, dout = op
@@ -243,6 +258,25 @@ def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_dr
 
 
 # ----------------------------------------------------------------------------
+# GatedMessagePassingLayer (GGNN; spec frozen in the product's docstring, **parity unpinned** like M1-M3):
+#   m_e = h[src] @ W[type(e)];  a_v = max (0 if none);  h' = Dropout(GRUCell(a_v, h_v)), gates [r|z|n]
+# ----------------------------------------------------------------------------
+def gated_mp_layer(h, W, Wi, bi, Wh, bh, msg_src, msg_tgt, type_ptr, p_drop, seed, stream):
+    N, D = h.shape
+    src = torch.as_tensor(msg_src, dtype=torch.int64)
+    tgt = torch.as_tensor(msg_tgt, dtype=torch.int64)
+    msgs = [h[src[int(type_ptr[t]):int(type_ptr[t + 1])]] @ W[t] for t in range(W.shape[0])]
+    m = torch.cat(msgs, dim=0) if msgs else h.new_zeros((0, W.shape[2]))
+    agg, _ = scatter_max_with_arg(m, tgt, N)
+    gi = agg @ Wi + bi
+    gh = h @ Wh + bh
+    r = torch.sigmoid(gi[:, :D] + gh[:, :D])
+    z = torch.sigmoid(gi[:, D:2 * D] + gh[:, D:2 * D])
+    n = torch.tanh(gi[:, 2 * D:] + r * gh[:, 2 * D:])
+    return apply_dropout((1 - z) * n + z * h, p_drop, seed, stream)
+
+
+# ----------------------------------------------------------------------------
 # M4-M5  GNN stack (gnnlayerdefs.py:26-39; ConcatResidualLayer = [stash ; current])
 # ----------------------------------------------------------------------------
 def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None):
@@ -250,11 +284,17 @@ def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None):
     if trace is not None:
         trace.append({"embed": h})
     stash = {}
-    for op in gnn_mlp_stack(cfg.hidden, cfg.num_layers):
+    napplied = 0
+    for op in (gnn_mlp_stack(cfg.hidden, cfg.num_layers) if cfg.model != "ggnn" else ggnn_stack(cfg.hidden)):
         if op[0] == "stash":
             stash[op[1]] = h
         elif op[0] == "concat":
             h = torch.cat([stash[op[1]], h], dim=-1)
+        elif op[0] == "gg":
+            li = op[1]
+            h = gated_mp_layer(h, params[f"mp.{li}.W"], params[f"mp.{li}.Wi"], params[f"mp.{li}.bi"], params[f"mp.{li}.Wh"],
+                               params[f"mp.{li}.bh"], gd["msg_src"], gd["msg_tgt"], gd["type_ptr"], cfg.dropout, seed, stream=1 + napplied)
+            napplied += 1
         else:
             li = op[1]
             h = mp_layer(

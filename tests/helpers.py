@@ -53,7 +53,7 @@ def build_module_like(cfg, params=None, device="cuda"):
     from buglab.models.gnn import build_gnn_mlp_module
 
     m = build_gnn_mlp_module(cfg.hidden, cfg.num_layers, cfg.num_edge_types, cfg.vocab_size, cfg.max_subtokens,
-                             cfg.rewrite_vocab_size, cfg.dropout, cfg.msg_act, cfg.buggy_samples_weight).to(device)
+                             cfg.rewrite_vocab_size, cfg.dropout, cfg.msg_act, cfg.buggy_samples_weight, model=cfg.model).to(device)
     if params is not None:
         load_oracle_params(m, params)
     return m

@@ -204,3 +204,20 @@ def test_hot_path_fails_loudly_without_gpu():
     mb = C.to_device(C.collate_samples(make_samples(2, num_nodes=20, num_messages=50, num_edge_types=3, vocab_size=50, num_candidates=4), 3), "cpu")
     with pytest.raises(hip_ops.HipOpsUnavailable):
         m(**mb)
+
+
+def test_ggnn_registry_recipe_shapes():
+    """`ggnn` (reference modelregistry.py:132, gnnlayerdefs.py:42-68): 7 applications of ONE shared
+    gated layer, concat residual, one gated layer on 2H-wide states; no self-loop edge type."""
+    from buglab.models.layers.messagepassing import GatedMessagePassingLayer
+    from buglab.models.modelregistry import load_model
+
+    data = make_buglab_dataset(6, seed=7)
+    model = load_model({"modelName": "ggnn", "hidden_state_size": 32}, Path("/tmp/_bl_ggnn.pkl.gz"))[0]
+    model.compute_metadata(copy.deepcopy(data))
+    assert model.gnn_model.num_presented_edge_types == 10  # 5 kinds + reversed, add_self_edge=False
+    nn = model.build_neural_module()
+    gated = [l for l in nn._gnn._recipe if isinstance(l, GatedMessagePassingLayer)]
+    assert len(gated) == 8 and len({id(l) for l in gated[:7]}) == 1 and len(nn._gnn.mp) == 2
+    assert nn._gnn.mp[0].W.shape == (10, 32, 32) and nn._gnn.mp[1].W.shape == (10, 64, 32) and nn._gnn.mp[1].Wh.shape == (64, 192)
+    assert nn._gnn.output_node_state_dim == 64 and nn._localization_module.Ws.shape == (64, 64)

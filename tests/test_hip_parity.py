@@ -284,3 +284,12 @@ def test_generator_loss_through_collator_matches_oracle():
         module.eval()
         loss = module(**to_device(mb_np, "cuda"))
         assert abs(float(loss.detach()) - float(ref)) < TOL, loss_type
+
+
+def test_ggnn_forward_backward_matches_oracle():
+    """`ggnn` registry model (reference gnnlayerdefs.py:42-68): shared gated layer x7 + concat + gated
+    layer on 2H states, GRU node update in HIP.  Spec frozen like gnn-mlp's (parity unpinned vs ptgnn)."""
+    cfg, _, mb = Hh.make_case(B=3, n=70, E=350, T=5, H=32, layers=4, model="ggnn", seed=13)
+    _check_against_oracle(cfg, mb)
+    cfg, _, mb = Hh.make_case(B=2, n=60, E=300, T=3, H=64, layers=4, model="ggnn", dropout=0.15, seed=14)
+    _check_against_oracle(cfg, mb, seed=4242)
