@@ -179,6 +179,7 @@ class KernelTimer:
 
 
 _overlap_depth = 0
+_free_running = False  # weight-gradient GEMMs of earlier layers may still be running on the side stream
 
 
 class _timed:
@@ -195,7 +196,7 @@ class _timed:
         if self.t is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.t.records.append((self.kind, self.flop, self.e0, e1, (not self.span) and _overlap_depth > 0))
+            self.t.records.append((self.kind, self.flop, self.e0, e1, (not self.span) and (_overlap_depth > 0 or _free_running)))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -332,6 +333,29 @@ def scatter_add_rows(src, col_off, width, idx, out):
 # the other kernel's workgroups.  BL_SIDE_STREAM=0 disables.
 _side_streams = {}
 USE_SIDE_STREAM = os.environ.get("BL_SIDE_STREAM", "1") != "0"
+# Weight gradients of the message-passing layers are accumulated (fp32 atomics in the kernel)
+# straight into `param.grad` when it already exists (FlatAdam pre-binds every .grad to a view of the
+# flat gradient buffer), on the side stream, WITHOUT joining at the end of the layer's backward:
+# the side stream runs one weight-gradient GEMM after the other behind the main chain and is
+# joined once, by `join_side_stream()`, before the gradients are consumed (FlatAdam.step / tests).
+DIRECT_PARAM_GRAD = os.environ.get("BL_DIRECT_GRAD", "1") != "0"
+
+
+def join_side_stream():
+    """Make the current stream wait for every weight-gradient GEMM still running on the side stream."""
+    global _free_running
+    if torch.cuda.is_available():
+        key = torch.cuda.current_device()
+        if key in _side_streams:
+            torch.cuda.current_stream().wait_stream(_side_streams[key])
+    _free_running = False
+
+
+def _direct_grad_target(param):
+    g = getattr(param, "grad", None)
+    if DIRECT_PARAM_GRAD and USE_SIDE_STREAM and g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
+        return g
+    return None
 
 
 class _on_side_stream:
@@ -361,6 +385,16 @@ class _on_side_stream:
         global _overlap_depth
         if self.enabled:
             self.main.wait_stream(self.side)
+            _overlap_depth -= 1
+
+    def detach(self, *tensors):
+        """Leave the side-stream work running: the tensors it reads are pinned to the side stream
+        (the caching allocator will not recycle them before that work is done)."""
+        global _overlap_depth
+        if self.enabled:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.side)
             _overlap_depth -= 1
 
 
@@ -454,8 +488,9 @@ class _MpLayer(torch.autograd.Function):
         # dense + tanh + dropout
         g_bd = torch.zeros((Dout,), dtype=torch.float32, device=dev)
         g_z = act_bwd(g_out, out, ACT_TANH, drop, g_bd)
-        g_Wd = torch.zeros_like(Wd)
-        g_W = torch.zeros_like(W)
+        Wd_direct, W_direct = _direct_grad_target(Wd), _direct_grad_target(W)
+        g_Wd = Wd_direct if Wd_direct is not None else torch.zeros_like(Wd)
+        g_W = W_direct if W_direct is not None else torch.zeros_like(W)
         side1 = _on_side_stream(dev)
         with side1:
             gemm_wgrad([(ln_out, None)], g_z, N, Dout, g_Wd)
@@ -480,9 +515,20 @@ class _MpLayer(torch.autograd.Function):
                                               g.tgt_ptr.data_ptr(), g.tgt_msgs.data_ptr(), N, Din, 0, g_h.data_ptr(),
                                               g_h.stride(0), _stream()),
             "bl_mp_scatter_grad")
+        if W_direct is not None and Wd_direct is not None:
+            # gradients land in param.grad behind the main chain; joined by join_side_stream()
+            global _free_running
+            _free_running = True
+            side2.detach(h, gq, arg)
+            side1.detach(ln_out, g_z)
+            return g_h, None, g_lng, g_lnb, None, g_bd, None, None, None
         side2.join()
         side1.join()
         pair.__exit__(None, None, None)
+        if W_direct is not None:
+            g_W = None
+        if Wd_direct is not None:
+            g_Wd = None
         return g_h, g_W, g_lng, g_lnb, g_Wd, g_bd, None, None, None
 
 

@@ -43,6 +43,7 @@ class FlatAdam:
         self.process_group = process_group
 
     def zero_grad(self):
+        hip_ops.join_side_stream()
         self.flat_grad.zero_()
 
     def lr_at(self, step: int) -> float:
@@ -67,6 +68,7 @@ class FlatAdam:
         return grad_weight
 
     def step(self, grad_weight: float = 1.0):
+        hip_ops.join_side_stream()  # weight-gradient GEMMs accumulate into flat_grad on the side stream
         self.step_count += 1
         prescale = self.reduce_gradients(grad_weight)
         if self.flat_param.is_cuda:

@@ -30,6 +30,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// clock probe (tuning only): min start / max end of the shader-clock and the 100 MHz wall counters
+__device__ unsigned long long bl_clk_probe[4];
+
 #define BM 128
 #define BN 128
 
@@ -99,19 +102,19 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) { return ok ? v : make
 // wave (measured: message GEMM 0.487 -> 0.462 ms, input-gradient GEMM 0.566 -> 0.510 ms at c2 shapes).
 // The weight-gradient kernel keeps the plain layout (col = lane & 31): its fp32 atomics then hit 32
 // consecutive floats of one row per instruction.
-template <bool SWAP>
-__device__ __forceinline__ void mfma_group(const float (&a_)[2][4], const float (&b_)[2][4], f32x16 (&acc)[2][2]) {
+template <bool SWAP, int TI>
+__device__ __forceinline__ void mfma_group(const float (&a_)[TI][4], const float (&b_)[2][4], f32x16 (&acc)[TI][2]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
         acc[ti][tj] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b_[tj][s], a_[ti][s], acc[ti][tj], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_32x32x2f32(a_[ti][s], b_[tj][s], acc[ti][tj], 0, 0, 0);
 }
 
-template <bool B_NK, int ACT, int BK, int NBUF, int MINW, bool MASKED>
+template <bool B_NK, int ACT, int BK, int NBUF, int MINW, bool MASKED, int TBM>
 __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const int* __restrict__ mask_arg,
                                                               int mask_ld, const float* __restrict__ b,
                                                               long long strideB, int ldb,
@@ -119,26 +122,32 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
                                                               const int* __restrict__ group_ptr,
                                                               const int* __restrict__ group_w, int G, int M, int N,
                                                               int K, uint32_t drop_key, uint32_t drop_thresh,
-                                                              float drop_scale, float* __restrict__ c, int ldc) {
+                                                              float drop_scale, float* __restrict__ c, int ldc, int probe) {
   constexpr int LDS_MN = BK + 4;        // row stride of an MN-major image
   constexpr int LDS_K = 128;            // row stride of a K-major image
-  constexpr int A_SZ = BM * LDS_MN;     // floats per A buffer
+  constexpr int TI = TBM / 64;          // 32-row MFMA tiles per wave (waves are 2 x 2 over TBM x 128)
+  constexpr int A_SZ = TBM * LDS_MN;    // floats per A buffer
   constexpr int B_SZ = B_NK ? BN * LDS_MN : BK * LDS_K;
-  constexpr int NLD = BK / 8;           // float4 loads per thread per operand per stage
+  constexpr int NLD = BK / 8;           // float4 loads per thread per stage, B operand (128 x BK)
+  constexpr int NLDA = (TBM * BK / 4) / 256;  // ... A operand (TBM x BK)
   constexpr int A_LPR = BK / 4;         // lanes per MN-major line
   constexpr int A_LSTEP = 256 / A_LPR;  // MN-major lines covered by one pass of the block
   __shared__ __attribute__((aligned(16))) float As[NBUF * A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[NBUF * B_SZ];
-  __shared__ int rowidx[3][BM];
+  __shared__ int rowidx[3][TBM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (probe && tid == 0 && blockIdx.x == 7 && blockIdx.y == 0) {
+    bl_clk_probe[0] = (unsigned long long)clock64();
+    bl_clk_probe[1] = (unsigned long long)wall_clock64();
+  }
   int g, row0, nrows;
-  if (!find_piece(group_ptr, G, M, BM, blockIdx.x, g, row0, nrows)) return;
+  if (!find_piece(group_ptr, G, M, TBM, blockIdx.x, g, row0, nrows)) return;
   const int n0 = blockIdx.y * BN;
   const int wsel = group_w ? group_w[g] : g;
   const float* __restrict__ Bg = b + (long long)wsel * strideB;
 
-  if (tid < BM) {
+  if (tid < TBM) {
     const int r = row0 + min(tid, nrows - 1);  // rows past the group end re-read its last row (never stored)
     rowidx[0][tid] = idx0 ? idx0[r] : r;
     if (nsrc > 1) rowidx[1][tid] = idx1 ? idx1[r] : r;
@@ -146,8 +155,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
   }
   __syncthreads();
 
-  float4 ra[NLD], rb[NLD];
-  int4 ia[MASKED ? NLD : 1];  // winner ids of the routing mask (source 0), compared at LDS-store time
+  float4 ra[NLDA], rb[NLD];
+  int4 ia[MASKED ? NLDA : 1];  // winner ids of the routing mask (source 0), compared at LDS-store time
   const int a_c4 = tid % A_LPR, a_line0 = tid / A_LPR;  // MN-major loader
   const int k_c4 = tid & 31, k_line0 = tid >> 5;         // K-major loader: 32 lanes per 512-byte line
   const int nk = (K + BK - 1) / BK;
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
     const int kl_ = kc_ - (j_ == 0 ? 0 : (j_ == 1 ? koff1 : koff2));                                      \
     const float* base_ = j_ == 0 ? x0 : (j_ == 1 ? x1 : x2);                                              \
     const int ld_ = j_ == 0 ? ld0 : (j_ == 1 ? ld1 : ld2);                                                \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                     \
+    _Pragma("unroll") for (int i = 0; i < NLDA; ++i) {                                                    \
       const int line_ = a_line0 + A_LSTEP * i;                                                            \
       ra[i] = ld4(base_ + (size_t)rowidx[j_][line_] * ld_ + kl_);                                         \
       if (MASKED)                                                                                         \
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
     float* As_w = As + (buf_) * A_SZ;                                                                        \
     float* Bs_w = Bs + (buf_) * B_SZ;                                                                        \
     const bool kok_ = (k0_) + 4 * a_c4 < K;                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
+    _Pragma("unroll") for (int i = 0; i < NLDA; ++i) {                                                       \
       float4 av_ = ra[i];                                                                                    \
       if (MASKED) { /* routing mask: keep element k of row r only where r is the recorded winner */          \
         const int rid_ = row0 + a_line0 + A_LSTEP * i;                                                       \
@@ -200,6 +209,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
         av_.z = ia[i].z == rid_ ? av_.z : 0.f; av_.w = ia[i].w == rid_ ? av_.w : 0.f;                        \
       }                                                                                                      \
       *reinterpret_cast<float4*>(&As_w[(a_line0 + A_LSTEP * i) * LDS_MN + 4 * a_c4]) = sel4(kok_, av_);      \
+    }                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
       if (!B_NK)                                                                                             \
         *reinterpret_cast<float4*>(&Bs_w[(k_line0 + 8 * i) * LDS_K + 4 * k_c4]) =                             \
             sel4(n0 + 4 * k_c4 < N && (k0_) + k_line0 + 8 * i < K, rb[i]);                                    \
@@ -209,9 +220,9 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
     }                                                                                                        \
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][2];
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
@@ -228,11 +239,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
     const float* As_ = As + cur * A_SZ;
     const float* Bs_ = Bs + cur * B_SZ;
     // fragments of k-group q+1 are read from LDS while the 16 MFMAs of group q issue
-    float fa[2][2][4], fb[2][2][4];
+    float fa[2][TI][4], fb[2][2][4];
 #define ROWS_READ_FRAGS(q_, slot_)                                                                                      \
   {                                                                                                                     \
-    _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) {                                                                  \
-      const float4 v = *reinterpret_cast<const float4*>(&As_[(wm * 64 + ti * 32 + li) * LDS_MN + 8 * (q_) + 4 * half]);  \
+    _Pragma("unroll") for (int ti = 0; ti < TI; ++ti) {                                                                 \
+      const float4 v = *reinterpret_cast<const float4*>(&As_[(wm * 32 * TI + ti * 32 + li) * LDS_MN + 8 * (q_) + 4 * half]); \
       fa[slot_][ti][0] = v.x; fa[slot_][ti][1] = v.y; fa[slot_][ti][2] = v.z; fa[slot_][ti][3] = v.w;                   \
     }                                                                                                                   \
     _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) {                                                                  \
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
 #pragma unroll
     for (int q = 0; q < BK / 8; ++q) {
       if (q + 1 < BK / 8) ROWS_READ_FRAGS(q + 1, (q + 1) & 1)
-      mfma_group<true>(fa[q & 1], fb[q & 1], acc);
+      mfma_group<true, TI>(fa[q & 1], fb[q & 1], acc);
     }
     if (NBUF == 1) {
       __syncthreads();
@@ -267,8 +278,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
   // epilogue (transposed accumulator, see mfma_group): lane owns row m = li of each 32x32 tile and,
   // per register group g, the 4 consecutive columns n = 8g + 4*half + 0..3 -> one float4 store each
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti) {
-    const int m = wm * 64 + ti * 32 + li;
+  for (int ti = 0; ti < TI; ++ti) {
+    const int m = wm * 32 * TI + ti * 32 + li;
     if (m >= nrows) continue;
     float* __restrict__ crow = c + (size_t)(row0 + m) * ldc;
 #pragma unroll
@@ -291,6 +302,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
         }
         *reinterpret_cast<float4*>(crow + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
+  }
+  if (probe && tid == 0 && blockIdx.x == 7 && blockIdx.y == 0) {
+    bl_clk_probe[2] = (unsigned long long)clock64();
+    bl_clk_probe[3] = (unsigned long long)wall_clock64();
   }
 }
 
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, cons
 #pragma unroll
     for (int q = 0; q < BK / 8; ++q) {
       if (q + 1 < BK / 8) WGRAD_READ_FRAGS(q + 1, (q + 1) & 1)
-      mfma_group<false>(fa[q & 1], fb[q & 1], acc);
+      mfma_group<false, 2>(fa[q & 1], fb[q & 1], acc);
     }
     if (NBUF == 1) {
       __syncthreads();
@@ -473,14 +488,29 @@ static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t m
   BL_CHECK_ARG(group_ptr == nullptr || G >= 1, "bl_gemm_rows: G must be >= 1 with group_ptr");
   BL_CHECK_ARG((uint64_t)M * (uint64_t)N < (1ull << 32) || drop.p <= 0.f, "bl_gemm_rows: dropout index space is 32 bit");
   const bl_drop_dev dd = bl_make_drop(drop);
-  dim3 grid((M + BM - 1) / BM + (group_ptr ? G : 0), (N + BN - 1) / BN);
+  static const int tbm = getenv("BL_GEMM_TBM") ? atoi(getenv("BL_GEMM_TBM")) : 128;
+  dim3 grid((M + tbm - 1) / tbm + (group_ptr ? G : 0), (N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
-#define ROWS_LAUNCH ROWS_ARGS(d), mask_arg, mask_ld, b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc
-#define ROWS_GO(NK_, ACT_, ...) hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, __VA_ARGS__, false>), grid, dim3(256), 0, st, ROWS_LAUNCH)
+  static const int probe = getenv("BL_CLK_PROBE") ? 1 : 0;
+  if (probe) {
+    unsigned long long init[4] = {~0ull, ~0ull, 0ull, 0ull};
+    hipMemcpyToSymbol(HIP_SYMBOL(bl_clk_probe), init, sizeof(init));
+  }
+#define ROWS_LAUNCH ROWS_ARGS(d), mask_arg, mask_ld, b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc, probe
+#define ROWS_GO(NK_, ACT_, ...)                                                                                     \
+  {                                                                                                                 \
+    if (tbm == 64)                                                                                                  \
+      hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, 32, 1, 4, false, 64>), grid, dim3(256), 0, st, ROWS_LAUNCH);   \
+    else                                                                                                            \
+      hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, __VA_ARGS__, false, 128>), grid, dim3(256), 0, st, ROWS_LAUNCH); \
+  }
   if (b_is_nk) {
     BL_CHECK_ARG(act == BL_ACT_NONE, "bl_gemm_rows: the transposed-B (input gradient) form takes no activation");
     if (mask_arg) {
-      hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, 32, 1, 2, true>), grid, dim3(256), 0, st, ROWS_LAUNCH);
+      if (tbm == 64)
+        hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, 32, 1, 4, true, 64>), grid, dim3(256), 0, st, ROWS_LAUNCH);
+      else
+        hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, 32, 1, 2, true, 128>), grid, dim3(256), 0, st, ROWS_LAUNCH);
     } else
     switch (gemm_variant()) {
       case 1: ROWS_GO(true, BL_ACT_NONE, 32, 1, 4); break;
@@ -511,6 +541,13 @@ static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t m
     }
   }
   BL_LAUNCH_CHECK("bl_gemm_rows");
+  if (probe) {
+    hipStreamSynchronize(st);
+    unsigned long long v[4];
+    hipMemcpyFromSymbol(v, HIP_SYMBOL(bl_clk_probe), sizeof(v));
+    const double wall_s = (double)(v[3] - v[1]) / 1e8;
+    fprintf(stderr, "[buglab_hip] clock probe: %.1f us, shader clock %.3f GHz\n", wall_s * 1e6, (double)(v[2] - v[0]) / wall_s / 1e9);
+  }
   return BL_OK;
 }
 

@@ -32,8 +32,16 @@ def _run_hip(module, mb_np, seed=None):
 
     mb = to_device(mb_np, "cuda")
     module.zero_grad(set_to_none=True)
+    # bind every .grad to a preallocated buffer like FlatAdam does: exercises the direct
+    # accumulation of weight gradients into param.grad on the free-running side stream
+    for i, p in enumerate(module.parameters()):
+        if i % 2 == 0:
+            p.grad = torch.zeros_like(p)
     loss = module(**mb, dropout_seed=seed)
     loss.backward()
+    from buglab.models import hip_ops
+
+    hip_ops.join_side_stream()
     torch.cuda.synchronize()
     return loss, mb
 
