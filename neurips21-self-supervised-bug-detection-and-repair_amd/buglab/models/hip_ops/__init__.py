@@ -171,7 +171,8 @@ class KernelTimer:
         read as exclusive kernel time (the enclosing "*_pair" span is the exclusive one)."""
         out = {}
         for kind, flop, e0, e1, overlapped in self.records:
-            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flop": 0.0, "overlapped": overlapped})
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flop": 0.0, "overlapped": False})
+            d["overlapped"] = d["overlapped"] or overlapped
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flop"] += flop

@@ -19,6 +19,8 @@ def init_from_env(device_type: str = "cuda") -> Tuple[int, int, torch.device]:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if device_type == "cuda":
+        if os.environ.get("BL_FORCE_DEVICE") is not None:  # testing only: several ranks on one GPU (needs gloo)
+            local = int(os.environ["BL_FORCE_DEVICE"])
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -27,7 +29,8 @@ def init_from_env(device_type: str = "cuda") -> Tuple[int, int, torch.device]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl" if device_type == "cuda" else "gloo", rank=rank, world_size=world)
+        backend = os.environ.get("BL_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, device
 
 
