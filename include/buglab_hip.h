@@ -89,6 +89,27 @@ int bl_gemm_rows_routed(const bl_rows_t* a, const int32_t* winner, int32_t ld_wi
                         int64_t b_group_stride, int32_t ldb, const int32_t* group_ptr, const int32_t* group_w, int32_t G,
                         int32_t M, int32_t N, int32_t K, float* c, int32_t ldc, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * fp32-accurate GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand is split once into
+ * three bf16 terms hi + mid + lo (bl_pack_bf16x3*: per row, per 8 consecutive k, 48 bytes
+ * [hi x8 | mid x8 | lo x8]) and a product is evaluated as the six MFMA terms hh + hm + mh + hl + lh + mm
+ * with fp32 accumulation; dropped terms are < 2^-26 of the product, below fp32's own rounding.
+ * Same contract as bl_gemm_rows with b_is_nk = 1 (B_g given as [N, K], i.e. C = A . B_g^T), no
+ * bias/activation epilogue; `winner` != NULL selects the routed left operand of bl_gemm_rows_routed.
+ * Source widths must be multiples of 32. */
+typedef struct {
+  const uint16_t* xp[3];  /* packed matrices (bl_pack_bf16x3) */
+  const int32_t* idx[3];  /* row gather index or NULL */
+  int32_t width[3];       /* k's taken from each source (the packed matrix's D) */
+  int32_t nsrc;
+} bl_rows_packed_t;
+int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, uint16_t* out, void* stream);
+/* w [G][K][N] fp32 -> out [G][N][K/8][3][8]: the [N, K] (transposed) packed form bl_gemm_rows_x6 takes as B */
+int bl_pack_bf16x3_transposed(const float* w, int32_t G, int32_t K, int32_t N, uint16_t* out, void* stream);
+int bl_gemm_rows_x6(const bl_rows_packed_t* a, const int32_t* winner, int32_t ld_winner, const uint16_t* bp,
+                    int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
+                    int32_t N, int32_t K, float* c, int32_t ldc, void* stream);
+
 /* Weight-gradient GEMM (reduction over rows, split across row chunks, fp32 atomics):
  *   gw[group_w[g]][0:K, 0:N] += rows(a)[rows of g, 0:K]^T . g_c[rows of g, 0:N]
  * gw must be zeroed (or hold the running gradient) by the caller.  autograd equivalent:

@@ -30,6 +30,10 @@ class bl_rows_t(Structure):
     _fields_ = [("x", c_void_p * 3), ("idx", c_void_p * 3), ("ld", c_int32 * 3), ("width", c_int32 * 3), ("nsrc", c_int32)]
 
 
+class bl_rows_packed_t(Structure):
+    _fields_ = [("xp", c_void_p * 3), ("idx", c_void_p * 3), ("width", c_int32 * 3), ("nsrc", c_int32)]
+
+
 class bl_dropout_t(Structure):
     _fields_ = [("p", c_float), ("seed", c_uint32), ("stream", c_uint32)]
 
@@ -41,6 +45,9 @@ _SIGNATURES = {
     "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows": ([POINTER(bl_rows_t), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_pack_bf16x3_transposed": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
@@ -219,6 +226,56 @@ def gemm_rows(sources, b, M, N, *, b_is_nk=False, b_group_stride=0, ldb=None, bi
                 out.stride(0), _stream()),
             "bl_gemm_rows")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32-accurate GEMM on the bf16 matrix cores (csrc/bl_gemm_x6.hip)
+GEMM_MODE = os.environ.get("BL_GEMM_MODE", "bf16x6")  # "bf16x6" | "fp32"
+
+
+def pack_bf16x3(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [R, D] -> packed int16 [R, 3 * D]: per 8 consecutive columns [hi x8 | mid x8 | lo x8]."""
+    _f32(x, "x")
+    R, D = x.shape
+    out = torch.empty((R, 3 * D), dtype=torch.int16, device=x.device)
+    _check(load_library().bl_pack_bf16x3(x.data_ptr(), x.stride(0), R, D, out.data_ptr(), _stream()), "bl_pack_bf16x3")
+    return out
+
+
+def pack_bf16x3_transposed(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [G, K, N] -> packed int16 [G, N, 3 * K] (the [N, K] operand form of gemm_rows_x6)."""
+    _f32(w, "w")
+    G, K, N = w.shape
+    out = torch.empty((G, N, 3 * K), dtype=torch.int16, device=w.device)
+    _check(load_library().bl_pack_bf16x3_transposed(w.data_ptr(), G, K, N, out.data_ptr(), _stream()), "bl_pack_bf16x3_transposed")
+    return out
+
+
+def gemm_rows_x6(sources, bp, M, N, *, b_group_stride=0, group_ptr=None, group_w=None, G=1, winner=None, kind="gemm_rows_x6"):
+    """sources: [(packed int16 [*, 3*width], row index or None, width)]; bp: packed [G, N, 3K] (or [N, 3K])."""
+    r = bl_rows_packed_t()
+    K = 0
+    for j, (xp, idx, width) in enumerate(sources):
+        _req(xp, torch.int16, f"packed source {j}")
+        r.xp[j] = xp.data_ptr()
+        r.idx[j] = _i32(idx).data_ptr() if idx is not None else None
+        r.width[j] = width
+        K += width
+    r.nsrc = len(sources)
+    out = torch.empty((M, N), dtype=torch.float32, device=bp.device)
+    if M == 0:
+        return out
+    with _timed(kind + ("_grouped" if group_ptr is not None else ""), 2.0 * M * N * K):
+        _check(
+            load_library().bl_gemm_rows_x6(ctypes.byref(r), _p(winner), winner.stride(0) if winner is not None else 0,
+                                           _req(bp, torch.int16, "bp").data_ptr(), int(b_group_stride), _p(group_ptr), _p(group_w),
+                                           int(G), int(M), int(N), int(K), out.data_ptr(), out.stride(0), _stream()),
+            "bl_gemm_rows_x6")
+    return out
+
+
+def x6_ok(*dims) -> bool:
+    return GEMM_MODE == "bf16x6" and all(d % 32 == 0 for d in dims)
 
 
 def gemm_rows_routed(g_node, node_of_row, winner, b, M, N, *, b_group_stride=0, ldb=None, group_ptr=None, group_w=None, G=1):
@@ -465,8 +522,15 @@ class _MpLayer(torch.autograd.Function):
         Dout = Wd.shape[1]
         E = g.num_messages
         assert K2 == 2 * Din and T == g.num_types and N == g.num_nodes
-        pre = gemm_rows([(h, g.msg_src), (h, g.msg_tgt)], _f32(W, "W"), E, Dm, b_group_stride=K2 * Dm, ldb=Dm,
-                        group_ptr=g.type_ptr, G=T)
+        if x6_ok(Din, Dm):
+            hp = pack_bf16x3(h)                   # [N, 3*Din]
+            wtp = pack_bf16x3_transposed(_f32(W, "W"))  # [T, Dm, 3*K2]
+            pre = gemm_rows_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din)], wtp, E, Dm, b_group_stride=Dm * 3 * K2,
+                               group_ptr=g.type_ptr, G=T)
+            del hp, wtp
+        else:
+            pre = gemm_rows([(h, g.msg_src), (h, g.msg_tgt)], _f32(W, "W"), E, Dm, b_group_stride=K2 * Dm, ldb=Dm,
+                            group_ptr=g.type_ptr, G=T)
         agg, arg, ln_out, mean, rstd, dact = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)),
                                                          want_dact=True)
         del pre
@@ -509,7 +573,12 @@ class _MpLayer(torch.autograd.Function):
             gemm_wgrad_routed([(h, g.msg_src), (h, g.msg_tgt)], gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K2 * Dm,
                               group_ptr=g.type_ptr, G=T)
         # node states: per-message input gradients, then segmented sums over the src / tgt CSRs
-        g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K2, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
+        if x6_ok(Din, Dm):
+            # d a = G . W_t^T: B_g = W_t itself as [n = 2*Din, k = Dm], row-packed
+            g_a = gemm_rows_x6([(pack_bf16x3(gq), g.msg_tgt, Dm)], pack_bf16x3(W.view(T * K2, Dm)), E, K2,
+                               b_group_stride=K2 * 3 * Dm, group_ptr=g.type_ptr, G=T, winner=arg, kind="gemm_rows_nk_routed_x6")
+        else:
+            g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K2, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
         g_h = torch.empty((N, Din), dtype=torch.float32, device=dev)
         _check(
             load_library().bl_mp_scatter_grad(g_a.data_ptr(), g_a.stride(0), g.src_ptr.data_ptr(), g.src_msgs.data_ptr(),

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
   __shared__ int rowidx[3][TBM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (probe && tid == 0 && blockIdx.x == 7 && blockIdx.y == 0) {
+  if (probe == 1 && tid == 0 && blockIdx.x == 7 && blockIdx.y == 0) {
     bl_clk_probe[0] = (unsigned long long)clock64();
     bl_clk_probe[1] = (unsigned long long)wall_clock64();
   }
@@ -260,7 +260,14 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
 #pragma unroll
     for (int q = 0; q < BK / 8; ++q) {
       if (q + 1 < BK / 8) ROWS_READ_FRAGS(q + 1, (q + 1) & 1)
-      mfma_group<true, TI>(fa[q & 1], fb[q & 1], acc);
+      if (probe != 2) {
+        mfma_group<true, TI>(fa[q & 1], fb[q & 1], acc);
+      } else {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) asm volatile("" ::"v"(fa[q & 1][ti][0]), "v"(fa[q & 1][ti][3]));
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) asm volatile("" ::"v"(fb[q & 1][tj][0]), "v"(fb[q & 1][tj][3]));
+      }
     }
     if (NBUF == 1) {
       __syncthreads();
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
         *reinterpret_cast<float4*>(crow + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
   }
-  if (probe && tid == 0 && blockIdx.x == 7 && blockIdx.y == 0) {
+  if (probe == 1 && tid == 0 && blockIdx.x == 7 && blockIdx.y == 0) {
     bl_clk_probe[2] = (unsigned long long)clock64();
     bl_clk_probe[3] = (unsigned long long)wall_clock64();
   }
@@ -491,8 +498,8 @@ static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t m
   static const int tbm = getenv("BL_GEMM_TBM") ? atoi(getenv("BL_GEMM_TBM")) : 128;
   dim3 grid((M + tbm - 1) / tbm + (group_ptr ? G : 0), (N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
-  static const int probe = getenv("BL_CLK_PROBE") ? 1 : 0;
-  if (probe) {
+  static const int probe = getenv("BL_CLK_PROBE") ? atoi(getenv("BL_CLK_PROBE")) : 0;
+  if (probe == 1) {
     unsigned long long init[4] = {~0ull, ~0ull, 0ull, 0ull};
     hipMemcpyToSymbol(HIP_SYMBOL(bl_clk_probe), init, sizeof(init));
   }
@@ -541,7 +548,7 @@ static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t m
     }
   }
   BL_LAUNCH_CHECK("bl_gemm_rows");
-  if (probe) {
+  if (probe == 1) {
     hipStreamSynchronize(st);
     unsigned long long v[4];
     hipMemcpyFromSymbol(v, HIP_SYMBOL(bl_clk_probe), sizeof(v));

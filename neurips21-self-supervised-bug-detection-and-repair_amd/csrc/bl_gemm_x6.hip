@@ -1,0 +1,342 @@
+// fp32-accurate GEMMs on the bf16 matrix cores ("bf16x6").
+//
+// The exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 MFMA rate, and at the
+// ~1.9 GHz the chip sustains under this load the message / input-gradient GEMMs are pinned at
+// 85-110 TF/s.  Here every fp32 operand x is split ONCE into three bf16 terms
+//      x = hi + mid + lo  (+ r, |r| <= 2^-27 |x|),   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)
+// and a product a*b is evaluated as the six bf16 x bf16 MFMA terms
+//      a_h b_h + a_h b_m + a_m b_h + a_h b_l + a_l b_h + a_m b_m          (fp32 accumulate),
+// dropping only terms below 2^-26 |ab| -- smaller than fp32's own rounding unit (2^-24): results
+// are fp32-equivalent (the parity tests keep the same 1e-4 bound and pass with ~1e-6).  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each)
+// per 16 k's: 2.67x fewer matrix-pipe cycles.
+//
+// Packed operand layout ("bf16x3 packed", produced by bl_pack_bf16x3*): for every row and every
+// group of 8 consecutive k:  [hi x8 | mid x8 | lo x8]  = 48 contiguous bytes.  One 32-k stage of a
+// row is 192 contiguous bytes in HBM and in LDS (row stride 208 B: b128 reads/writes conflict-free),
+// and an MFMA fragment (8 k's of one row) is three consecutive ds_read_b128.
+//
+// Kernel shape is the fp32 one's (csrc/bl_gemm.hip): 128 x 128 tile, 4 waves 2 x 2, transposed
+// accumulators -> float4 epilogue stores, wave-cooperative group lookup, optional routed
+// (winner-masked) left operand for the input-gradient GEMM.
+#include "bl_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define XBM 128
+#define XBN 128
+#define XROW 13  // uint4 per LDS row: 4 k-groups x 3 planes + 1 pad
+
+__device__ __forceinline__ uint16_t f2bf_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  h = f2bf_rne(x);
+  const float r1 = x - bf2f(h);  // exact
+  m = f2bf_rne(r1);
+  const float r2 = r1 - bf2f(m);  // exact
+  l = f2bf_rne(r2);
+}
+
+// ---- packing ------------------------------------------------------------------------------------
+// rows: out[r][kg][plane][j] = plane(x[r, 8 kg + j])
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ x, int ld, long long R, int D,
+                                                        uint4* __restrict__ out) {
+  const int kgn = D >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= R * kgn) return;
+  const long long r = t / kgn;
+  const int kg = (int)(t % kgn);
+  const float4 a = *reinterpret_cast<const float4*>(x + r * ld + 8 * kg);
+  const float4 b = *reinterpret_cast<const float4*>(x + r * ld + 8 * kg + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint16_t h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
+  uint4* o = out + t * 3;
+#define PK(a_, b_) ((uint32_t)(a_) | ((uint32_t)(b_) << 16))
+  o[0] = make_uint4(PK(h[0], h[1]), PK(h[2], h[3]), PK(h[4], h[5]), PK(h[6], h[7]));
+  o[1] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
+  o[2] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
+}
+
+// transposed weights: w [G][K][N] fp32 -> out[g][n][kg][plane][j] = plane(w[g][8 kg + j][n])
+__global__ __launch_bounds__(256) void pack_transposed_kernel(const float* __restrict__ w, int G, int K, int N,
+                                                              uint4* __restrict__ out) {
+  const int kgn = K >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)G * N * kgn) return;
+  // consecutive threads -> consecutive n (coalesced reads of the fp32 rows)
+  const int n = (int)(t % N);
+  const int kg = (int)((t / N) % kgn);
+  const int g = (int)(t / ((long long)N * kgn));
+  uint16_t h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3(w[((size_t)g * K + 8 * kg + j) * N + n], h[j], m[j], l[j]);
+  uint4* o = out + (((size_t)g * N + n) * kgn + kg) * 3;
+  o[0] = make_uint4(PK(h[0], h[1]), PK(h[2], h[3]), PK(h[4], h[5]), PK(h[6], h[7]));
+  o[1] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
+  o[2] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
+}
+
+// ---- GEMM -----------------------------------------------------------------------------------------
+__device__ __forceinline__ bool x6_find_piece(const int* __restrict__ group_ptr, int G, int M, int piece, int t,
+                                              int& g, int& row0, int& nrows) {
+  if (group_ptr == nullptr) {
+    g = 0;
+    row0 = t * piece;
+    if (row0 >= M) return false;
+    nrows = min(piece, M - row0);
+    return true;
+  }
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  for (int g0 = 0; g0 < G; g0 += 64) {
+    const int gi = g0 + lane;
+    const int lo = gi < G ? group_ptr[gi] : 0;
+    const int hi = gi < G ? group_ptr[gi + 1] : 0;
+    const int nt = (hi - lo + piece - 1) / piece;
+    int incl = nt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    const int excl = base + incl - nt;
+    const unsigned long long hit = __ballot(t >= excl && t < excl + nt);
+    if (hit) {
+      const int src = __ffsll((long long)hit) - 1;
+      g = g0 + src;
+      const int lo_s = __shfl(lo, src, 64), hi_s = __shfl(hi, src, 64), ex_s = __shfl(excl, src, 64);
+      row0 = lo_s + (t - ex_s) * piece;
+      nrows = min(piece, hi_s - row0);
+      return true;
+    }
+    base += __shfl(incl, 63, 64);
+  }
+  return false;
+}
+
+__device__ __forceinline__ uint32_t mask_pair(int w0, int w1, int rid) {
+  return (w0 == rid ? 0x0000FFFFu : 0u) | (w1 == rid ? 0xFFFF0000u : 0u);
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
+    const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
+    const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
+    int koff1, int koff2, int nsrc, const int* __restrict__ mask_arg, int mask_ld, const uint4* __restrict__ bp,
+    long long strideB, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G, int M, int N, int K,
+    float* __restrict__ c, int ldc) {
+  __shared__ uint4 As[XBM * XROW];
+  __shared__ uint4 Bs[XBN * XROW];
+  __shared__ int rowidx[3][XBM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int g, row0, nrows;
+  if (!x6_find_piece(group_ptr, G, M, XBM, blockIdx.x, g, row0, nrows)) return;
+  const int n0 = blockIdx.y * XBN;
+  const int wsel = group_w ? group_w[g] : g;
+  const uint4* __restrict__ Bg = bp + (long long)wsel * strideB;  // [N][K/8][3] uint4
+  const int kgK = K >> 3;                                          // k-groups per B row
+
+  if (tid < XBM) {
+    const int r = row0 + min(tid, nrows - 1);
+    rowidx[0][tid] = idx0 ? idx0[r] : r;
+    if (nsrc > 1) rowidx[1][tid] = idx1 ? idx1[r] : r;
+    if (nsrc > 2) rowidx[2][tid] = idx2 ? idx2[r] : r;
+  }
+  __syncthreads();
+
+  // loader mapping: (row, k-group) pairs, 2 per thread; 4 consecutive lanes cover one row's 192 bytes
+  const int p_kg = tid & 3, p_row0 = tid >> 2;  // rows p_row0 and p_row0 + 64
+  uint4 ra[2][3], rb[2][3];
+  int4 ma[MASKED ? 2 : 1][2];
+  const int nk = (K + 31) / 32;
+
+#define X6_LOAD_STAGE(k0_)                                                                                    \
+  {                                                                                                           \
+    const int k_ = (k0_) + 8 * p_kg;                                                                          \
+    const int kc_ = k_ < K ? k_ : 0;                                                                          \
+    int j_ = 0;                                                                                               \
+    if (nsrc > 1 && kc_ >= koff1) j_ = 1;                                                                     \
+    if (nsrc > 2 && kc_ >= koff2) j_ = 2;                                                                     \
+    const int kl_ = kc_ - (j_ == 0 ? 0 : (j_ == 1 ? koff1 : koff2));                                          \
+    const uint4* base_ = j_ == 0 ? xp0 : (j_ == 1 ? xp1 : xp2);                                               \
+    const int wj_ = j_ == 0 ? w0 : (j_ == 1 ? w1 : w2);                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
+      const int row_ = p_row0 + 64 * i;                                                                       \
+      const uint4* src_ = base_ + ((size_t)rowidx[j_][row_] * (wj_ >> 3) + (kl_ >> 3)) * 3;                   \
+      ra[i][0] = src_[0];                                                                                     \
+      ra[i][1] = src_[1];                                                                                     \
+      ra[i][2] = src_[2];                                                                                     \
+      if (MASKED) {                                                                                           \
+        const int4* m_ = reinterpret_cast<const int4*>(mask_arg + (size_t)rowidx[0][row_] * mask_ld + kc_);   \
+        ma[i][0] = m_[0];                                                                                     \
+        ma[i][1] = m_[1];                                                                                     \
+      }                                                                                                       \
+      const int n_ = n0 + row_;                                                                               \
+      const uint4* bsrc_ = Bg + ((size_t)(n_ < N ? n_ : 0) * kgK + (kc_ >> 3)) * 3;                           \
+      rb[i][0] = bsrc_[0];                                                                                    \
+      rb[i][1] = bsrc_[1];                                                                                    \
+      rb[i][2] = bsrc_[2];                                                                                    \
+    }                                                                                                         \
+  }
+#define X6_STORE_STAGE(k0_)                                                                                   \
+  {                                                                                                           \
+    const bool kok_ = (k0_) + 8 * p_kg < K;                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
+      const int row_ = p_row0 + 64 * i;                                                                       \
+      uint4 keep_ = make_uint4(~0u, ~0u, ~0u, ~0u);                                                           \
+      if (MASKED) {                                                                                           \
+        const int rid_ = row0 + row_;                                                                         \
+        keep_.x = mask_pair(ma[i][0].x, ma[i][0].y, rid_);                                                    \
+        keep_.y = mask_pair(ma[i][0].z, ma[i][0].w, rid_);                                                    \
+        keep_.z = mask_pair(ma[i][1].x, ma[i][1].y, rid_);                                                    \
+        keep_.w = mask_pair(ma[i][1].z, ma[i][1].w, rid_);                                                    \
+      }                                                                                                       \
+      if (!kok_) keep_ = make_uint4(0u, 0u, 0u, 0u);                                                          \
+      const bool nok_ = kok_ && (n0 + row_ < N);                                                              \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                         \
+        uint4 a_ = ra[i][p];                                                                                  \
+        a_.x &= keep_.x; a_.y &= keep_.y; a_.z &= keep_.z; a_.w &= keep_.w;                                   \
+        As[row_ * XROW + p_kg * 3 + p] = a_;                                                                  \
+        Bs[row_ * XROW + p_kg * 3 + p] = nok_ ? rb[i][p] : make_uint4(0u, 0u, 0u, 0u);                        \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, half = lane >> 5;
+
+  X6_LOAD_STAGE(0)
+  X6_STORE_STAGE(0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) X6_LOAD_STAGE((kt + 1) * 32)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {  // two 16-k MFMA steps per stage; this lane's 8 k's = group 2s + half
+      const int kg = 2 * s + half;
+      bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        const uint4* p = &As[(wm * 64 + ti * 32 + li) * XROW + kg * 3];
+        ah[ti] = __builtin_bit_cast(bf16x8, p[0]);
+        am[ti] = __builtin_bit_cast(bf16x8, p[1]);
+        al[ti] = __builtin_bit_cast(bf16x8, p[2]);
+      }
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const uint4* p = &Bs[(wn * 64 + tj * 32 + li) * XROW + kg * 3];
+        bh[tj] = __builtin_bit_cast(bf16x8, p[0]);
+        bm[tj] = __builtin_bit_cast(bf16x8, p[1]);
+        bl[tj] = __builtin_bit_cast(bf16x8, p[2]);
+      }
+      // swapped operands (B fragment in the A slot): the accumulator holds the transposed tile, so
+      // a lane owns 4 consecutive columns of one row -> float4 epilogue stores.  Small terms first.
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          f32x16 a = acc[ti][tj];
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[tj], am[ti], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[tj], ah[ti], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], al[ti], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[tj], ah[ti], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], am[ti], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], ah[ti], a, 0, 0, 0);
+          acc[ti][tj] = a;
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      X6_STORE_STAGE((kt + 1) * 32)
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const int m = wm * 64 + ti * 32 + li;
+    if (m >= nrows) continue;
+    float* __restrict__ crow = c + (size_t)(row0 + m) * ldc;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = n0 + wn * 64 + tj * 32 + 8 * gq + 4 * half;
+        if (n >= N) continue;
+        *reinterpret_cast<float4*>(crow + n) =
+            make_float4(acc[ti][tj][4 * gq + 0], acc[ti][tj][4 * gq + 1], acc[ti][tj][4 * gq + 2], acc[ti][tj][4 * gq + 3]);
+      }
+  }
+}
+
+// ================================================================================================
+extern "C" int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, uint16_t* out, void* stream) {
+  if (R == 0) return BL_OK;
+  BL_CHECK_ARG(x && out && bl_aligned16(x) && bl_aligned16(out), "bl_pack_bf16x3: null or misaligned pointer");
+  BL_CHECK_ARG(D > 0 && D % 8 == 0 && ld % 4 == 0, "bl_pack_bf16x3: D must be a multiple of 8 (got %d)", D);
+  const long long total = (long long)R * (D / 8);
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld,
+                     (long long)R, D, reinterpret_cast<uint4*>(out));
+  BL_LAUNCH_CHECK("bl_pack_bf16x3");
+  return BL_OK;
+}
+
+extern "C" int bl_pack_bf16x3_transposed(const float* w, int32_t G, int32_t K, int32_t N, uint16_t* out, void* stream) {
+  if (G == 0) return BL_OK;
+  BL_CHECK_ARG(w && out && bl_aligned16(out), "bl_pack_bf16x3_transposed: null or misaligned pointer");
+  BL_CHECK_ARG(K > 0 && K % 8 == 0 && N > 0, "bl_pack_bf16x3_transposed: K must be a multiple of 8");
+  const long long total = (long long)G * N * (K / 8);
+  hipLaunchKernelGGL(pack_transposed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, G,
+                     K, N, reinterpret_cast<uint4*>(out));
+  BL_LAUNCH_CHECK("bl_pack_bf16x3_transposed");
+  return BL_OK;
+}
+
+extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const int32_t* winner, int32_t ld_winner, const uint16_t* bp,
+                               int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G,
+                               int32_t M, int32_t N, int32_t K, float* c, int32_t ldc, void* stream) {
+  if (M == 0) return BL_OK;
+  BL_CHECK_ARG(a && a->nsrc >= 1 && a->nsrc <= 3, "bl_gemm_rows_x6: rows descriptor needs 1..3 sources");
+  int off = 0, koff[3] = {0, 0, 0};
+  for (int j = 0; j < a->nsrc; ++j) {
+    BL_CHECK_ARG(a->xp[j] && bl_aligned16(a->xp[j]) && a->width[j] > 0 && a->width[j] % 32 == 0,
+                 "bl_gemm_rows_x6: source %d: packed pointer 16-byte aligned and width a multiple of 32 required", j);
+    koff[j] = off;
+    off += a->width[j];
+  }
+  BL_CHECK_ARG(off == K, "bl_gemm_rows_x6: K (%d) != sum of source widths (%d)", K, off);
+  BL_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0 && bp && c && bl_aligned16(bp) && bl_aligned16(c),
+               "bl_gemm_rows_x6: N/ldc multiples of 4, aligned pointers required");
+  BL_CHECK_ARG(b_group_stride % 8 == 0, "bl_gemm_rows_x6: packed group stride must be a multiple of 8 elements");
+  BL_CHECK_ARG(winner == nullptr || (a->nsrc == 1 && a->idx[0] && ld_winner % 4 == 0),
+               "bl_gemm_rows_x6: the routed form needs exactly one gathered source");
+  dim3 grid((M + XBM - 1) / XBM + (group_ptr ? G : 0), (N + XBN - 1) / XBN);
+  const uint4* x0 = reinterpret_cast<const uint4*>(a->xp[0]);
+  const uint4* x1 = a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr;
+  const uint4* x2 = a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr;
+#define X6_ARGS                                                                                                          \
+  x0, x1, x2, a->idx[0], a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],              \
+      a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc, winner, ld_winner,        \
+      reinterpret_cast<const uint4*>(bp), (long long)(b_group_stride / 8), group_ptr, group_w, G, M, N, K, c, ldc
+  if (winner)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  BL_LAUNCH_CHECK("bl_gemm_rows_x6");
+  return BL_OK;
+}

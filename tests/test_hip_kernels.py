@@ -272,3 +272,32 @@ def test_flat_adam_matches_oracle(ops):
         O.adam_clip_step(ref_p, grads, m, v, step, lr=1e-2, clip=0.5, warmup=3)
         for i, p in enumerate(ps):
             assert (p.detach().cpu() - ref_p[i]).abs().max() < 2e-6, (step, i)
+
+
+@pytest.mark.parametrize("Din,Dm,sizes", [(64, 96, [130, 0, 1, 257, 64]), (32, 128, [5, 300]), (128, 256, [129, 128, 127])])
+def test_gemm_rows_bf16x6_is_fp32_accurate(ops, Din, Dm, sizes):
+    """fp32-accurate GEMM on the bf16 matrix cores: split hi/mid/lo + six MFMA terms.  The error vs an
+    fp64 reference must be in the same class as the exact-fp32 MFMA kernel's (K <= 256: < 2e-5 abs on
+    O(1) results; typically ~1e-6)."""
+    rng = np.random.default_rng(0)
+    N, T, E = 211, len(sizes), int(sum(sizes))
+    h = torch.randn(N, Din)
+    W = torch.randn(T, 2 * Din, Dm) / math.sqrt(2 * Din)
+    src, tgt = rng.integers(0, N, E).astype(np.int32), rng.integers(0, N, E).astype(np.int32)
+    ptr = _groups(rng, sizes)
+    ref = torch.zeros(E, Dm, dtype=torch.float64)
+    for t in range(T):
+        lo, hi = ptr[t], ptr[t + 1]
+        ref[lo:hi] = torch.cat([h[src[lo:hi]], h[tgt[lo:hi]]], -1).double() @ W[t].double()
+    # the packing itself: hi + mid + lo reproduces the fp32 value to ~2^-25
+    hp = ops.pack_bf16x3(_dev(h))
+    planes = hp.cpu().view(N, Din // 8, 3, 8).to(torch.int32).bitwise_and(0xFFFF)
+    vals = (planes << 16).view(torch.float32) if False else torch.from_numpy((planes.numpy().astype(np.uint32) << 16).view(np.float32))
+    recon = vals[:, :, 0, :] .double() + vals[:, :, 1, :].double() + vals[:, :, 2, :].double()
+    assert (recon.reshape(N, Din) - h.double()).abs().max() <= 2.0 ** -24 * float(h.abs().max())
+    out = ops.gemm_rows_x6([(hp, _dev(src), Din), (hp, _dev(tgt), Din)], ops.pack_bf16x3_transposed(_dev(W)), E, Dm,
+                           b_group_stride=Dm * 3 * 2 * Din, group_ptr=_dev(ptr), G=T)
+    err = (out.cpu().double() - ref).abs().max()
+    exact = ops.gemm_rows([(_dev(h), _dev(src)), (_dev(h), _dev(tgt))], _dev(W), E, Dm, b_group_stride=2 * Din * Dm, ldb=Dm, group_ptr=_dev(ptr), G=T)
+    err32 = (exact.cpu().double() - ref).abs().max()
+    assert err < 2e-5 and err < 4 * err32 + 1e-6, (float(err), float(err32))

@@ -45,6 +45,14 @@ def main():
         "nk": lambda: ops.gemm_rows([(G, None)], W, E, 2 * Din, b_is_nk=True, b_group_stride=2 * Din * Dm, ldb=Dm, group_ptr=ptr, G=T, out=ga),
         "wgrad": lambda: ops.gemm_wgrad([(h, src), (h, tgt)], G, E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T),
     }
+    hp, wtp, wp = ops.pack_bf16x3(h), ops.pack_bf16x3_transposed(W), ops.pack_bf16x3(W.view(T * 2 * Din, Dm))
+    gq = torch.randn(N, Dm, device="cuda")
+    gqp = ops.pack_bf16x3(gq)
+    arg = torch.randint(0, E, (N, Dm), device="cuda", dtype=torch.int32)
+    fns["fwd_x6"] = lambda: ops.gemm_rows_x6([(hp, src, Din), (hp, tgt, Din)], wtp, E, Dm, b_group_stride=Dm * 6 * Din, group_ptr=ptr, G=T)
+    fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, b_group_stride=2 * Din * 3 * Dm, group_ptr=ptr, G=T, winner=arg)
+    fns["pack_h"] = lambda: ops.pack_bf16x3(h)
+    fns["pack_wt"] = lambda: ops.pack_bf16x3_transposed(W)
     for name in a.which.split(","):
         f = fns[name]
         for _ in range(2):
