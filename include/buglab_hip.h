@@ -91,8 +91,8 @@ int bl_gemm_rows_routed(const bl_rows_t* a, const int32_t* winner, int32_t ld_wi
 
 /* ---------------------------------------------------------------------------------------------
  * fp32-accurate GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand is split once into
- * three bf16 terms hi + mid + lo (bl_pack_bf16x3*: per row, per 8 consecutive k, 48 bytes
- * [hi x8 | mid x8 | lo x8]) and a product is evaluated as the six MFMA terms hh + hm + mh + hl + lh + mm
+ * three bf16 terms hi + mid + lo (bl_pack_bf16x3*: every row is three bf16 planes back to
+ * back, [hi x D | mid x D | lo x D]) and a product is evaluated as the six MFMA terms hh + hm + mh + hl + lh + mm
  * with fp32 accumulation; dropped terms are < 2^-26 of the product, below fp32's own rounding.
  * Same contract as bl_gemm_rows with b_is_nk = 1 (B_g given as [N, K], i.e. C = A . B_g^T), no
  * bias/activation epilogue; `winner` != NULL selects the routed left operand of bl_gemm_rows_routed.
@@ -104,11 +104,18 @@ typedef struct {
   int32_t nsrc;
 } bl_rows_packed_t;
 int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, uint16_t* out, void* stream);
-/* w [G][K][N] fp32 -> out [G][N][K/8][3][8]: the [N, K] (transposed) packed form bl_gemm_rows_x6 takes as B */
+/* w [G][K][N] fp32 -> out [G][N][3][K]: the [N, K] (transposed) packed form bl_gemm_rows_x6 takes as B */
 int bl_pack_bf16x3_transposed(const float* w, int32_t G, int32_t K, int32_t N, uint16_t* out, void* stream);
 int bl_gemm_rows_x6(const bl_rows_packed_t* a, const int32_t* winner, int32_t ld_winner, const uint16_t* bp,
                     int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
                     int32_t N, int32_t K, float* c, int32_t ldc, void* stream);
+/* bf16x6 form of bl_gemm_wgrad_routed (below): `a` packed rows, g_node_packed = bl_pack_bf16x3 of the
+ * node gradient [*, N]; the message-major operands are transposed on the fly by gfx950's transposing
+ * LDS read (ds_read_b64_tr_b16).  N and the source widths must be multiples of 32. */
+int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_packed, const int32_t* g_idx,
+                            const int32_t* winner, int32_t ld_winner, const int32_t* group_ptr, const int32_t* group_w,
+                            int32_t G, int32_t M, int32_t N, int32_t K, float* gw, int64_t gw_group_stride, int32_t ld_gw,
+                            void* stream);
 
 /* Weight-gradient GEMM (reduction over rows, split across row chunks, fp32 atomics):
  *   gw[group_w[g]][0:K, 0:N] += rows(a)[rows of g, 0:K]^T . g_c[rows of g, 0:N]

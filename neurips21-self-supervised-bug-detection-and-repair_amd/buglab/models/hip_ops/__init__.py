@@ -48,6 +48,7 @@ _SIGNATURES = {
     "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_pack_bf16x3_transposed": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gemm_wgrad_routed_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
@@ -231,10 +232,11 @@ def gemm_rows(sources, b, M, N, *, b_is_nk=False, b_group_stride=0, ldb=None, bi
 # ------------------------------------------------------------------------------------------------
 # fp32-accurate GEMM on the bf16 matrix cores (csrc/bl_gemm_x6.hip)
 GEMM_MODE = os.environ.get("BL_GEMM_MODE", "bf16x6")  # "bf16x6" | "fp32"
+WGRAD_X6 = os.environ.get("BL_WGRAD_X6", "1") != "0"   # bf16x6 weight gradient of the message layers
 
 
 def pack_bf16x3(x: torch.Tensor) -> torch.Tensor:
-    """fp32 [R, D] -> packed int16 [R, 3 * D]: per 8 consecutive columns [hi x8 | mid x8 | lo x8]."""
+    """fp32 [R, D] -> packed int16 [R, 3 * D]: per row the three bf16 planes [hi x D | mid x D | lo x D]."""
     _f32(x, "x")
     R, D = x.shape
     out = torch.empty((R, 3 * D), dtype=torch.int16, device=x.device)
@@ -272,6 +274,34 @@ def gemm_rows_x6(sources, bp, M, N, *, b_group_stride=0, group_ptr=None, group_w
                                            int(G), int(M), int(N), int(K), out.data_ptr(), out.stride(0), _stream()),
             "bl_gemm_rows_x6")
     return out
+
+
+def _rows_packed(sources):
+    r = bl_rows_packed_t()
+    K = 0
+    for j, (xp, idx, width) in enumerate(sources):
+        _req(xp, torch.int16, f"packed source {j}")
+        r.xp[j] = xp.data_ptr()
+        r.idx[j] = _i32(idx).data_ptr() if idx is not None else None
+        r.width[j] = width
+        K += width
+    r.nsrc = len(sources)
+    return r, K
+
+
+def gemm_wgrad_routed_x6(sources, g_node_packed, node_of_row, winner, M, N, gw, *, gw_group_stride=0, group_ptr=None, group_w=None, G=1):
+    """bf16x6 weight gradient of the routed (max-aggregated) messages; accumulates into gw."""
+    rows, K = _rows_packed(sources)
+    if M == 0:
+        return gw
+    with _timed("gemm_wgrad_routed_x6", 2.0 * M * N * K):
+        _check(
+            load_library().bl_gemm_wgrad_routed_x6(ctypes.byref(rows), _req(g_node_packed, torch.int16, "g_node_packed").data_ptr(),
+                                                   _i32(node_of_row).data_ptr(), _i32(winner).data_ptr(), winner.stride(0),
+                                                   _p(group_ptr), _p(group_w), int(G), int(M), int(N), int(K),
+                                                   _f32(gw).data_ptr(), int(gw_group_stride), int(gw.shape[-1]), _stream()),
+            "bl_gemm_wgrad_routed_x6")
+    return gw
 
 
 def x6_ok(*dims) -> bool:
@@ -527,8 +557,11 @@ class _MpLayer(torch.autograd.Function):
             wtp = pack_bf16x3_transposed(_f32(W, "W"))  # [T, Dm, 3*K2]
             pre = gemm_rows_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din)], wtp, E, Dm, b_group_stride=Dm * 3 * K2,
                                group_ptr=g.type_ptr, G=T)
-            del hp, wtp
+            del wtp
+            if not WGRAD_X6:
+                hp = None
         else:
+            hp = None
             pre = gemm_rows([(h, g.msg_src), (h, g.msg_tgt)], _f32(W, "W"), E, Dm, b_group_stride=K2 * Dm, ldb=Dm,
                             group_ptr=g.type_ptr, G=T)
         agg, arg, ln_out, mean, rstd, dact = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)),
@@ -537,12 +570,12 @@ class _MpLayer(torch.autograd.Function):
         if msg_act == ACT_NONE:
             dact = None  # derivative is identically 1
         out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
-        ctx.saved = (h, W, ln_g, Wd, dact, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop)
+        ctx.saved = (h, hp, W, ln_g, Wd, dact, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        h, W, ln_g, Wd, dact, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
+        h, hp, W, ln_g, Wd, dact, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
         ctx.saved = None
         N, Din = h.shape
         T, K2, Dm = W.shape
@@ -568,14 +601,19 @@ class _MpLayer(torch.autograd.Function):
         # per-edge-type weights; message m's gradient row = gq[tgt(m)] masked to the channels m won
         pair = _timed("mp_bwd_gemm_pair(wgrad||dgrad+node-sums)", 2.0 * (2.0 * E * K2 * Dm), span=True)
         pair.__enter__()
+        gqp = pack_bf16x3(gq) if x6_ok(Din, Dm) else None
         side2 = _on_side_stream(dev)
         with side2:
-            gemm_wgrad_routed([(h, g.msg_src), (h, g.msg_tgt)], gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K2 * Dm,
-                              group_ptr=g.type_ptr, G=T)
+            if hp is not None:
+                gemm_wgrad_routed_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din)], gqp, g.msg_tgt, arg, E, Dm, g_W,
+                                     gw_group_stride=K2 * Dm, group_ptr=g.type_ptr, G=T)
+            else:
+                gemm_wgrad_routed([(h, g.msg_src), (h, g.msg_tgt)], gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K2 * Dm,
+                                  group_ptr=g.type_ptr, G=T)
         # node states: per-message input gradients, then segmented sums over the src / tgt CSRs
-        if x6_ok(Din, Dm):
+        if gqp is not None:
             # d a = G . W_t^T: B_g = W_t itself as [n = 2*Din, k = Dm], row-packed
-            g_a = gemm_rows_x6([(pack_bf16x3(gq), g.msg_tgt, Dm)], pack_bf16x3(W.view(T * K2, Dm)), E, K2,
+            g_a = gemm_rows_x6([(gqp, g.msg_tgt, Dm)], pack_bf16x3(W.view(T * K2, Dm)), E, K2,
                                b_group_stride=K2 * 3 * Dm, group_ptr=g.type_ptr, G=T, winner=arg, kind="gemm_rows_nk_routed_x6")
         else:
             g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K2, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
@@ -589,7 +627,7 @@ class _MpLayer(torch.autograd.Function):
             # gradients land in param.grad behind the main chain; joined by join_side_stream()
             global _free_running
             _free_running = True
-            side2.detach(h, gq, arg)
+            side2.detach(h, gq, arg, hp, gqp)
             side1.detach(ln_out, g_z)
             return g_h, None, g_lng, g_lnb, None, g_bd, None, None, None
         side2.join()

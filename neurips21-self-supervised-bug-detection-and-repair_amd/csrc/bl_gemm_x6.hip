@@ -11,14 +11,19 @@
 // v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each)
 // per 16 k's: 2.67x fewer matrix-pipe cycles.
 //
-// Packed operand layout ("bf16x3 packed", produced by bl_pack_bf16x3*): for every row and every
-// group of 8 consecutive k:  [hi x8 | mid x8 | lo x8]  = 48 contiguous bytes.  One 32-k stage of a
-// row is 192 contiguous bytes in HBM and in LDS (row stride 208 B: b128 reads/writes conflict-free),
-// and an MFMA fragment (8 k's of one row) is three consecutive ds_read_b128.
+// Packed operand layout ("bf16x3 packed", produced by bl_pack_bf16x3*): every row is three bf16
+// planes back to back, [hi x D | mid x D | lo x D] (6 D bytes): a row's plane is contiguous, which
+// is what both the k-contiguous loads of this file's row GEMM (64 B per row, plane and 32-k stage)
+// and the feature-contiguous loads of the weight-gradient GEMM want.  In LDS a stage row of the row
+// GEMM is [k-group][plane][8] (row stride 208 B: b128 reads/writes conflict-free), so an MFMA
+// fragment (8 k's of one row) is three consecutive ds_read_b128.
 //
 // Kernel shape is the fp32 one's (csrc/bl_gemm.hip): 128 x 128 tile, 4 waves 2 x 2, transposed
 // accumulators -> float4 epilogue stores, wave-cooperative group lookup, optional routed
 // (winner-masked) left operand for the input-gradient GEMM.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "bl_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,11 +63,11 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
   uint16_t h[8], m[8], l[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
-  uint4* o = out + t * 3;
+  uint4* o = out + r * 3 * kgn + kg;
 #define PK(a_, b_) ((uint32_t)(a_) | ((uint32_t)(b_) << 16))
   o[0] = make_uint4(PK(h[0], h[1]), PK(h[2], h[3]), PK(h[4], h[5]), PK(h[6], h[7]));
-  o[1] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
-  o[2] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
+  o[kgn] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
+  o[2 * kgn] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
 }
 
 // transposed weights: w [G][K][N] fp32 -> out[g][n][kg][plane][j] = plane(w[g][8 kg + j][n])
@@ -78,10 +83,10 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const float* __res
   uint16_t h[8], m[8], l[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) split3(w[((size_t)g * K + 8 * kg + j) * N + n], h[j], m[j], l[j]);
-  uint4* o = out + (((size_t)g * N + n) * kgn + kg) * 3;
+  uint4* o = out + ((size_t)g * N + n) * 3 * kgn + kg;
   o[0] = make_uint4(PK(h[0], h[1]), PK(h[2], h[3]), PK(h[4], h[5]), PK(h[6], h[7]));
-  o[1] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
-  o[2] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
+  o[kgn] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
+  o[2 * kgn] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
 }
 
 // ---- GEMM -----------------------------------------------------------------------------------------
@@ -171,20 +176,20 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
     const int wj_ = j_ == 0 ? w0 : (j_ == 1 ? w1 : w2);                                                       \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
       const int row_ = p_row0 + 64 * i;                                                                       \
-      const uint4* src_ = base_ + ((size_t)rowidx[j_][row_] * (wj_ >> 3) + (kl_ >> 3)) * 3;                   \
+      const uint4* src_ = base_ + (size_t)rowidx[j_][row_] * 3 * (wj_ >> 3) + (kl_ >> 3);                     \
       ra[i][0] = src_[0];                                                                                     \
-      ra[i][1] = src_[1];                                                                                     \
-      ra[i][2] = src_[2];                                                                                     \
+      ra[i][1] = src_[wj_ >> 3];                                                                              \
+      ra[i][2] = src_[2 * (wj_ >> 3)];                                                                        \
       if (MASKED) {                                                                                           \
         const int4* m_ = reinterpret_cast<const int4*>(mask_arg + (size_t)rowidx[0][row_] * mask_ld + kc_);   \
         ma[i][0] = m_[0];                                                                                     \
         ma[i][1] = m_[1];                                                                                     \
       }                                                                                                       \
       const int n_ = n0 + row_;                                                                               \
-      const uint4* bsrc_ = Bg + ((size_t)(n_ < N ? n_ : 0) * kgK + (kc_ >> 3)) * 3;                           \
+      const uint4* bsrc_ = Bg + (size_t)(n_ < N ? n_ : 0) * 3 * kgK + (kc_ >> 3);                             \
       rb[i][0] = bsrc_[0];                                                                                    \
-      rb[i][1] = bsrc_[1];                                                                                    \
-      rb[i][2] = bsrc_[2];                                                                                    \
+      rb[i][1] = bsrc_[kgK];                                                                                  \
+      rb[i][2] = bsrc_[2 * kgK];                                                                              \
     }                                                                                                         \
   }
 #define X6_STORE_STAGE(k0_)                                                                                   \
@@ -284,6 +289,175 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
   }
 }
 
+// ---- weight-gradient GEMM -------------------------------------------------------------------------
+// gW_g[i, n] += sum_{e in group g} A[e, i] * Gr[e, n]     A = gathered packed rows (h[src] | h[tgt]),
+//                                                          Gr[e, :] = g_node[g_idx[e], :] where winner == e
+// The contraction runs over MESSAGES, but the bf16 MFMA wants 8 consecutive k's of one row in a
+// lane: the operands have to be transposed on the way.  Both tiles are stored in LDS exactly as
+// they arrive -- [plane][message][feature], feature-contiguous rows of 320 B -- and the fragments are
+// read with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group reads a
+// [4 messages][16 features] block (lane 4j+q supplies the address of message j, features 4q..4q+3)
+// and lane i receives the 4 messages of feature i.  Two reads = the 8 k's of one MFMA operand.
+// Row stride 320 B puts the 4 message rows of a block 16 banks apart: conflict-free.
+// Global loads are full 256-byte plane rows (16 lanes x 16 B per message and plane).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define WRS 160                 // shorts per LDS message row (128 features + 32 pad)
+#define WPLANE (32 * WRS)       // shorts per plane (32 messages)
+#define WOPER (3 * WPLANE)      // shorts per operand image
+
+__device__ __forceinline__ bf16x8 tr_frag(const short* p) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * WRS));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
+    const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
+    const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
+    int koff1, int koff2, int nsrc, const uint4* __restrict__ gp, const int* __restrict__ g_idx,
+    const int* __restrict__ g_mask, int ld_mask, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G,
+    int M, int N, int K, int kchunk, float* __restrict__ gw_base, long long strideW, int ldw, int ntiles_n) {
+  __shared__ __attribute__((aligned(16))) short As[WOPER];
+  __shared__ __attribute__((aligned(16))) short Bs[WOPER];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int g, e0, ne;
+  if (!x6_find_piece(group_ptr, G, M, kchunk, blockIdx.x, g, e0, ne)) return;
+  const int e1 = e0 + ne;
+  const int i0 = (blockIdx.y / ntiles_n) * XBM;
+  const int n0 = (blockIdx.y % ntiles_n) * XBN;
+  const int wsel = group_w ? group_w[g] : g;
+
+  // loader: units (message, 8-feature group); unit u = tid + 256 i -> message u >> 4, group u & 15
+  const int fg = tid & 15, msg0 = tid >> 4;  // messages msg0 and msg0 + 16
+  const int fi = i0 + 8 * fg, nn = n0 + 8 * fg;
+  const bool a_ok = fi < K, b_ok = nn < N;
+  const int fic = a_ok ? fi : 0, nnc = b_ok ? nn : 0;
+  int aj = 0;
+  if (nsrc > 1 && fic >= koff1) aj = 1;
+  if (nsrc > 2 && fic >= koff2) aj = 2;
+  const uint4* __restrict__ abase = (aj == 0 ? xp0 : (aj == 1 ? xp1 : xp2)) + ((fic - (aj == 0 ? 0 : (aj == 1 ? koff1 : koff2))) >> 3);
+  const int* __restrict__ aidx = aj == 0 ? idx0 : (aj == 1 ? idx1 : idx2);
+  const int awg = (aj == 0 ? w0 : (aj == 1 ? w1 : w2)) >> 3;  // uint4 per plane of an A row
+  const int gwg = N >> 3;                                      // uint4 per plane of a G row
+  const uint4* __restrict__ gbase = gp + (nnc >> 3);
+  const int* __restrict__ mbase = g_mask + nnc;
+
+  uint4 ra[2][3], rb[2][3];
+  int4 mk[2][2];
+  int arow[2], grow[2];  // gathered rows of the NEXT stage to load
+
+#define WX6_LOAD_IDX(k0_)                                          \
+  {                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                \
+      const int e_ = (k0_) + msg0 + 16 * i;                        \
+      const int ec_ = e_ < e1 ? e_ : e0;                           \
+      arow[i] = aidx ? aidx[ec_] : ec_;                            \
+      grow[i] = g_idx[ec_];                                        \
+    }                                                              \
+  }
+#define WX6_LOAD_STAGE()                                                                         \
+  {                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+      const uint4* a_ = abase + (size_t)arow[i] * 3 * awg;                                       \
+      ra[i][0] = a_[0];                                                                          \
+      ra[i][1] = a_[awg];                                                                        \
+      ra[i][2] = a_[2 * awg];                                                                    \
+      const uint4* g_ = gbase + (size_t)grow[i] * 3 * gwg;                                       \
+      rb[i][0] = g_[0];                                                                          \
+      rb[i][1] = g_[gwg];                                                                        \
+      rb[i][2] = g_[2 * gwg];                                                                    \
+      const int4* m_ = reinterpret_cast<const int4*>(mbase + (size_t)grow[i] * ld_mask);         \
+      mk[i][0] = m_[0];                                                                          \
+      mk[i][1] = m_[1];                                                                          \
+    }                                                                                            \
+  }
+#define WX6_STORE_STAGE(k0_)                                                                     \
+  {                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+      const int eid_ = (k0_) + msg0 + 16 * i;                                                    \
+      const bool eok_ = eid_ < e1;                                                               \
+      uint4 keep_;                                                                               \
+      keep_.x = mask_pair(mk[i][0].x, mk[i][0].y, eid_);                                         \
+      keep_.y = mask_pair(mk[i][0].z, mk[i][0].w, eid_);                                         \
+      keep_.z = mask_pair(mk[i][1].x, mk[i][1].y, eid_);                                         \
+      keep_.w = mask_pair(mk[i][1].z, mk[i][1].w, eid_);                                         \
+      if (!(eok_ && b_ok)) keep_ = make_uint4(0u, 0u, 0u, 0u);                                   \
+      const int slot_ = (msg0 + 16 * i) * WRS + 8 * fg;                                          \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
+        *reinterpret_cast<uint4*>(&As[p * WPLANE + slot_]) = (eok_ && a_ok) ? ra[i][p] : make_uint4(0u, 0u, 0u, 0u); \
+        uint4 b_ = rb[i][p];                                                                     \
+        b_.x &= keep_.x; b_.y &= keep_.y; b_.z &= keep_.z; b_.w &= keep_.w;                      \
+        *reinterpret_cast<uint4*>(&Bs[p * WPLANE + slot_]) = b_;                                 \
+      }                                                                                          \
+    }                                                                                            \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, half = lane >> 5;
+  // transposing-read address of this lane inside a [32 messages][WRS] plane, tile feature base 0
+  const int l16 = lane & 15, grp = lane >> 4;
+  const int tr_off = ((grp >> 1) * 8 + (l16 >> 2)) * WRS + (grp & 1) * 16 + 4 * (l16 & 3);
+  const short* a_tr = As + tr_off + wm * 64;
+  const short* b_tr = Bs + tr_off + wn * 64;
+  const int nk = (ne + 31) / 32;
+
+  WX6_LOAD_IDX(e0)
+  WX6_LOAD_STAGE()
+  WX6_LOAD_IDX(e0 + 32)
+  WX6_STORE_STAGE(e0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      WX6_LOAD_STAGE()
+      WX6_LOAD_IDX(e0 + (kt + 2) * 32)
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {  // two 16-message MFMA steps per stage
+      bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          af[t][p] = tr_frag(a_tr + p * WPLANE + s * 16 * WRS + t * 32);
+          bf[t][p] = tr_frag(b_tr + p * WPLANE + s * 16 * WRS + t * 32);
+        }
+#define WX6_TERM(pa_, pb_)                                                                            \
+  _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)   \
+      acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti][pa_], bf[tj][pb_], acc[ti][tj], 0, 0, 0);
+      WX6_TERM(1, 1) WX6_TERM(2, 0) WX6_TERM(0, 2) WX6_TERM(1, 0) WX6_TERM(0, 1) WX6_TERM(0, 0)
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      WX6_STORE_STAGE(e0 + (kt + 1) * 32)
+      __syncthreads();
+    }
+  }
+
+  float* __restrict__ gw = gw_base + (long long)wsel * strideW;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int n = n0 + wn * 64 + tj * 32 + li;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = i0 + wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (f < K) unsafeAtomicAdd(&gw[(size_t)f * ldw + n], acc[ti][tj][r]);
+      }
+    }
+}
+
 // ================================================================================================
 extern "C" int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, uint16_t* out, void* stream) {
   if (R == 0) return BL_OK;
@@ -338,5 +512,61 @@ extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const int32_t* winner,
   else
     hipLaunchKernelGGL((gemm_rows_x6_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
   BL_LAUNCH_CHECK("bl_gemm_rows_x6");
+  return BL_OK;
+}
+
+extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_packed, const int32_t* g_idx,
+                                       const int32_t* winner, int32_t ld_winner, const int32_t* group_ptr,
+                                       const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
+                                       int64_t gw_group_stride, int32_t ld_gw, void* stream) {
+  if (M == 0) return BL_OK;
+  BL_CHECK_ARG(a && a->nsrc >= 1 && a->nsrc <= 3, "bl_gemm_wgrad_routed_x6: rows descriptor needs 1..3 sources");
+  int off = 0, koff[3] = {0, 0, 0};
+  for (int j = 0; j < a->nsrc; ++j) {
+    BL_CHECK_ARG(a->xp[j] && bl_aligned16(a->xp[j]) && a->width[j] > 0 && a->width[j] % 32 == 0,
+                 "bl_gemm_wgrad_routed_x6: source %d: packed pointer 16-byte aligned and width a multiple of 32 required", j);
+    koff[j] = off;
+    off += a->width[j];
+  }
+  BL_CHECK_ARG(off == K, "bl_gemm_wgrad_routed_x6: K (%d) != sum of source widths (%d)", K, off);
+  BL_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && g_node_packed && gw && bl_aligned16(g_node_packed),
+               "bl_gemm_wgrad_routed_x6: N a multiple of 32 and aligned pointers required");
+  BL_CHECK_ARG(g_idx && winner && ld_winner % 4 == 0 && bl_aligned16(winner), "bl_gemm_wgrad_routed_x6: needs g_idx and a winner table");
+  // rows reduced by one workgroup: an integer number of rounds of resident workgroups (see bl_gemm.hip)
+  static int resident = 0;
+  if (resident == 0) {
+    int per_cu = 0;
+    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_x6_kernel, 256, 0);
+    if (oe != hipSuccess || per_cu <= 0) per_cu = 2;
+    int dev = 0, ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+    resident = per_cu * ncu;
+    if (getenv("BL_DEBUG")) fprintf(stderr, "[buglab_hip] wgrad_x6: %d workgroups/CU x %d CUs\n", per_cu, ncu);
+  }
+  const int ntiles_n = (N + XBN - 1) / XBN;
+  const int ntiles_all = ((K + XBM - 1) / XBM) * ntiles_n;
+  const int extra = (group_ptr ? G : 0) * ntiles_all;
+  int kchunk = 256;
+  for (int rounds = 1; rounds <= 64; ++rounds) {
+    const long long slots = (long long)resident * rounds - extra;
+    if (slots <= 0) continue;
+    const long long kc = ((long long)M * ntiles_all + slots - 1) / slots;
+    if (kc <= 1024 || rounds == 64) {
+      kchunk = (int)((kc + 31) / 32 * 32);
+      break;
+    }
+  }
+  if (kchunk < 256) kchunk = 256;
+  dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ntiles_all);
+  hipLaunchKernelGGL(gemm_wgrad_x6_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const uint4*>(a->xp[0]), a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr,
+                     a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr, a->idx[0],
+                     a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],
+                     a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc,
+                     reinterpret_cast<const uint4*>(g_node_packed), g_idx, winner, ld_winner, group_ptr, group_w, G, M, N, K,
+                     kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n);
+  BL_LAUNCH_CHECK("bl_gemm_wgrad_routed_x6");
   return BL_OK;
 }

@@ -291,7 +291,7 @@ def test_gemm_rows_bf16x6_is_fp32_accurate(ops, Din, Dm, sizes):
         ref[lo:hi] = torch.cat([h[src[lo:hi]], h[tgt[lo:hi]]], -1).double() @ W[t].double()
     # the packing itself: hi + mid + lo reproduces the fp32 value to ~2^-25
     hp = ops.pack_bf16x3(_dev(h))
-    planes = hp.cpu().view(N, Din // 8, 3, 8).to(torch.int32).bitwise_and(0xFFFF)
+    planes = hp.cpu().view(N, 3, Din // 8, 8).permute(0, 2, 1, 3).to(torch.int32).bitwise_and(0xFFFF)
     vals = (planes << 16).view(torch.float32) if False else torch.from_numpy((planes.numpy().astype(np.uint32) << 16).view(np.float32))
     recon = vals[:, :, 0, :] .double() + vals[:, :, 1, :].double() + vals[:, :, 2, :].double()
     assert (recon.reshape(N, Din) - h.double()).abs().max() <= 2.0 ** -24 * float(h.abs().max())
@@ -301,3 +301,46 @@ def test_gemm_rows_bf16x6_is_fp32_accurate(ops, Din, Dm, sizes):
     exact = ops.gemm_rows([(_dev(h), _dev(src)), (_dev(h), _dev(tgt))], _dev(W), E, Dm, b_group_stride=2 * Din * Dm, ldb=Dm, group_ptr=_dev(ptr), G=T)
     err32 = (exact.cpu().double() - ref).abs().max()
     assert err < 2e-5 and err < 4 * err32 + 1e-6, (float(err), float(err32))
+
+
+@pytest.mark.parametrize("Din,Dm,sizes", [(32, 64, [130, 0, 1, 700, 64]), (128, 128, [2100, 5, 300]), (64, 256, [129, 128, 1500])])
+def test_routed_gemms_bf16x6_match_fp64(ops, Din, Dm, sizes):
+    """bf16x6 input-gradient and weight-gradient GEMMs of the max-aggregated messages (winner-masked
+    operand, transposing LDS reads in the weight gradient) against an fp64 reference."""
+    rng = np.random.default_rng(1)
+    N, T, E = 97, len(sizes), int(sum(sizes))
+    h = torch.randn(N, Din)
+    W = torch.randn(T, 2 * Din, Dm) / math.sqrt(2 * Din)
+    gq = torch.randn(N, Dm)
+    src, tgt = rng.integers(0, N, E).astype(np.int32), rng.integers(0, N, E).astype(np.int32)
+    ptr = _groups(rng, sizes)
+    # winner table: for every (node, channel) one of the messages targeting the node (or -1)
+    arg = np.full((N, Dm), -1, dtype=np.int32)
+    for n in range(N):
+        inc = np.nonzero(tgt == n)[0]
+        if len(inc):
+            arg[n] = rng.choice(inc, Dm)
+    Gm = torch.zeros(E, Dm, dtype=torch.float64)   # routed message gradient
+    e_ids = torch.arange(E)[:, None]
+    Gm = torch.where(torch.from_numpy(arg)[tgt.astype(np.int64)].long() == e_ids, gq[tgt.astype(np.int64)].double(), Gm)
+    A = torch.cat([h[src.astype(np.int64)], h[tgt.astype(np.int64)]], -1).double()
+    ref_dW = torch.zeros(T, 2 * Din, Dm, dtype=torch.float64)
+    ref_dA = torch.zeros(E, 2 * Din, dtype=torch.float64)
+    for t in range(T):
+        lo, hi = ptr[t], ptr[t + 1]
+        ref_dW[t] = A[lo:hi].T @ Gm[lo:hi]
+        ref_dA[lo:hi] = Gm[lo:hi] @ W[t].double().T
+    hp, gqp = ops.pack_bf16x3(_dev(h)), ops.pack_bf16x3(_dev(gq))
+    d_arg, d_src, d_tgt, d_ptr = _dev(arg), _dev(src), _dev(tgt), _dev(ptr)
+    gw = torch.zeros(T, 2 * Din, Dm, device="cuda")
+    ops.gemm_wgrad_routed_x6([(hp, d_src, Din), (hp, d_tgt, Din)], gqp, d_tgt, d_arg, E, Dm, gw, gw_group_stride=2 * Din * Dm,
+                             group_ptr=d_ptr, G=T)
+    gw32 = torch.zeros_like(gw)
+    ops.gemm_wgrad_routed([(_dev(h), d_src), (_dev(h), d_tgt)], _dev(gq), d_tgt, d_arg, E, Dm, gw32, gw_group_stride=2 * Din * Dm,
+                          group_ptr=d_ptr, G=T)
+    scale = float(ref_dW.abs().max())
+    err, err32 = float((gw.cpu().double() - ref_dW).abs().max()), float((gw32.cpu().double() - ref_dW).abs().max())
+    assert err < 2e-6 * max(scale, 1.0) * 4 and err < 4 * err32 + 1e-6 * scale, (err, err32, scale)
+    dA = ops.gemm_rows_x6([(gqp, d_tgt, Dm)], ops.pack_bf16x3(_dev(W).view(T * 2 * Din, Dm)), E, 2 * Din,
+                          b_group_stride=2 * Din * 3 * Dm, group_ptr=d_ptr, G=T, winner=d_arg)
+    assert float((dA.cpu().double() - ref_dA).abs().max()) < 2e-5

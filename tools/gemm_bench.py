@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--types", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--which", default="fwd,nk,wgrad")
+    ap.add_argument("--order", default="type", help="type: type-major; chunk: (graph chunk, type)-major")
+    ap.add_argument("--chunk", type=int, default=1, help="graphs per chunk")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
     N, E, Din, Dm, T = a.nodes, a.msgs, a.din, a.dm, a.types
@@ -32,6 +34,20 @@ def main():
     # graph-local sources like the real collator: messages of a type sorted by target
     tgt = np.concatenate([np.sort(rng.integers(0, N, s)) for s in sizes]).astype(np.int32)
     src = (tgt // 2000 * 2000 + rng.integers(0, 2000, E)).clip(0, N - 1).astype(np.int32)
+    gw_t = None
+    if a.order == "chunk":
+        typ = np.repeat(np.arange(T), sizes)
+        chunk = tgt // (2000 * a.chunk)
+        nchunk = int(chunk.max()) + 1
+        order = np.lexsort((tgt, typ, chunk))
+        src, tgt, typ, chunk = src[order], tgt[order], typ[order], chunk[order]
+        key = chunk * T + typ
+        counts = np.bincount(key, minlength=nchunk * T)
+        ptr = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32).cuda()
+        gw_t = torch.tensor(np.tile(np.arange(T), nchunk), dtype=torch.int32).cuda()
+        T_groups = nchunk * T
+    else:
+        T_groups = T
     h = torch.randn(N, Din, device="cuda")
     W = torch.randn(T, 2 * Din, Dm, device="cuda") / np.sqrt(2 * Din)
     G = torch.randn(E, Dm, device="cuda")
@@ -49,8 +65,18 @@ def main():
     gq = torch.randn(N, Dm, device="cuda")
     gqp = ops.pack_bf16x3(gq)
     arg = torch.randint(0, E, (N, Dm), device="cuda", dtype=torch.int32)
-    fns["fwd_x6"] = lambda: ops.gemm_rows_x6([(hp, src, Din), (hp, tgt, Din)], wtp, E, Dm, b_group_stride=Dm * 6 * Din, group_ptr=ptr, G=T)
-    fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, b_group_stride=2 * Din * 3 * Dm, group_ptr=ptr, G=T, winner=arg)
+    fns["fwd_x6"] = lambda: ops.gemm_rows_x6([(hp, src, Din), (hp, tgt, Din)], wtp, E, Dm, b_group_stride=Dm * 6 * Din, group_ptr=ptr, G=T_groups, group_w=gw_t)
+    fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, b_group_stride=2 * Din * 3 * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t, winner=arg)
+    # a realistic winner table: every (node, channel) won by one of the node's incoming messages
+    order = torch.argsort(tgt.long(), stable=True)
+    first = torch.searchsorted(tgt.long()[order], torch.arange(N, device="cuda"))
+    deg = torch.bincount(tgt.long(), minlength=N)
+    pick = (torch.rand(N, Dm, device="cuda") * deg.clamp(min=1)[:, None]).long().clamp(max=E - 1)
+    arg_real = order[(first[:, None] + pick).clamp(max=E - 1)].to(torch.int32)
+    arg_real[deg == 0] = -1
+    gw6 = torch.zeros_like(W)
+    fns["wgrad_routed"] = lambda: ops.gemm_wgrad_routed([(h, src), (h, tgt)], gq, tgt, arg_real, E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
+    fns["wgrad_x6"] = lambda: ops.gemm_wgrad_routed_x6([(hp, src, Din), (hp, tgt, Din)], gqp, tgt, arg_real, E, Dm, gw6, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
     fns["pack_wt"] = lambda: ops.pack_bf16x3_transposed(W)
     for name in a.which.split(","):
