@@ -95,8 +95,9 @@ int bl_gemm_rows_routed(const bl_rows_t* a, const int32_t* winner, int32_t ld_wi
  * back, [hi x D | mid x D | lo x D]) and a product is evaluated as the six MFMA terms hh + hm + mh + hl + lh + mm
  * with fp32 accumulation; dropped terms are < 2^-26 of the product, below fp32's own rounding.
  * Same contract as bl_gemm_rows with b_is_nk = 1 (B_g given as [N, K], i.e. C = A . B_g^T), no
- * bias/activation epilogue; `winner` != NULL selects the routed left operand of bl_gemm_rows_routed.
- * Source widths must be multiples of 32. */
+ * bias/activation epilogue.  win_bits != NULL selects the routed left operand of bl_gemm_rows_routed,
+ * with the routing given as bl_segment_max_fwd's per-message bitmask (row r keeps channel k iff bit k
+ * of win_bits[r * ld_bits ...] is set; ld_bits in 32-bit words).  Source widths: multiples of 32. */
 typedef struct {
   const uint16_t* xp[3];  /* packed matrices (bl_pack_bf16x3) */
   const int32_t* idx[3];  /* row gather index or NULL */
@@ -106,14 +107,14 @@ typedef struct {
 int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, uint16_t* out, void* stream);
 /* w [G][K][N] fp32 -> out [G][N][3][K]: the [N, K] (transposed) packed form bl_gemm_rows_x6 takes as B */
 int bl_pack_bf16x3_transposed(const float* w, int32_t G, int32_t K, int32_t N, uint16_t* out, void* stream);
-int bl_gemm_rows_x6(const bl_rows_packed_t* a, const int32_t* winner, int32_t ld_winner, const uint16_t* bp,
+int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                     int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
                     int32_t N, int32_t K, float* c, int32_t ldc, void* stream);
 /* bf16x6 form of bl_gemm_wgrad_routed (below): `a` packed rows, g_node_packed = bl_pack_bf16x3 of the
  * node gradient [*, N]; the message-major operands are transposed on the fly by gfx950's transposing
  * LDS read (ds_read_b64_tr_b16).  N and the source widths must be multiples of 32. */
 int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_packed, const int32_t* g_idx,
-                            const int32_t* winner, int32_t ld_winner, const int32_t* group_ptr, const int32_t* group_w,
+                            const uint32_t* win_bits, int32_t ld_bits, const int32_t* group_ptr, const int32_t* group_w,
                             int32_t G, int32_t M, int32_t N, int32_t K, float* gw, int64_t gw_group_stride, int32_t ld_gw,
                             void* stream);
 
@@ -136,12 +137,14 @@ int bl_gemm_wgrad_routed(const bl_rows_t* a, const float* g_node, int32_t ld_g, 
  *   arg[v, d] = that item (ties: first in segment order), -1 and out = 0 for an empty segment;
  *   if ln_g != NULL also  ln_out[v,:] = LayerNorm(out[v,:]; ln_g, ln_b, eps), mean[v], rstd[v];
  *   if dact != NULL also  dact[v, d] = act'(x[arg[v, d], d]) (0 for an empty segment): with it the
- *   backward pass needs only [nseg, D] arrays, never the [items, D] pre-activations again.
+ *   backward pass needs only [nseg, D] arrays, never the [items, D] pre-activations again;
+ *   if winbits != NULL also  winbits[item, w] bit b = (arg[seg(item), 32 w + b] == item), ceil(D/32)
+ *   words per item: the routing table in the form the bf16x6 routed GEMMs read.
  * Replaces torch_scatter.scatter_max at ptgnn's "max" aggregation (gnnlayerdefs.py:11,21) and at
  * buglab/models/layers/localizationmodule.py:56-58, plus ptgnn's nn.LayerNorm. */
 int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg,
                        int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g, const float* ln_b,
-                       float eps, float* ln_out, float* mean, float* rstd, float* dact, void* stream);
+                       float eps, float* ln_out, float* mean, float* rstd, float* dact, uint32_t* winbits, void* stream);
 
 /* backward of the segmented max, gather form (deterministic, no atomics):
  *   g_x[i, d] = (arg[seg_of[i], d] == i) ? g_out[seg_of[i], d] * act'(x[i, d]) : 0      (g_x may alias x) */

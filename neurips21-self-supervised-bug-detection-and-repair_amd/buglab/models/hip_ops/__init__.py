@@ -51,7 +51,7 @@ _SIGNATURES = {
     "bl_gemm_wgrad_routed_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
-    "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
@@ -253,8 +253,9 @@ def pack_bf16x3_transposed(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gemm_rows_x6(sources, bp, M, N, *, b_group_stride=0, group_ptr=None, group_w=None, G=1, winner=None, kind="gemm_rows_x6"):
-    """sources: [(packed int16 [*, 3*width], row index or None, width)]; bp: packed [G, N, 3K] (or [N, 3K])."""
+def gemm_rows_x6(sources, bp, M, N, *, b_group_stride=0, group_ptr=None, group_w=None, G=1, win_bits=None, kind="gemm_rows_x6"):
+    """sources: [(packed int16 [*, 3*width], row index or None, width)]; bp: packed [G, N, 3K] (or [N, 3K]);
+    win_bits: segment_max's per-row routing bitmask -> the routed (winner-masked) left operand."""
     r = bl_rows_packed_t()
     K = 0
     for j, (xp, idx, width) in enumerate(sources):
@@ -269,7 +270,7 @@ def gemm_rows_x6(sources, bp, M, N, *, b_group_stride=0, group_ptr=None, group_w
         return out
     with _timed(kind + ("_grouped" if group_ptr is not None else ""), 2.0 * M * N * K):
         _check(
-            load_library().bl_gemm_rows_x6(ctypes.byref(r), _p(winner), winner.stride(0) if winner is not None else 0,
+            load_library().bl_gemm_rows_x6(ctypes.byref(r), _p(win_bits), win_bits.stride(0) if win_bits is not None else 0,
                                            _req(bp, torch.int16, "bp").data_ptr(), int(b_group_stride), _p(group_ptr), _p(group_w),
                                            int(G), int(M), int(N), int(K), out.data_ptr(), out.stride(0), _stream()),
             "bl_gemm_rows_x6")
@@ -289,7 +290,7 @@ def _rows_packed(sources):
     return r, K
 
 
-def gemm_wgrad_routed_x6(sources, g_node_packed, node_of_row, winner, M, N, gw, *, gw_group_stride=0, group_ptr=None, group_w=None, G=1):
+def gemm_wgrad_routed_x6(sources, g_node_packed, node_of_row, win_bits, M, N, gw, *, gw_group_stride=0, group_ptr=None, group_w=None, G=1):
     """bf16x6 weight gradient of the routed (max-aggregated) messages; accumulates into gw."""
     rows, K = _rows_packed(sources)
     if M == 0:
@@ -297,7 +298,7 @@ def gemm_wgrad_routed_x6(sources, g_node_packed, node_of_row, winner, M, N, gw, 
     with _timed("gemm_wgrad_routed_x6", 2.0 * M * N * K):
         _check(
             load_library().bl_gemm_wgrad_routed_x6(ctypes.byref(rows), _req(g_node_packed, torch.int16, "g_node_packed").data_ptr(),
-                                                   _i32(node_of_row).data_ptr(), _i32(winner).data_ptr(), winner.stride(0),
+                                                   _i32(node_of_row).data_ptr(), _i32(win_bits).data_ptr(), win_bits.stride(0),
                                                    _p(group_ptr), _p(group_w), int(G), int(M), int(N), int(K),
                                                    _f32(gw).data_ptr(), int(gw_group_stride), int(gw.shape[-1]), _stream()),
             "bl_gemm_wgrad_routed_x6")
@@ -351,8 +352,11 @@ def gemm_wgrad(sources, g_c, M, N, gw, *, gw_group_stride=0, group_ptr=None, gro
     return gw
 
 
-def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5, want_dact=False):
-    """-> (out [nseg, D], arg int32 [nseg, D], ln_out | None, mean | None, rstd | None[, dact])"""
+def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5, want_dact=False, want_bits=False):
+    """-> (out [nseg, D], arg int32 [nseg, D], ln_out | None, mean | None, rstd | None[, dact][, winbits])
+
+    winbits: int32 [items, ceil(D/32)], bit d of row i set iff item i won channel d of its segment
+    (every item must belong to exactly one segment)."""
     _f32(x, "x")
     D = x.shape[1]
     dev = x.device
@@ -364,14 +368,18 @@ def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5, wa
         mean = torch.empty((nseg,), dtype=torch.float32, device=dev)
         rstd = torch.empty((nseg,), dtype=torch.float32, device=dev)
     dact = torch.empty((nseg, D), dtype=torch.float32, device=dev) if want_dact else None
+    bits = torch.empty((x.shape[0], (D + 31) // 32), dtype=torch.int32, device=dev) if want_bits else None
     _check(
         load_library().bl_segment_max_fwd(x.data_ptr(), x.stride(0), _i32(seg_ptr).data_ptr(), _p(seg_items), int(nseg), int(D),
                                           int(act), out.data_ptr(), arg.data_ptr(), _p(ln[0]) if ln else None,
-                                          _p(ln[1]) if ln else None, float(eps), _p(ln_out), _p(mean), _p(rstd), _p(dact), _stream()),
+                                          _p(ln[1]) if ln else None, float(eps), _p(ln_out), _p(mean), _p(rstd), _p(dact), _p(bits), _stream()),
         "bl_segment_max_fwd")
+    res = (out, arg, ln_out, mean, rstd)
     if want_dact:
-        return out, arg, ln_out, mean, rstd, dact
-    return out, arg, ln_out, mean, rstd
+        res += (dact,)
+    if want_bits:
+        res += (bits,)
+    return res
 
 
 def segment_max_bwd(g_out, arg, x, seg_of, act=ACT_NONE, out=None):
@@ -564,18 +572,22 @@ class _MpLayer(torch.autograd.Function):
             hp = None
             pre = gemm_rows([(h, g.msg_src), (h, g.msg_tgt)], _f32(W, "W"), E, Dm, b_group_stride=K2 * Dm, ldb=Dm,
                             group_ptr=g.type_ptr, G=T)
-        agg, arg, ln_out, mean, rstd, dact = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)),
-                                                         want_dact=True)
-        del pre
+        use_bits = x6_ok(Din, Dm)
+        res = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)), want_dact=True, want_bits=use_bits)
+        agg, arg, ln_out, mean, rstd, dact = res[:6]
+        bits = res[6] if use_bits else None
+        if use_bits and WGRAD_X6:
+            arg = None  # the bf16x6 backward routes with the per-message bitmask only
+        del pre, res
         if msg_act == ACT_NONE:
             dact = None  # derivative is identically 1
         out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
-        ctx.saved = (h, hp, W, ln_g, Wd, dact, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop)
+        ctx.saved = (h, hp, W, ln_g, Wd, dact, arg, bits, agg, mean, rstd, ln_out, out, g, msg_act, drop)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        h, hp, W, ln_g, Wd, dact, arg, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
+        h, hp, W, ln_g, Wd, dact, arg, bits, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
         ctx.saved = None
         N, Din = h.shape
         T, K2, Dm = W.shape
@@ -605,7 +617,7 @@ class _MpLayer(torch.autograd.Function):
         side2 = _on_side_stream(dev)
         with side2:
             if hp is not None:
-                gemm_wgrad_routed_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din)], gqp, g.msg_tgt, arg, E, Dm, g_W,
+                gemm_wgrad_routed_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din)], gqp, g.msg_tgt, bits, E, Dm, g_W,
                                      gw_group_stride=K2 * Dm, group_ptr=g.type_ptr, G=T)
             else:
                 gemm_wgrad_routed([(h, g.msg_src), (h, g.msg_tgt)], gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K2 * Dm,
@@ -614,7 +626,7 @@ class _MpLayer(torch.autograd.Function):
         if gqp is not None:
             # d a = G . W_t^T: B_g = W_t itself as [n = 2*Din, k = Dm], row-packed
             g_a = gemm_rows_x6([(gqp, g.msg_tgt, Dm)], pack_bf16x3(W.view(T * K2, Dm)), E, K2,
-                               b_group_stride=K2 * 3 * Dm, group_ptr=g.type_ptr, G=T, winner=arg, kind="gemm_rows_nk_routed_x6")
+                               b_group_stride=K2 * 3 * Dm, group_ptr=g.type_ptr, G=T, win_bits=bits, kind="gemm_rows_nk_routed_x6")
         else:
             g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K2, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
         g_h = torch.empty((N, Din), dtype=torch.float32, device=dev)
@@ -627,7 +639,7 @@ class _MpLayer(torch.autograd.Function):
             # gradients land in param.grad behind the main chain; joined by join_side_stream()
             global _free_running
             _free_running = True
-            side2.detach(h, gq, arg, hp, gqp)
+            side2.detach(h, gq, arg, bits, hp, gqp)
             side1.detach(ln_out, g_z)
             return g_h, None, g_lng, g_lnb, None, g_bd, None, None, None
         side2.join()

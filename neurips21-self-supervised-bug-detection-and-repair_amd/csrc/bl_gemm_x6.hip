@@ -127,15 +127,21 @@ __device__ __forceinline__ bool x6_find_piece(const int* __restrict__ group_ptr,
   return false;
 }
 
-__device__ __forceinline__ uint32_t mask_pair(int w0, int w1, int rid) {
-  return (w0 == rid ? 0x0000FFFFu : 0u) | (w1 == rid ? 0xFFFF0000u : 0u);
+// routing byte (8 channels, bit c = keep channel c) -> AND-masks for the 8 packed bf16 of a plane
+__device__ __forceinline__ uint4 keep_from_bits(uint32_t b) {
+  uint4 k;
+  k.x = (__builtin_amdgcn_sbfe(b, 0, 1) & 0x0000FFFFu) | (__builtin_amdgcn_sbfe(b, 1, 1) & 0xFFFF0000u);
+  k.y = (__builtin_amdgcn_sbfe(b, 2, 1) & 0x0000FFFFu) | (__builtin_amdgcn_sbfe(b, 3, 1) & 0xFFFF0000u);
+  k.z = (__builtin_amdgcn_sbfe(b, 4, 1) & 0x0000FFFFu) | (__builtin_amdgcn_sbfe(b, 5, 1) & 0xFFFF0000u);
+  k.w = (__builtin_amdgcn_sbfe(b, 6, 1) & 0x0000FFFFu) | (__builtin_amdgcn_sbfe(b, 7, 1) & 0xFFFF0000u);
+  return k;
 }
 
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
-    int koff1, int koff2, int nsrc, const int* __restrict__ mask_arg, int mask_ld, const uint4* __restrict__ bp,
+    int koff1, int koff2, int nsrc, const uint32_t* __restrict__ win_bits, int ld_bits, const uint4* __restrict__ bp,
     long long strideB, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G, int M, int N, int K,
     float* __restrict__ c, int ldc) {
   __shared__ uint4 As[XBM * XROW];
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
   // loader mapping: (row, k-group) pairs, 2 per thread; 4 consecutive lanes cover one row's 192 bytes
   const int p_kg = tid & 3, p_row0 = tid >> 2;  // rows p_row0 and p_row0 + 64
   uint4 ra[2][3], rb[2][3];
-  int4 ma[MASKED ? 2 : 1][2];
+  uint32_t ma[2];
   const int nk = (K + 31) / 32;
 
 #define X6_LOAD_STAGE(k0_)                                                                                    \
@@ -180,11 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
       ra[i][0] = src_[0];                                                                                     \
       ra[i][1] = src_[wj_ >> 3];                                                                              \
       ra[i][2] = src_[2 * (wj_ >> 3)];                                                                        \
-      if (MASKED) {                                                                                           \
-        const int4* m_ = reinterpret_cast<const int4*>(mask_arg + (size_t)rowidx[0][row_] * mask_ld + kc_);   \
-        ma[i][0] = m_[0];                                                                                     \
-        ma[i][1] = m_[1];                                                                                     \
-      }                                                                                                       \
+      if (MASKED) ma[i] = win_bits[(size_t)(row0 + min(row_, nrows - 1)) * ld_bits + (kc_ >> 5)];              \
       const int n_ = n0 + row_;                                                                               \
       const uint4* bsrc_ = Bg + (size_t)(n_ < N ? n_ : 0) * 3 * kgK + (kc_ >> 3);                             \
       rb[i][0] = bsrc_[0];                                                                                    \
@@ -198,13 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
       const int row_ = p_row0 + 64 * i;                                                                       \
       uint4 keep_ = make_uint4(~0u, ~0u, ~0u, ~0u);                                                           \
-      if (MASKED) {                                                                                           \
-        const int rid_ = row0 + row_;                                                                         \
-        keep_.x = mask_pair(ma[i][0].x, ma[i][0].y, rid_);                                                    \
-        keep_.y = mask_pair(ma[i][0].z, ma[i][0].w, rid_);                                                    \
-        keep_.z = mask_pair(ma[i][1].x, ma[i][1].y, rid_);                                                    \
-        keep_.w = mask_pair(ma[i][1].z, ma[i][1].w, rid_);                                                    \
-      }                                                                                                       \
+      if (MASKED) keep_ = keep_from_bits(ma[i] >> (8 * p_kg)); /* k0 is a multiple of 32 */                  \
       if (!kok_) keep_ = make_uint4(0u, 0u, 0u, 0u);                                                          \
       const bool nok_ = kok_ && (n0 + row_ < N);                                                              \
       _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                         \
@@ -317,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
     int koff1, int koff2, int nsrc, const uint4* __restrict__ gp, const int* __restrict__ g_idx,
-    const int* __restrict__ g_mask, int ld_mask, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G,
+    const uint32_t* __restrict__ win_bits, int ld_bits, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G,
     int M, int N, int K, int kchunk, float* __restrict__ gw_base, long long strideW, int ldw, int ntiles_n) {
   __shared__ __attribute__((aligned(16))) short As[WOPER];
   __shared__ __attribute__((aligned(16))) short Bs[WOPER];
@@ -343,11 +339,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
   const int awg = (aj == 0 ? w0 : (aj == 1 ? w1 : w2)) >> 3;  // uint4 per plane of an A row
   const int gwg = N >> 3;                                      // uint4 per plane of a G row
   const uint4* __restrict__ gbase = gp + (nnc >> 3);
-  const int* __restrict__ mbase = g_mask + nnc;
+  const uint32_t* __restrict__ mbase = win_bits + (nnc >> 5);
+  const int mshift = nnc & 31;
 
   uint4 ra[2][3], rb[2][3];
-  int4 mk[2][2];
-  int arow[2], grow[2];  // gathered rows of the NEXT stage to load
+  uint32_t mk[2];
+  int arow[2], grow[2], mrow[2];  // gathered rows / message ids of the NEXT stage to load
 
 #define WX6_LOAD_IDX(k0_)                                          \
   {                                                                \
@@ -356,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
       const int ec_ = e_ < e1 ? e_ : e0;                           \
       arow[i] = aidx ? aidx[ec_] : ec_;                            \
       grow[i] = g_idx[ec_];                                        \
+      mrow[i] = ec_;                                               \
     }                                                              \
   }
 #define WX6_LOAD_STAGE()                                                                         \
@@ -369,9 +367,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
       rb[i][0] = g_[0];                                                                          \
       rb[i][1] = g_[gwg];                                                                        \
       rb[i][2] = g_[2 * gwg];                                                                    \
-      const int4* m_ = reinterpret_cast<const int4*>(mbase + (size_t)grow[i] * ld_mask);         \
-      mk[i][0] = m_[0];                                                                          \
-      mk[i][1] = m_[1];                                                                          \
+      mk[i] = mbase[(size_t)mrow[i] * ld_bits];                                                  \
     }                                                                                            \
   }
 #define WX6_STORE_STAGE(k0_)                                                                     \
@@ -379,11 +375,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
       const int eid_ = (k0_) + msg0 + 16 * i;                                                    \
       const bool eok_ = eid_ < e1;                                                               \
-      uint4 keep_;                                                                               \
-      keep_.x = mask_pair(mk[i][0].x, mk[i][0].y, eid_);                                         \
-      keep_.y = mask_pair(mk[i][0].z, mk[i][0].w, eid_);                                         \
-      keep_.z = mask_pair(mk[i][1].x, mk[i][1].y, eid_);                                         \
-      keep_.w = mask_pair(mk[i][1].z, mk[i][1].w, eid_);                                         \
+      uint4 keep_ = keep_from_bits(mk[i] >> mshift);                                             \
       if (!(eok_ && b_ok)) keep_ = make_uint4(0u, 0u, 0u, 0u);                                   \
       const int slot_ = (msg0 + 16 * i) * WRS + 8 * fg;                                          \
       _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
@@ -481,7 +473,7 @@ extern "C" int bl_pack_bf16x3_transposed(const float* w, int32_t G, int32_t K, i
   return BL_OK;
 }
 
-extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const int32_t* winner, int32_t ld_winner, const uint16_t* bp,
+extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                                int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G,
                                int32_t M, int32_t N, int32_t K, float* c, int32_t ldc, void* stream) {
   if (M == 0) return BL_OK;
@@ -497,17 +489,17 @@ extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const int32_t* winner,
   BL_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0 && bp && c && bl_aligned16(bp) && bl_aligned16(c),
                "bl_gemm_rows_x6: N/ldc multiples of 4, aligned pointers required");
   BL_CHECK_ARG(b_group_stride % 8 == 0, "bl_gemm_rows_x6: packed group stride must be a multiple of 8 elements");
-  BL_CHECK_ARG(winner == nullptr || (a->nsrc == 1 && a->idx[0] && ld_winner % 4 == 0),
-               "bl_gemm_rows_x6: the routed form needs exactly one gathered source");
+  BL_CHECK_ARG(win_bits == nullptr || (a->nsrc == 1 && a->idx[0] && ld_bits * 32 >= K),
+               "bl_gemm_rows_x6: the routed form needs exactly one gathered source and ld_bits >= K / 32");
   dim3 grid((M + XBM - 1) / XBM + (group_ptr ? G : 0), (N + XBN - 1) / XBN);
   const uint4* x0 = reinterpret_cast<const uint4*>(a->xp[0]);
   const uint4* x1 = a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr;
   const uint4* x2 = a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr;
 #define X6_ARGS                                                                                                          \
   x0, x1, x2, a->idx[0], a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],              \
-      a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc, winner, ld_winner,        \
+      a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc, win_bits, ld_bits,        \
       reinterpret_cast<const uint4*>(bp), (long long)(b_group_stride / 8), group_ptr, group_w, G, M, N, K, c, ldc
-  if (winner)
+  if (win_bits)
     hipLaunchKernelGGL((gemm_rows_x6_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
   else
     hipLaunchKernelGGL((gemm_rows_x6_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
@@ -516,7 +508,7 @@ extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const int32_t* winner,
 }
 
 extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_packed, const int32_t* g_idx,
-                                       const int32_t* winner, int32_t ld_winner, const int32_t* group_ptr,
+                                       const uint32_t* win_bits, int32_t ld_bits, const int32_t* group_ptr,
                                        const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
                                        int64_t gw_group_stride, int32_t ld_gw, void* stream) {
   if (M == 0) return BL_OK;
@@ -531,7 +523,7 @@ extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t
   BL_CHECK_ARG(off == K, "bl_gemm_wgrad_routed_x6: K (%d) != sum of source widths (%d)", K, off);
   BL_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && g_node_packed && gw && bl_aligned16(g_node_packed),
                "bl_gemm_wgrad_routed_x6: N a multiple of 32 and aligned pointers required");
-  BL_CHECK_ARG(g_idx && winner && ld_winner % 4 == 0 && bl_aligned16(winner), "bl_gemm_wgrad_routed_x6: needs g_idx and a winner table");
+  BL_CHECK_ARG(g_idx && win_bits && ld_bits * 32 >= N, "bl_gemm_wgrad_routed_x6: needs g_idx and the winner bitmask (ld_bits >= N / 32)");
   // rows reduced by one workgroup: an integer number of rounds of resident workgroups (see bl_gemm.hip)
   static int resident = 0;
   if (resident == 0) {
@@ -565,7 +557,7 @@ extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t
                      a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr, a->idx[0],
                      a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],
                      a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc,
-                     reinterpret_cast<const uint4*>(g_node_packed), g_idx, winner, ld_winner, group_ptr, group_w, G, M, N, K,
+                     reinterpret_cast<const uint4*>(g_node_packed), g_idx, win_bits, ld_bits, group_ptr, group_w, G, M, N, K,
                      kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n);
   BL_LAUNCH_CHECK("bl_gemm_wgrad_routed_x6");
   return BL_OK;

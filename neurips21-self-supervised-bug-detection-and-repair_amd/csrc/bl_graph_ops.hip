@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           float eps, float* __restrict__ ln_out,
                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                          float* __restrict__ dact) {
+                                                          float* __restrict__ dact, uint32_t* __restrict__ winbits) {
   const int lane = threadIdx.x & 63;
   const int seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (seg >= nseg) return;
@@ -116,6 +116,24 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
           float t = row[d];
           if (act == BL_ACT_GELU) t = bl_gelu(t);
           if (t > best[j]) { best[j] = t; barg[j] = e; }
+        }
+      }
+    }
+  }
+  if (winbits) {
+    // per ITEM bitmask of the channels it won (bit d of row `item`): the routed bf16x6 GEMMs of the
+    // backward pass read these 4 bytes per 32 channels instead of 128 bytes of the arg table
+    const int wpr = (D + 31) >> 5;
+    for (int base = beg; base < end; base += 64) {
+      const int cnt = min(64, end - base);
+      const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
+      for (int i = 0; i < cnt; ++i) {
+        const int e = __shfl(mine, i, 64);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const unsigned long long b = __ballot(barg[j] == e);  // padding lanes hold -1
+          if (lane == 0 && 2 * j < wpr) winbits[(size_t)e * wpr + 2 * j] = (uint32_t)b;
+          if (lane == 0 && 2 * j + 1 < wpr) winbits[(size_t)e * wpr + 2 * j + 1] = (uint32_t)(b >> 32);
         }
       }
     }
@@ -447,7 +465,7 @@ extern "C" int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const
 extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items,
                                   int32_t nseg, int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g,
                                   const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, float* dact,
-                                  void* stream) {
+                                  uint32_t* winbits, void* stream) {
   if (nseg == 0) return BL_OK;
   BL_CHECK_ARG(seg_ptr && out && arg, "bl_segment_max_fwd: null pointer");
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
@@ -458,10 +476,10 @@ extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* se
   hipStream_t st = (hipStream_t)stream;
   if (has_ln) {
     DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, true>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
-                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact))
+                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits))
   } else {
     DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, false>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
-                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact))
+                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits))
   }
   BL_LAUNCH_CHECK("bl_segment_max_fwd");
   return BL_OK;

@@ -117,11 +117,19 @@ def test_segment_max_layernorm_fwd_bwd(ops, D, act):
     xa = O._gelu(x.double()) if act == "gelu" else x.double()
     ref, arg = O.scatter_max_with_arg(xa, torch.from_numpy(seg), nseg)
     ref_ln = torch.nn.functional.layer_norm(ref, (D,), g.double(), b.double(), eps=1e-5)
-    out, a, ln_out, mean, rstd, dact = ops.segment_max(_dev(x), _dev(ptr), _dev(order), nseg, act=ops._ACTS[act], ln=(_dev(g), _dev(b)), want_dact=True)
+    out, a, ln_out, mean, rstd, dact, wbits = ops.segment_max(_dev(x), _dev(ptr), _dev(order), nseg, act=ops._ACTS[act], ln=(_dev(g), _dev(b)),
+                                                              want_dact=True, want_bits=True)
     assert (out.cpu().double() - ref).abs().max() < 1e-6
     a_ref = torch.where(arg == E, torch.full_like(arg, -1), arg)
     assert (a.cpu().long() == a_ref).all()
     assert (ln_out.cpu().double() - ref_ln).abs().max() < 2e-5
+    # per-item routing bitmask: bit d of item i <=> i is the arg-max of channel d of its segment
+    won = (a_ref[torch.from_numpy(seg).long()] == torch.arange(E)[:, None]).numpy()
+    W32 = (D + 31) // 32
+    wpad = np.zeros((E, W32 * 32), dtype=bool)
+    wpad[:, :D] = won
+    ref_bits = np.packbits(wpad.reshape(E, W32, 32), axis=-1, bitorder="little").view(np.uint32).reshape(E, W32)
+    assert (wbits.cpu().numpy().view(np.uint32) == ref_bits).all()
     # backward of the max (gather form) against autograd through the oracle
     if D % 4 == 0:
         go = torch.randn(nseg, D)
@@ -332,8 +340,11 @@ def test_routed_gemms_bf16x6_match_fp64(ops, Din, Dm, sizes):
         ref_dA[lo:hi] = Gm[lo:hi] @ W[t].double().T
     hp, gqp = ops.pack_bf16x3(_dev(h)), ops.pack_bf16x3(_dev(gq))
     d_arg, d_src, d_tgt, d_ptr = _dev(arg), _dev(src), _dev(tgt), _dev(ptr)
+    won = (arg[tgt] == np.arange(E)[:, None])                       # [E, Dm] routing as booleans
+    bits = np.packbits(won.reshape(E, Dm // 32, 32), axis=-1, bitorder="little").view(np.uint32).reshape(E, Dm // 32)
+    d_bits = _dev(bits.view(np.int32))
     gw = torch.zeros(T, 2 * Din, Dm, device="cuda")
-    ops.gemm_wgrad_routed_x6([(hp, d_src, Din), (hp, d_tgt, Din)], gqp, d_tgt, d_arg, E, Dm, gw, gw_group_stride=2 * Din * Dm,
+    ops.gemm_wgrad_routed_x6([(hp, d_src, Din), (hp, d_tgt, Din)], gqp, d_tgt, d_bits, E, Dm, gw, gw_group_stride=2 * Din * Dm,
                              group_ptr=d_ptr, G=T)
     gw32 = torch.zeros_like(gw)
     ops.gemm_wgrad_routed([(_dev(h), d_src), (_dev(h), d_tgt)], _dev(gq), d_tgt, d_arg, E, Dm, gw32, gw_group_stride=2 * Din * Dm,
@@ -342,5 +353,5 @@ def test_routed_gemms_bf16x6_match_fp64(ops, Din, Dm, sizes):
     err, err32 = float((gw.cpu().double() - ref_dW).abs().max()), float((gw32.cpu().double() - ref_dW).abs().max())
     assert err < 2e-6 * max(scale, 1.0) * 4 and err < 4 * err32 + 1e-6 * scale, (err, err32, scale)
     dA = ops.gemm_rows_x6([(gqp, d_tgt, Dm)], ops.pack_bf16x3(_dev(W).view(T * 2 * Din, Dm)), E, 2 * Din,
-                          b_group_stride=2 * Din * 3 * Dm, group_ptr=d_ptr, G=T, winner=d_arg)
+                          b_group_stride=2 * Din * 3 * Dm, group_ptr=d_ptr, G=T, win_bits=d_bits)
     assert float((dA.cpu().double() - ref_dA).abs().max()) < 2e-5

@@ -66,7 +66,6 @@ def main():
     gqp = ops.pack_bf16x3(gq)
     arg = torch.randint(0, E, (N, Dm), device="cuda", dtype=torch.int32)
     fns["fwd_x6"] = lambda: ops.gemm_rows_x6([(hp, src, Din), (hp, tgt, Din)], wtp, E, Dm, b_group_stride=Dm * 6 * Din, group_ptr=ptr, G=T_groups, group_w=gw_t)
-    fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, b_group_stride=2 * Din * 3 * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t, winner=arg)
     # a realistic winner table: every (node, channel) won by one of the node's incoming messages
     order = torch.argsort(tgt.long(), stable=True)
     first = torch.searchsorted(tgt.long()[order], torch.arange(N, device="cuda"))
@@ -74,9 +73,13 @@ def main():
     pick = (torch.rand(N, Dm, device="cuda") * deg.clamp(min=1)[:, None]).long().clamp(max=E - 1)
     arg_real = order[(first[:, None] + pick).clamp(max=E - 1)].to(torch.int32)
     arg_real[deg == 0] = -1
+    won = arg_real[tgt.long()] == torch.arange(E, device="cuda", dtype=torch.int32)[:, None]
+    wts = (1 << torch.arange(32, device="cuda", dtype=torch.int64))
+    bits_real = (won.view(E, Dm // 32, 32).long() * wts).sum(-1).to(torch.int32)   # low 32 bits, two's complement
     gw6 = torch.zeros_like(W)
     fns["wgrad_routed"] = lambda: ops.gemm_wgrad_routed([(h, src), (h, tgt)], gq, tgt, arg_real, E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
-    fns["wgrad_x6"] = lambda: ops.gemm_wgrad_routed_x6([(hp, src, Din), (hp, tgt, Din)], gqp, tgt, arg_real, E, Dm, gw6, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
+    fns["wgrad_x6"] = lambda: ops.gemm_wgrad_routed_x6([(hp, src, Din), (hp, tgt, Din)], gqp, tgt, bits_real, E, Dm, gw6, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
+    fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, b_group_stride=2 * Din * 3 * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t, win_bits=bits_real)
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
     fns["pack_wt"] = lambda: ops.pack_bf16x3_transposed(W)
     for name in a.which.split(","):
