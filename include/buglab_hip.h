@@ -151,11 +151,13 @@ int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, cons
 int bl_segment_max_bwd(const float* g_out, const int32_t* arg, const float* x, int32_t ldx, const int32_t* seg_of,
                        int32_t nitems, int32_t D, int32_t act, float* g_x, void* stream);
 
-/* LayerNorm backward (rows of D <= 512):  g_x (times post_scale elementwise if not NULL -- used to
- * fold the message activation's derivative `dact` in), and g_gamma/g_beta ACCUMULATED with fp32 atomics. */
+/* LayerNorm backward (rows of even D <= 512):  g_x (times post_scale elementwise if not NULL -- used to
+ * fold the message activation's derivative `dact` in), and g_gamma/g_beta ACCUMULATED with fp32 atomics.
+ * g_x_packed (if not NULL; D % 8 == 0) also receives the result in bl_pack_bf16x3's packed form, the
+ * operand of the bf16x6 routed GEMMs; g_x may then be NULL. */
 int bl_layernorm_bwd(const float* g_y, const float* x, const float* mean, const float* rstd, const float* gamma,
                      int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta, const float* post_scale,
-                     void* stream);
+                     uint16_t* g_x_packed, void* stream);
 
 /* activation(+dropout) backward from the OUTPUT y of y = drop(act(z + bias)); g_bias (if not NULL)
  * accumulates column sums of g_z with fp32 atomics.  g_z may alias g_y.  (GELU is not supported

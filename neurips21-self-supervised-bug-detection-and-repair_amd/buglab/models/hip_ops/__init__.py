@@ -53,7 +53,7 @@ _SIGNATURES = {
     "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gru_cell_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
@@ -393,15 +393,17 @@ def segment_max_bwd(g_out, arg, x, seg_of, act=ACT_NONE, out=None):
     return out
 
 
-def layernorm_bwd(g_y, x, mean, rstd, gamma, g_gamma, g_beta, post_scale=None):
+def layernorm_bwd(g_y, x, mean, rstd, gamma, g_gamma, g_beta, post_scale=None, want="f32"):
+    """want: "f32" -> g_x; "packed" -> bf16x3-packed g_x only (int16 [n, 3 D]); "both" -> (g_x, packed)."""
     n, D = x.shape
-    g_x = torch.empty_like(x)
+    g_x = torch.empty_like(x) if want != "packed" else None
+    g_xp = torch.empty((n, 3 * D), dtype=torch.int16, device=x.device) if want != "f32" else None
     _check(
         load_library().bl_layernorm_bwd(_f32(g_y).data_ptr(), _f32(x).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                        _f32(gamma).data_ptr(), int(n), int(D), g_x.data_ptr(), g_gamma.data_ptr(),
-                                        g_beta.data_ptr(), _p(post_scale), _stream()),
+                                        _f32(gamma).data_ptr(), int(n), int(D), _p(g_x), g_gamma.data_ptr(),
+                                        g_beta.data_ptr(), _p(post_scale), _p(g_xp), _stream()),
         "bl_layernorm_bwd")
-    return g_x
+    return g_x if want == "f32" else (g_xp if want == "packed" else (g_x, g_xp))
 
 
 def act_bwd(g_y, y, act, drop: Dropout = NO_DROPOUT, g_bias=None):
@@ -445,6 +447,15 @@ def join_side_stream():
         if key in _side_streams:
             torch.cuda.current_stream().wait_stream(_side_streams[key])
     _free_running = False
+
+
+def _direct_small(param):
+    """.grad of a small (bias / LayerNorm) parameter when the kernels may accumulate into it directly
+    (FlatAdam's flat gradient buffer): no zero-fill, no autograd accumulation kernel."""
+    g = getattr(param, "grad", None)
+    if DIRECT_PARAM_GRAD and g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
+        return g
+    return None
 
 
 def _direct_grad_target(param):
@@ -582,12 +593,12 @@ class _MpLayer(torch.autograd.Function):
         if msg_act == ACT_NONE:
             dact = None  # derivative is identically 1
         out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
-        ctx.saved = (h, hp, W, ln_g, Wd, dact, arg, bits, agg, mean, rstd, ln_out, out, g, msg_act, drop)
+        ctx.saved = (h, hp, W, ln_g, ln_b, Wd, bd, dact, arg, bits, agg, mean, rstd, ln_out, out, g, msg_act, drop)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        h, hp, W, ln_g, Wd, dact, arg, bits, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
+        h, hp, W, ln_g, ln_b, Wd, bd, dact, arg, bits, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
         ctx.saved = None
         N, Din = h.shape
         T, K2, Dm = W.shape
@@ -596,7 +607,8 @@ class _MpLayer(torch.autograd.Function):
         dev = h.device
         g_out = g_out.contiguous()
         # dense + tanh + dropout
-        g_bd = torch.zeros((Dout,), dtype=torch.float32, device=dev)
+        bd_direct, lng_direct, lnb_direct = _direct_small(bd), _direct_small(ln_g), _direct_small(ln_b)
+        g_bd = bd_direct if bd_direct is not None else torch.zeros((Dout,), dtype=torch.float32, device=dev)
         g_z = act_bwd(g_out, out, ACT_TANH, drop, g_bd)
         Wd_direct, W_direct = _direct_grad_target(Wd), _direct_grad_target(W)
         g_Wd = Wd_direct if Wd_direct is not None else torch.zeros_like(Wd)
@@ -606,14 +618,26 @@ class _MpLayer(torch.autograd.Function):
             gemm_wgrad([(ln_out, None)], g_z, N, Dout, g_Wd)
         g_ln = gemm_rows([(g_z, None)], Wd, N, Dm, b_is_nk=True, ldb=Dout)
         # LayerNorm
-        g_lng = torch.zeros((Dm,), dtype=torch.float32, device=dev)
-        g_lnb = torch.zeros((Dm,), dtype=torch.float32, device=dev)
-        # LayerNorm (+ the message activation's derivative at each winner): d loss / d (winning pre-activation) per node
-        gq = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact)
+        g_lng = lng_direct if lng_direct is not None else torch.zeros((Dm,), dtype=torch.float32, device=dev)
+        g_lnb = lnb_direct if lnb_direct is not None else torch.zeros((Dm,), dtype=torch.float32, device=dev)
+        # LayerNorm (+ the message activation's derivative at each winner): d loss / d (winning pre-activation) per node;
+        # the bf16x6 GEMMs take it packed, straight from the LayerNorm kernel
+        use_x6 = x6_ok(Din, Dm) and bits is not None
+        if use_x6 and hp is not None:
+            gq, gqp = None, layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact, want="packed")
+        elif use_x6:
+            gq, gqp = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact, want="both")
+        else:
+            gq, gqp = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact), None
+        if bd_direct is not None:
+            g_bd = None
+        if lng_direct is not None:
+            g_lng = None
+        if lnb_direct is not None:
+            g_lnb = None
         # per-edge-type weights; message m's gradient row = gq[tgt(m)] masked to the channels m won
         pair = _timed("mp_bwd_gemm_pair(wgrad||dgrad+node-sums)", 2.0 * (2.0 * E * K2 * Dm), span=True)
         pair.__enter__()
-        gqp = pack_bf16x3(gq) if x6_ok(Din, Dm) else None
         side2 = _on_side_stream(dev)
         with side2:
             if hp is not None:

@@ -90,3 +90,18 @@ __device__ __forceinline__ float bl_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---- bf16x3 split of an fp32 value (csrc/bl_gemm_x6.hip): x = hi + mid + lo up to 2^-27 |x| ------
+__device__ __forceinline__ uint16_t f2bf_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  h = f2bf_rne(x);
+  const float r1 = x - bf2f(h);  // exact
+  m = f2bf_rne(r1);
+  const float r2 = r1 - bf2f(m);  // exact
+  l = f2bf_rne(r2);
+}

@@ -33,20 +33,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define XBN 128
 #define XROW 13  // uint4 per LDS row: 4 k-groups x 3 planes + 1 pad
 
-__device__ __forceinline__ uint16_t f2bf_rne(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-
-__device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
-  h = f2bf_rne(x);
-  const float r1 = x - bf2f(h);  // exact
-  m = f2bf_rne(r1);
-  const float r2 = r1 - bf2f(m);  // exact
-  l = f2bf_rne(r2);
-}
 
 // ---- packing ------------------------------------------------------------------------------------
 // rows: out[r][kg][plane][j] = plane(x[r, 8 kg + j])

@@ -129,12 +129,14 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
       const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
       for (int i = 0; i < cnt; ++i) {
         const int e = __shfl(mine, i, 64);
+        uint32_t word = 0;  // lane w ends up holding word w of the item's mask: one store per item
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           const unsigned long long b = __ballot(barg[j] == e);  // padding lanes hold -1
-          if (lane == 0 && 2 * j < wpr) winbits[(size_t)e * wpr + 2 * j] = (uint32_t)b;
-          if (lane == 0 && 2 * j + 1 < wpr) winbits[(size_t)e * wpr + 2 * j + 1] = (uint32_t)(b >> 32);
+          if (lane == 2 * j) word = (uint32_t)b;
+          if (lane == 2 * j + 1) word = (uint32_t)(b >> 32);
         }
+        if (lane < wpr) winbits[(size_t)e * wpr + lane] = word;
       }
     }
   }
@@ -200,55 +202,93 @@ __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm backward: one wave per row (grid-stride), column sums reduced per block then atomics
-template <int NV>
+// LayerNorm backward: one wave per row, two rows in flight per wave (grid-stride); a lane owns the
+// channel PAIRS 2*lane + 128*j (+0, +1): float2 loads/stores, and the optional bf16x3-packed copy of
+// the result (the operand form of the bf16x6 GEMMs) is written as 32-bit stores.  Column sums are
+// reduced per block, then atomics.
+template <int NP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g_y, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int nrows, int D,
                                                             float* __restrict__ g_x, float* __restrict__ g_gamma,
                                                             float* __restrict__ g_beta,
-                                                            const float* __restrict__ post_scale) {
-  __shared__ float red[2][4][64 * NV];
+                                                            const float* __restrict__ post_scale,
+                                                            uint32_t* __restrict__ g_x_packed) {
+  __shared__ float red[2][4][128 * NP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nw = gridDim.x * 4;
-  float dg[NV], db[NV], gam[NV];
+  float2 dg[NP], db[NP], gam[NP];
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    dg[j] = 0.f; db[j] = 0.f;
-    const int d = lane + 64 * j;
-    gam[j] = d < D ? gamma[d] : 0.f;
+  for (int j = 0; j < NP; ++j) {
+    dg[j] = make_float2(0.f, 0.f);
+    db[j] = make_float2(0.f, 0.f);
+    const int d = 2 * lane + 128 * j;
+    gam[j] = d < D ? *reinterpret_cast<const float2*>(gamma + d) : make_float2(0.f, 0.f);
   }
   const float invD = 1.0f / (float)D;
-  for (int r = blockIdx.x * 4 + w; r < nrows; r += nw) {
-    const float mu = mean[r], rs = rstd[r];
-    float gy[NV], xh[NV];
-    float a = 0.f, b = 0.f;
+  const int halfD = D >> 1;
+  for (int r0 = (blockIdx.x * 4 + w) * 2; r0 < nrows; r0 += nw * 2) {
+    float2 gy[2][NP], xh[2][NP], ps[2][NP];
+    float mu[2], rs[2];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int d = lane + 64 * j;
-      if (d < D) {
-        gy[j] = g_y[(size_t)r * D + d];
-        xh[j] = (x[(size_t)r * D + d] - mu) * rs;
-      } else { gy[j] = 0.f; xh[j] = 0.f; }
-      const float gg = gy[j] * gam[j];
-      a += gg; b += gg * xh[j];
-      dg[j] += gy[j] * xh[j]; db[j] += gy[j];
+    for (int q = 0; q < 2; ++q) {
+      const int r = min(r0 + q, nrows - 1);
+      mu[q] = mean[r];
+      rs[q] = rstd[r];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int d = 2 * lane + 128 * j;
+        const bool ok = d < D;
+        gy[q][j] = ok ? *reinterpret_cast<const float2*>(g_y + (size_t)r * D + d) : make_float2(0.f, 0.f);
+        xh[q][j] = ok ? *reinterpret_cast<const float2*>(x + (size_t)r * D + d) : make_float2(0.f, 0.f);
+        ps[q][j] = (ok && post_scale) ? *reinterpret_cast<const float2*>(post_scale + (size_t)r * D + d) : make_float2(1.f, 1.f);
+      }
     }
-    a = bl_wave_sum(a) * invD;
-    b = bl_wave_sum(b) * invD;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int d = lane + 64 * j;
-      if (d < D) {
-        float gx = rs * (gy[j] * gam[j] - a - xh[j] * b);
-        if (post_scale) gx *= post_scale[(size_t)r * D + d];
-        g_x[(size_t)r * D + d] = gx;
+    for (int q = 0; q < 2; ++q) {
+      const int r = r0 + q;
+      if (r >= nrows) break;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const bool ok = 2 * lane + 128 * j < D;
+        xh[q][j].x = ok ? (xh[q][j].x - mu[q]) * rs[q] : 0.f;
+        xh[q][j].y = ok ? (xh[q][j].y - mu[q]) * rs[q] : 0.f;
+        const float g0 = gy[q][j].x * gam[j].x, g1 = gy[q][j].y * gam[j].y;
+        a += g0 + g1;
+        b += g0 * xh[q][j].x + g1 * xh[q][j].y;
+        dg[j].x += gy[q][j].x * xh[q][j].x; dg[j].y += gy[q][j].y * xh[q][j].y;
+        db[j].x += gy[q][j].x; db[j].y += gy[q][j].y;
+      }
+      a = bl_wave_sum(a) * invD;
+      b = bl_wave_sum(b) * invD;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int d = 2 * lane + 128 * j;
+        if (d < D) {
+          float2 gx;
+          gx.x = rs[q] * (gy[q][j].x * gam[j].x - a - xh[q][j].x * b) * ps[q][j].x;
+          gx.y = rs[q] * (gy[q][j].y * gam[j].y - a - xh[q][j].y * b) * ps[q][j].y;
+          if (g_x) *reinterpret_cast<float2*>(g_x + (size_t)r * D + d) = gx;
+          if (g_x_packed) {
+            uint16_t h0, m0, l0, h1, m1, l1;
+            split3(gx.x, h0, m0, l0);
+            split3(gx.y, h1, m1, l1);
+            uint32_t* o = g_x_packed + (size_t)r * 3 * halfD + (d >> 1);
+            o[0] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            o[halfD] = (uint32_t)m0 | ((uint32_t)m1 << 16);
+            o[2 * halfD] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+          }
+        }
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < NV; ++j) { red[0][w][lane + 64 * j] = dg[j]; red[1][w][lane + 64 * j] = db[j]; }
+  for (int j = 0; j < NP; ++j) {
+    red[0][w][2 * lane + 128 * j] = dg[j].x; red[0][w][2 * lane + 128 * j + 1] = dg[j].y;
+    red[1][w][2 * lane + 128 * j] = db[j].x; red[1][w][2 * lane + 128 * j + 1] = db[j].y;
+  }
   __syncthreads();
   for (int d = threadIdx.x; d < D; d += 256) {
     unsafeAtomicAdd(&g_gamma[d], red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
@@ -258,7 +298,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------
 // backward through y = drop(act(z + bias)) from y; column sums -> g_bias
-// 256 threads = (256 / tpr) rows x tpr float4-columns (tpr = power of two >= N/4), 128 rows per block
+// 256 threads = (256 / tpr) rows x tpr float4-columns (tpr = power of two >= N/4), ACT_BWD_ROWS rows per
+// block, four independent rows of loads in flight per thread
+#define ACT_BWD_ROWS 64
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const float* __restrict__ y, int nrows, int N,
                                                       int ld, int act, bl_drop_dev drop, float* g_z,
                                                       float* __restrict__ g_bias, int tpr_log2) {
@@ -269,26 +311,36 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const fl
   const int c = (blockIdx.y * tpr + tx) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < N) {
-    const int r_end = min(nrows, (int)(blockIdx.x + 1) * 128);
-    for (int r = blockIdx.x * 128 + ty; r < r_end; r += rows_per_iter) {
-      const size_t o = (size_t)r * ld + c;
-      float4 g = *reinterpret_cast<const float4*>(g_y + o);
-      const float4 yv = *reinterpret_cast<const float4*>(y + o);
-      float yy[4] = {yv.x, yv.y, yv.z, yv.w};
-      float gg[4] = {g.x, g.y, g.z, g.w};
+    const int r_end = min(nrows, (int)(blockIdx.x + 1) * ACT_BWD_ROWS);
+    for (int r0 = blockIdx.x * ACT_BWD_ROWS + ty; r0 < r_end; r0 += 4 * rows_per_iter) {
+      float4 gin[4], yin[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float yu = yy[u];
-        if (drop.thresh) {
-          const bool keep = bl_keep(drop, (uint32_t)r * (uint32_t)N + (uint32_t)(c + u));
-          gg[u] = keep ? gg[u] * drop.scale : 0.f;
-          yu = yu * (1.0f / drop.scale);  // undo the dropout scale to recover act(z)
-        }
-        gg[u] *= bl_act_grad_from_out(act, yu);
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + q * rows_per_iter;
+        const size_t o = (size_t)(r < r_end ? r : r0) * ld + c;
+        gin[q] = *reinterpret_cast<const float4*>(g_y + o);
+        yin[q] = *reinterpret_cast<const float4*>(y + o);
       }
-      g = make_float4(gg[0], gg[1], gg[2], gg[3]);
-      *reinterpret_cast<float4*>(g_z + o) = g;
-      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + q * rows_per_iter;
+        if (r >= r_end) break;
+        float yy[4] = {yin[q].x, yin[q].y, yin[q].z, yin[q].w};
+        float gg[4] = {gin[q].x, gin[q].y, gin[q].z, gin[q].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float yu = yy[u];
+          if (drop.thresh) {
+            const bool keep = bl_keep(drop, (uint32_t)r * (uint32_t)N + (uint32_t)(c + u));
+            gg[u] = keep ? gg[u] * drop.scale : 0.f;
+            yu = yu * (1.0f / drop.scale);  // undo the dropout scale to recover act(z)
+          }
+          gg[u] *= bl_act_grad_from_out(act, yu);
+        }
+        const float4 g = make_float4(gg[0], gg[1], gg[2], gg[3]);
+        *reinterpret_cast<float4*>(g_z + (size_t)r * ld + c) = g;
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+      }
     }
   }
   if (g_bias) {
@@ -501,14 +553,18 @@ extern "C" int bl_segment_max_bwd(const float* g_out, const int32_t* arg, const 
 
 extern "C" int bl_layernorm_bwd(const float* g_y, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta,
-                                const float* post_scale, void* stream) {
+                                const float* post_scale, uint16_t* g_x_packed, void* stream) {
   if (nrows == 0) return BL_OK;
-  BL_CHECK_ARG(g_y && x && mean && rstd && gamma && g_x && g_gamma && g_beta, "bl_layernorm_bwd: null pointer");
-  BL_CHECK_ARG(D > 0 && D <= 512, "bl_layernorm_bwd: D must be in 1..512");
-  const int blocks = min((nrows + 3) / 4, 1024);
+  BL_CHECK_ARG(g_y && x && mean && rstd && gamma && (g_x || g_x_packed) && g_gamma && g_beta, "bl_layernorm_bwd: null pointer");
+  BL_CHECK_ARG(D > 0 && D <= 512 && D % 2 == 0, "bl_layernorm_bwd: D must be even and in 2..512 (got %d)", D);
+  BL_CHECK_ARG(g_x_packed == nullptr || D % 8 == 0, "bl_layernorm_bwd: the packed output needs D %% 8 == 0");
+  const int blocks = min((nrows + 7) / 8, 2048);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd,
-                                     gamma, nrows, D, g_x, g_gamma, g_beta, post_scale))
+  uint32_t* gp = reinterpret_cast<uint32_t*>(g_x_packed);
+#define LN_BWD_GO(NP_) hipLaunchKernelGGL((layernorm_bwd_kernel<NP_>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd, gamma, nrows, D, g_x, g_gamma, g_beta, post_scale, gp)
+  if (D <= 128) LN_BWD_GO(1);
+  else if (D <= 256) LN_BWD_GO(2);
+  else LN_BWD_GO(4);
   BL_LAUNCH_CHECK("bl_layernorm_bwd");
   return BL_OK;
 }
@@ -521,7 +577,7 @@ extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32
   BL_CHECK_ARG(act != BL_ACT_GELU, "bl_act_bwd: GELU needs the pre-activation (use bl_segment_max_bwd)");
   int tpr_log2 = 0;
   while ((1 << tpr_log2) < N / 4 && tpr_log2 < 8) ++tpr_log2;
-  dim3 grid((nrows + 127) / 128, (N / 4 + (1 << tpr_log2) - 1) >> tpr_log2);
+  dim3 grid((nrows + ACT_BWD_ROWS - 1) / ACT_BWD_ROWS, (N / 4 + (1 << tpr_log2) - 1) >> tpr_log2);
   hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g_y, y, nrows, N, ld, act,
                      bl_make_drop(drop), g_z, g_bias, tpr_log2);
   BL_LAUNCH_CHECK("bl_act_bwd");
