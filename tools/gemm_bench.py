@@ -46,8 +46,18 @@ def main():
         ptr = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32).cuda()
         gw_t = torch.tensor(np.tile(np.arange(T), nchunk), dtype=torch.int32).cuda()
         T_groups = nchunk * T
+
+        def tile_map(piece):
+            gp = np.concatenate([[0], np.cumsum(counts)])
+            nt = (counts + piece - 1) // piece
+            grp = np.repeat(np.arange(len(counts)), nt)
+            first = np.arange(nt.sum()) - np.repeat(np.cumsum(nt) - nt, nt)
+            return torch.tensor(np.stack([grp, gp[grp] + first * piece], 1), dtype=torch.int32).cuda()
+
+        tm128, tm1024 = tile_map(128), tile_map(1024)
     else:
         T_groups = T
+        tm128 = tm1024 = None
     h = torch.randn(N, Din, device="cuda")
     W = torch.randn(T, 2 * Din, Dm, device="cuda") / np.sqrt(2 * Din)
     G = torch.randn(E, Dm, device="cuda")
@@ -78,7 +88,7 @@ def main():
     bits_real = (won.view(E, Dm // 32, 32).long() * wts).sum(-1).to(torch.int32)   # low 32 bits, two's complement
     gw6 = torch.zeros_like(W)
     fns["wgrad_routed"] = lambda: ops.gemm_wgrad_routed([(h, src), (h, tgt)], gq, tgt, arg_real, E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
-    fns["wgrad_x6"] = lambda: ops.gemm_wgrad_routed_x6([(hp, src, Din), (hp, tgt, Din)], gqp, tgt, bits_real, E, Dm, gw6, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
+    fns["wgrad_x6"] = lambda: ops.gemm_wgrad_routed_x6([(hp, src, Din), (hp, tgt, Din)], gqp, tgt, bits_real, E, Dm, gw6, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t)
     fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, b_group_stride=2 * Din * 3 * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t, win_bits=bits_real)
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
     fns["pack_wt"] = lambda: ops.pack_bf16x3_transposed(W)
