@@ -143,8 +143,10 @@ __device__ __forceinline__ uint4 keep_from_bits(uint32_t b) {
   return k;
 }
 
+// The plain form fits three workgroups per CU (3 x 52 KB of LDS, <= 168 registers); the routed form
+// keeps its routing bytes and masks in registers and runs two.
 template <bool MASKED>
-__global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
+__global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
     int koff1, int koff2, int nsrc, const uint32_t* __restrict__ win_bits, int ld_bits, const uint4* __restrict__ bp,
@@ -152,7 +154,6 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
     float* __restrict__ c, int ldc, int xcd_remap) {
   __shared__ uint4 As[XBM * XROW];
   __shared__ uint4 Bs[XBN * XROW];
-  __shared__ int rowidx[3][XBM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g, row0, nrows, tile_y;
@@ -162,16 +163,17 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
   const uint4* __restrict__ Bg = bp + (long long)wsel * strideB;  // [N][K/8][3] uint4
   const int kgK = K >> 3;                                          // k-groups per B row
 
-  if (tid < XBM) {
-    const int r = row0 + min(tid, nrows - 1);
-    rowidx[0][tid] = idx0 ? idx0[r] : r;
-    if (nsrc > 1) rowidx[1][tid] = idx1 ? idx1[r] : r;
-    if (nsrc > 2) rowidx[2][tid] = idx2 ? idx2[r] : r;
-  }
-  __syncthreads();
-
-  // loader mapping: (row, k-group) pairs, 2 per thread; 4 consecutive lanes cover one row's 192 bytes
+  // loader mapping: (row, k-group) pairs, 2 per thread; 4 consecutive lanes cover one row's 64-byte
+  // plane segment.  Gathered row ids live in registers (one per piece and source).
   const int p_kg = tid & 3, p_row0 = tid >> 2;  // rows p_row0 and p_row0 + 64
+  int gr0[2], gr1[2], gr2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = row0 + min(p_row0 + 64 * i, nrows - 1);
+    gr0[i] = idx0 ? idx0[r] : r;
+    gr1[i] = nsrc > 1 ? (idx1 ? idx1[r] : r) : 0;
+    gr2[i] = nsrc > 2 ? (idx2 ? idx2[r] : r) : 0;
+  }
   uint4 ra[2][3], rb[2][3];
   uint32_t ma[2];
   const int nk = (K + 31) / 32;
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x6_kernel(
     const int wj_ = j_ == 0 ? w0 : (j_ == 1 ? w1 : w2);                                                       \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
       const int row_ = p_row0 + 64 * i;                                                                       \
-      const uint4* src_ = base_ + (size_t)rowidx[j_][row_] * 3 * (wj_ >> 3) + (kl_ >> 3);                     \
+      const int gr_ = j_ == 0 ? gr0[i] : (j_ == 1 ? gr1[i] : gr2[i]);                                         \
+      const uint4* src_ = base_ + (size_t)gr_ * 3 * (wj_ >> 3) + (kl_ >> 3);                                  \
       ra[i][0] = src_[0];                                                                                     \
       ra[i][1] = src_[wj_ >> 3];                                                                              \
       ra[i][2] = src_[2 * (wj_ >> 3)];                                                                        \
@@ -499,6 +502,7 @@ extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bi
                "bl_gemm_rows_x6: the routed form needs exactly one gathered source and ld_bits >= K / 32");
   dim3 grid((M + XBM - 1) / XBM + (group_ptr ? G : 0), (N + XBN - 1) / XBN);
   static const int xcd = getenv("BL_XCD_REMAP") ? atoi(getenv("BL_XCD_REMAP")) : 1;
+  static const int pad_lds = getenv("BL_X6_PAD_LDS") ? atoi(getenv("BL_X6_PAD_LDS")) : 0;  // tuning: caps workgroups/CU
   const uint4* x0 = reinterpret_cast<const uint4*>(a->xp[0]);
   const uint4* x1 = a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr;
   const uint4* x2 = a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr;
@@ -509,7 +513,7 @@ extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bi
   if (win_bits)
     hipLaunchKernelGGL((gemm_rows_x6_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
   else
-    hipLaunchKernelGGL((gemm_rows_x6_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false>), grid, dim3(256), pad_lds, (hipStream_t)stream, X6_ARGS);
   BL_LAUNCH_CHECK("bl_gemm_rows_x6");
   return BL_OK;
 }
