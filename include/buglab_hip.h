@@ -94,7 +94,7 @@ int bl_gemm_rows_routed(const bl_rows_t* a, const int32_t* winner, int32_t ld_wi
  * three bf16 terms hi + mid + lo (bl_pack_bf16x3*: every row is three bf16 planes back to
  * back, [hi x D | mid x D | lo x D]) and a product is evaluated as the six MFMA terms hh + hm + mh + hl + lh + mm
  * with fp32 accumulation; dropped terms are < 2^-26 of the product, below fp32's own rounding.
- * Same contract as bl_gemm_rows with b_is_nk = 1 (B_g given as [N, K], i.e. C = A . B_g^T), no
+ * Same contract as bl_gemm_rows (C[rows of g] = A . B_g), B given by bl_pack_weights_x6, no
  * bias/activation epilogue.  win_bits != NULL selects the routed left operand of bl_gemm_rows_routed,
  * with the routing given as bl_segment_max_fwd's per-message bitmask (row r keeps channel k iff bit k
  * of win_bits[r * ld_bits ...] is set; ld_bits in 32-bit words).  Source widths: multiples of 32. */
@@ -105,8 +105,11 @@ typedef struct {
   int32_t nsrc;
 } bl_rows_packed_t;
 int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, uint16_t* out, void* stream);
-/* w [G][K][N] fp32 -> out [G][N][3][K]: the [N, K] (transposed) packed form bl_gemm_rows_x6 takes as B */
-int bl_pack_bf16x3_transposed(const float* w, int32_t G, int32_t K, int32_t N, uint16_t* out, void* stream);
+/* Weights of the bf16x6 row GEMM, packed and TILED: per group ceil(N/128) * (K/32) blocks of 24 KB
+ * (12288 uint16), block (tile, stage) = [i (2)][plane (3)][row_lo (64)][k-group (4)][8] for column
+ * n = 128 tile + 64 i + row_lo and k = 32 stage + 8 k-group + 0..7; columns past N are zero.
+ * w is [G][K][N] if w_is_kn (forward weights W[t]: C = A . W) or [G][N][K] (C = A . w^T). */
+int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t N, int32_t w_is_kn, uint16_t* out, void* stream);
 int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                     int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
                     int32_t N, int32_t K, float* c, int32_t ldc, void* stream);

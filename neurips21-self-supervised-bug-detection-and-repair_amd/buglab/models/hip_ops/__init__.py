@@ -46,7 +46,7 @@ _SIGNATURES = {
     "bl_gemm_rows": ([POINTER(bl_rows_t), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_pack_bf16x3_transposed": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_pack_weights_x6": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
@@ -244,17 +244,18 @@ def pack_bf16x3(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pack_bf16x3_transposed(w: torch.Tensor) -> torch.Tensor:
-    """fp32 [G, K, N] -> packed int16 [G, N, 3 * K] (the [N, K] operand form of gemm_rows_x6)."""
+def pack_weights_x6(w: torch.Tensor, w_is_kn: bool) -> torch.Tensor:
+    """fp32 weights -> the tiled packed B operand of gemm_rows_x6 (int16 [G, tiles * stages * 12288]).
+    w is [G, K, N] when w_is_kn (C = A @ w[g]) or [G, N, K] (C = A @ w[g]^T)."""
     _f32(w, "w")
-    G, K, N = w.shape
-    out = torch.empty((G, N, 3 * K), dtype=torch.int16, device=w.device)
-    _check(load_library().bl_pack_bf16x3_transposed(w.data_ptr(), G, K, N, out.data_ptr(), _stream()), "bl_pack_bf16x3_transposed")
+    G, K, N = (w.shape[0], w.shape[1], w.shape[2]) if w_is_kn else (w.shape[0], w.shape[2], w.shape[1])
+    out = torch.empty((G, ((N + 127) // 128) * (K // 32) * 12288), dtype=torch.int16, device=w.device)
+    _check(load_library().bl_pack_weights_x6(w.data_ptr(), G, K, N, 1 if w_is_kn else 0, out.data_ptr(), _stream()), "bl_pack_weights_x6")
     return out
 
 
-def gemm_rows_x6(sources, bp, M, N, *, b_group_stride=0, group_ptr=None, group_w=None, G=1, win_bits=None, kind="gemm_rows_x6"):
-    """sources: [(packed int16 [*, 3*width], row index or None, width)]; bp: packed [G, N, 3K] (or [N, 3K]);
+def gemm_rows_x6(sources, bp, M, N, *, group_ptr=None, group_w=None, G=1, win_bits=None, kind="gemm_rows_x6"):
+    """sources: [(packed int16 [*, 3*width], row index or None, width)]; bp: pack_weights_x6 output [G, *];
     win_bits: segment_max's per-row routing bitmask -> the routed (winner-masked) left operand."""
     r = bl_rows_packed_t()
     K = 0
@@ -271,7 +272,7 @@ def gemm_rows_x6(sources, bp, M, N, *, b_group_stride=0, group_ptr=None, group_w
     with _timed(kind + ("_grouped" if group_ptr is not None else ""), 2.0 * M * N * K):
         _check(
             load_library().bl_gemm_rows_x6(ctypes.byref(r), _p(win_bits), win_bits.stride(0) if win_bits is not None else 0,
-                                           _req(bp, torch.int16, "bp").data_ptr(), int(b_group_stride), _p(group_ptr), _p(group_w),
+                                           _req(bp, torch.int16, "bp").data_ptr(), int(bp.stride(0)), _p(group_ptr), _p(group_w),
                                            int(G), int(M), int(N), int(K), out.data_ptr(), out.stride(0), _stream()),
             "bl_gemm_rows_x6")
     return out
@@ -573,9 +574,8 @@ class _MpLayer(torch.autograd.Function):
         assert K2 == 2 * Din and T == g.num_types and N == g.num_nodes
         if x6_ok(Din, Dm):
             hp = pack_bf16x3(h)                   # [N, 3*Din]
-            wtp = pack_bf16x3_transposed(_f32(W, "W"))  # [T, Dm, 3*K2]
-            pre = gemm_rows_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din)], wtp, E, Dm, b_group_stride=Dm * 3 * K2,
-                               group_ptr=g.type_ptr, G=T)
+            wtp = pack_weights_x6(_f32(W, "W"), True)
+            pre = gemm_rows_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din)], wtp, E, Dm, group_ptr=g.type_ptr, G=T)
             del wtp
             if not WGRAD_X6:
                 hp = None
@@ -648,9 +648,9 @@ class _MpLayer(torch.autograd.Function):
                                   group_ptr=g.type_ptr, G=T)
         # node states: per-message input gradients, then segmented sums over the src / tgt CSRs
         if gqp is not None:
-            # d a = G . W_t^T: B_g = W_t itself as [n = 2*Din, k = Dm], row-packed
-            g_a = gemm_rows_x6([(gqp, g.msg_tgt, Dm)], pack_bf16x3(W.view(T * K2, Dm)), E, K2,
-                               b_group_stride=K2 * 3 * Dm, group_ptr=g.type_ptr, G=T, win_bits=bits, kind="gemm_rows_nk_routed_x6")
+            # d a = G . W_t^T: B_g = W_t itself read as [n = 2*Din, k = Dm]
+            g_a = gemm_rows_x6([(gqp, g.msg_tgt, Dm)], pack_weights_x6(W, False), E, K2, group_ptr=g.type_ptr, G=T,
+                               win_bits=bits, kind="gemm_rows_nk_routed_x6")
         else:
             g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K2, b_group_stride=K2 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
         g_h = torch.empty((N, Din), dtype=torch.float32, device=dev)

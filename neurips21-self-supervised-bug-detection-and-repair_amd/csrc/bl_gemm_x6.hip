@@ -56,23 +56,38 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
   o[2 * kgn] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
 }
 
-// transposed weights: w [G][K][N] fp32 -> out[g][n][kg][plane][j] = plane(w[g][8 kg + j][n])
-__global__ __launch_bounds__(256) void pack_transposed_kernel(const float* __restrict__ w, int G, int K, int N,
-                                                              uint4* __restrict__ out) {
-  const int kgn = K >> 3;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)G * N * kgn) return;
-  // consecutive threads -> consecutive n (coalesced reads of the fp32 rows)
-  const int n = (int)(t % N);
-  const int kg = (int)((t / N) % kgn);
-  const int g = (int)(t / ((long long)N * kgn));
+// The B operand (weights) is packed TILED: for every group, 128-column tile and 32-k stage one
+// contiguous 24 KB block, ordered [i (2)][plane (3)][row_lo (64)][k-group (4)] x 8 bf16, column
+// n = 64 i + row_lo of the tile.  Thread t of the GEMM reads uint4s t, t + 256, ... of the block: every
+// wave-load is 1 KB contiguous, and the block's 24 KB spread over all L2 channels.  With the row-major
+// packed form ([n][plane][K], 16 x 64-byte pieces per wave-load, the same few lines requested by every
+// workgroup of an edge type at once) the B loads cost 1.8x more (load-only microbenchmark, c2 shapes:
+// 0.082 -> 0.045 ms per GEMM).  Columns past N are zero.
+// w is [G][K][N] (w_is_kn = 1: the forward weights, transposed on the fly) or [G][N][K] (w_is_kn = 0).
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int G, int K, int N, int w_is_kn,
+                                                           uint4* __restrict__ out) {
+  const int nst = K >> 5, ntn = (N + 127) >> 7;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one (g, tile, stage, i, row_lo, kg)
+  if (t >= (long long)G * ntn * nst * 512) return;
+  int r = (int)(t & 511);
+  const long long blk = t >> 9;
+  const int st = (int)(blk % nst), tile = (int)((blk / nst) % ntn), g = (int)(blk / ((long long)nst * ntn));
+  // consecutive threads -> consecutive n when the source is [K][N] (coalesced), consecutive k-groups otherwise
+  int i, row_lo, kg;
+  if (w_is_kn) { row_lo = r & 63; i = (r >> 6) & 1; kg = r >> 7; }
+  else { kg = r & 3; row_lo = (r >> 2) & 63; i = r >> 8; }
+  const int n = tile * 128 + 64 * i + row_lo, k0 = st * 32 + 8 * kg;
   uint16_t h[8], m[8], l[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) split3(w[((size_t)g * K + 8 * kg + j) * N + n], h[j], m[j], l[j]);
-  uint4* o = out + ((size_t)g * N + n) * 3 * kgn + kg;
+  for (int j = 0; j < 8; ++j) {
+    float v = 0.f;
+    if (n < N) v = w_is_kn ? w[((size_t)g * K + k0 + j) * N + n] : w[((size_t)g * N + n) * K + k0 + j];
+    split3(v, h[j], m[j], l[j]);
+  }
+  uint4* o = out + (size_t)blk * 1536 + i * 768 + row_lo * 4 + kg;
   o[0] = make_uint4(PK(h[0], h[1]), PK(h[2], h[3]), PK(h[4], h[5]), PK(h[6], h[7]));
-  o[kgn] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
-  o[2 * kgn] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
+  o[256] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
+  o[512] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
 }
 
 // ---- GEMM -----------------------------------------------------------------------------------------
@@ -160,8 +175,8 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
   if (!x6_locate(group_ptr, G, M, XBM, xcd_remap, tile_y, g, row0, nrows)) return;
   const int n0 = tile_y * XBN;
   const int wsel = group_w ? group_w[g] : g;
-  const uint4* __restrict__ Bg = bp + (long long)wsel * strideB;  // [N][K/8][3] uint4
-  const int kgK = K >> 3;                                          // k-groups per B row
+  // tiled packed weights: this workgroup's 24 KB stage blocks, thread t reads uint4s t + 256 q
+  const uint4* __restrict__ Bt = bp + (long long)wsel * strideB + (size_t)tile_y * (K >> 5) * 1536 + tid;
 
   // loader mapping: (row, k-group) pairs, 2 per thread; 4 consecutive lanes cover one row's 64-byte
   // plane segment.  Gathered row ids live in registers (one per piece and source).
@@ -196,11 +211,10 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
       ra[i][1] = src_[wj_ >> 3];                                                                              \
       ra[i][2] = src_[2 * (wj_ >> 3)];                                                                        \
       if (MASKED) ma[i] = win_bits[(size_t)(row0 + min(row_, nrows - 1)) * ld_bits + (kc_ >> 5)];              \
-      const int n_ = n0 + row_;                                                                               \
-      const uint4* bsrc_ = Bg + (size_t)(n_ < N ? n_ : 0) * 3 * kgK + (kc_ >> 3);                             \
+      const uint4* bsrc_ = Bt + (size_t)((k0_) >> 5) * 1536 + i * 768;                                        \
       rb[i][0] = bsrc_[0];                                                                                    \
-      rb[i][1] = bsrc_[kgK];                                                                                  \
-      rb[i][2] = bsrc_[2 * kgK];                                                                              \
+      rb[i][1] = bsrc_[256];                                                                                  \
+      rb[i][2] = bsrc_[512];                                                                                  \
     }                                                                                                         \
   }
 #define X6_STORE_STAGE(k0_)                                                                                   \
@@ -471,14 +485,15 @@ extern "C" int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, 
   return BL_OK;
 }
 
-extern "C" int bl_pack_bf16x3_transposed(const float* w, int32_t G, int32_t K, int32_t N, uint16_t* out, void* stream) {
+extern "C" int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t N, int32_t w_is_kn, uint16_t* out,
+                                  void* stream) {
   if (G == 0) return BL_OK;
-  BL_CHECK_ARG(w && out && bl_aligned16(out), "bl_pack_bf16x3_transposed: null or misaligned pointer");
-  BL_CHECK_ARG(K > 0 && K % 8 == 0 && N > 0, "bl_pack_bf16x3_transposed: K must be a multiple of 8");
-  const long long total = (long long)G * N * (K / 8);
-  hipLaunchKernelGGL(pack_transposed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, G,
-                     K, N, reinterpret_cast<uint4*>(out));
-  BL_LAUNCH_CHECK("bl_pack_bf16x3_transposed");
+  BL_CHECK_ARG(w && out && bl_aligned16(out), "bl_pack_weights_x6: null or misaligned pointer");
+  BL_CHECK_ARG(K > 0 && K % 32 == 0 && N > 0, "bl_pack_weights_x6: K must be a multiple of 32 (got %d)", K);
+  const long long total = (long long)G * ((N + 127) / 128) * (K / 32) * 512;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, G, K,
+                     N, w_is_kn, reinterpret_cast<uint4*>(out));
+  BL_LAUNCH_CHECK("bl_pack_weights_x6");
   return BL_OK;
 }
 
@@ -497,7 +512,8 @@ extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bi
   BL_CHECK_ARG(off == K, "bl_gemm_rows_x6: K (%d) != sum of source widths (%d)", K, off);
   BL_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0 && bp && c && bl_aligned16(bp) && bl_aligned16(c),
                "bl_gemm_rows_x6: N/ldc multiples of 4, aligned pointers required");
-  BL_CHECK_ARG(b_group_stride % 8 == 0, "bl_gemm_rows_x6: packed group stride must be a multiple of 8 elements");
+  BL_CHECK_ARG(b_group_stride % 8 == 0 && (G <= 1 || b_group_stride >= (int64_t)((N + 127) / 128) * (K / 32) * 12288),
+               "bl_gemm_rows_x6: packed group stride must cover one group's tiled weights (bl_pack_weights_x6)");
   BL_CHECK_ARG(win_bits == nullptr || (a->nsrc == 1 && a->idx[0] && ld_bits * 32 >= K),
                "bl_gemm_rows_x6: the routed form needs exactly one gathered source and ld_bits >= K / 32");
   dim3 grid((M + XBM - 1) / XBM + (group_ptr ? G : 0), (N + XBN - 1) / XBN);

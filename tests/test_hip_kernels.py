@@ -309,8 +309,8 @@ def test_gemm_rows_bf16x6_is_fp32_accurate(ops, Din, Dm, sizes):
     vals = (planes << 16).view(torch.float32) if False else torch.from_numpy((planes.numpy().astype(np.uint32) << 16).view(np.float32))
     recon = vals[:, :, 0, :] .double() + vals[:, :, 1, :].double() + vals[:, :, 2, :].double()
     assert (recon.reshape(N, Din) - h.double()).abs().max() <= 2.0 ** -24 * float(h.abs().max())
-    out = ops.gemm_rows_x6([(hp, _dev(src), Din), (hp, _dev(tgt), Din)], ops.pack_bf16x3_transposed(_dev(W)), E, Dm,
-                           b_group_stride=Dm * 3 * 2 * Din, group_ptr=_dev(ptr), G=T)
+    out = ops.gemm_rows_x6([(hp, _dev(src), Din), (hp, _dev(tgt), Din)], ops.pack_weights_x6(_dev(W), True), E, Dm,
+                           group_ptr=_dev(ptr), G=T)
     err = (out.cpu().double() - ref).abs().max()
     exact = ops.gemm_rows([(_dev(h), _dev(src)), (_dev(h), _dev(tgt))], _dev(W), E, Dm, b_group_stride=2 * Din * Dm, ldb=Dm, group_ptr=_dev(ptr), G=T)
     err32 = (exact.cpu().double() - ref).abs().max()
@@ -358,6 +358,5 @@ def test_routed_gemms_bf16x6_match_fp64(ops, Din, Dm, sizes):
     scale = float(ref_dW.abs().max())
     err, err32 = float((gw.cpu().double() - ref_dW).abs().max()), float((gw32.cpu().double() - ref_dW).abs().max())
     assert err < 2e-6 * max(scale, 1.0) * 4 and err < 4 * err32 + 1e-6 * scale, (err, err32, scale)
-    dA = ops.gemm_rows_x6([(gqp, d_tgt, Dm)], ops.pack_bf16x3(_dev(W).view(T * 2 * Din, Dm)), E, 2 * Din,
-                          b_group_stride=2 * Din * 3 * Dm, group_ptr=d_ptr, G=T, win_bits=d_bits)
+    dA = ops.gemm_rows_x6([(gqp, d_tgt, Dm)], ops.pack_weights_x6(_dev(W), False), E, 2 * Din, group_ptr=d_ptr, G=T, win_bits=d_bits)
     assert float((dA.cpu().double() - ref_dA).abs().max()) < 2e-5

@@ -71,11 +71,11 @@ def main():
         "nk": lambda: ops.gemm_rows([(G, None)], W, E, 2 * Din, b_is_nk=True, b_group_stride=2 * Din * Dm, ldb=Dm, group_ptr=ptr, G=T, out=ga),
         "wgrad": lambda: ops.gemm_wgrad([(h, src), (h, tgt)], G, E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T),
     }
-    hp, wtp, wp = ops.pack_bf16x3(h), ops.pack_bf16x3_transposed(W), ops.pack_bf16x3(W.view(T * 2 * Din, Dm))
+    hp, wtp, wp = ops.pack_bf16x3(h), ops.pack_weights_x6(W, True), ops.pack_weights_x6(W, False)
     gq = torch.randn(N, Dm, device="cuda")
     gqp = ops.pack_bf16x3(gq)
     arg = torch.randint(0, E, (N, Dm), device="cuda", dtype=torch.int32)
-    fns["fwd_x6"] = lambda: ops.gemm_rows_x6([(hp, src, Din), (hp, tgt, Din)], wtp, E, Dm, b_group_stride=Dm * 6 * Din, group_ptr=ptr, G=T_groups, group_w=gw_t)
+    fns["fwd_x6"] = lambda: ops.gemm_rows_x6([(hp, src, Din), (hp, tgt, Din)], wtp, E, Dm, group_ptr=ptr, G=T_groups, group_w=gw_t)
     # a realistic winner table: every (node, channel) won by one of the node's incoming messages
     order = torch.argsort(tgt.long(), stable=True)
     first = torch.searchsorted(tgt.long()[order], torch.arange(N, device="cuda"))
@@ -89,9 +89,9 @@ def main():
     gw6 = torch.zeros_like(W)
     fns["wgrad_routed"] = lambda: ops.gemm_wgrad_routed([(h, src), (h, tgt)], gq, tgt, arg_real, E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
     fns["wgrad_x6"] = lambda: ops.gemm_wgrad_routed_x6([(hp, src, Din), (hp, tgt, Din)], gqp, tgt, bits_real, E, Dm, gw6, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t)
-    fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, b_group_stride=2 * Din * 3 * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t, win_bits=bits_real)
+    fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, group_ptr=ptr, G=T_groups, group_w=gw_t, win_bits=bits_real)
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
-    fns["pack_wt"] = lambda: ops.pack_bf16x3_transposed(W)
+    fns["pack_wt"] = lambda: ops.pack_weights_x6(W, True)
     for name in a.which.split(","):
         f = fns[name]
         for _ in range(2):
