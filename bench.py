@@ -30,6 +30,32 @@ MFMA_X6_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0
 
 
+# rocprofv3 kernel names of the timed GEMM kinds (for the committed PMC traffic file)
+_KIND_TO_KERNEL = {
+    "gemm_rows_x6_grouped": "void gemm_rows_x6_kernel<false>",
+    "gemm_rows_nk_routed_x6_grouped": "void gemm_rows_x6_kernel<true>",
+    "gemm_wgrad_routed_x6": "gemm_wgrad_x6_kernel",
+}
+
+
+def measured_traffic(kind):
+    """HBM-side bytes per launch of `kind` from the newest committed PMC summary under profiles/
+    (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command; FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950).  None if there is no file."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_hbm_traffic.json")))
+    name = _KIND_TO_KERNEL.get(kind)
+    if not files or name is None:
+        return None, None
+    with open(files[-1]) as f:
+        rec = json.load(f).get("kernels", {}).get(name)
+    if not rec:
+        return None, None
+    byts = (2.0 * rec.get("FETCH_SIZE_KB_per_launch", 0.0) + rec.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
+    return byts, os.path.relpath(files[-1], ROOT)
+
+
 def algorithmic_work_per_graph(H, layers, N, E, T, B):
     """SURVEY.md section 8d formulas: forward FLOPs and compulsory HBM bytes of the MP stack per graph."""
     flop = 0.0
@@ -152,6 +178,7 @@ def main():
             achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12
             x6 = "x6" in dom
             peak = MFMA_X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS
+            traffic, traffic_src = measured_traffic(dom)
             roof = {
                 "bound": "mfma",
                 "kernel": dom,
@@ -162,7 +189,9 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
                 "frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": None if traffic is None else round(traffic),
+                "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits included)",
+                "traffic_source": traffic_src,
                 "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "launches_per_step": d["launches"] / args.steps,
                 "all_gemm_kernels": {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2), "overlapped": bool(v.get("overlapped"))} for k, v in kern.items()},

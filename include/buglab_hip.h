@@ -64,6 +64,13 @@ int bl_embed_subtoken_max_fwd(const float* table, int32_t V, int32_t H, const in
                               void* stream);
 int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const int32_t* ids, const int8_t* argsub, int32_t N,
                               int32_t S, int32_t H, int32_t V, bl_dropout_t drop, float* g_table, void* stream);
+/* The same gradient from a token-sorted occurrence list: occ[i] = n * S + s (every valid subtoken slot),
+ * sorted by ids[n, s] and cut in chunks of one token each (chunk_ptr [nchunks + 1], chunk_tok [nchunks];
+ * the collator uses <= 256 occurrences per chunk).  One atomic per (chunk, channel) instead of one per
+ * (node, channel): subtoken frequencies are Zipfian and same-address atomics serialise. */
+int bl_embed_subtoken_max_bwd_sorted(const float* g_out, int32_t ld_g, const int32_t* occ, const int32_t* chunk_ptr,
+                                     const int32_t* chunk_tok, int32_t nchunks, const int8_t* argsub, int32_t S,
+                                     int32_t H, bl_dropout_t drop, float* g_table, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Grouped, gathered fp32 GEMM on MFMA (v_mfma_f32_32x32x2_f32, exact fp32).

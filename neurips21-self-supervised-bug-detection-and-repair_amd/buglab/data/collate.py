@@ -93,6 +93,32 @@ def segments_from_index(index: np.ndarray, num_segments: int):
     return _csr(np.asarray(index, dtype=np.int64), num_segments)
 
 
+TOKEN_CHUNK = 256  # occurrences of one token summed by one wave of the embedding-gradient kernel
+
+
+def token_occurrence_chunks(token_ids: np.ndarray, token_lens: np.ndarray, chunk: int = TOKEN_CHUNK):
+    """Token-sorted list of the valid subtoken slots, cut in chunks of one token each.
+
+    -> occ int32 [n_occ] (= node * S + slot), chunk_ptr int32 [C + 1], chunk_tok int32 [C].  The embedding
+    gradient (`bl_embed_subtoken_max_bwd_sorted`) sums a chunk in registers and issues one atomic per
+    channel: subtoken frequencies are Zipfian, and same-address atomics serialise."""
+    N, S = token_ids.shape
+    valid = np.arange(S)[None, :] < token_lens[:, None]
+    flat = np.flatnonzero(valid.reshape(-1))
+    ids = token_ids.reshape(-1)[flat]
+    order = np.argsort(ids, kind="stable")
+    occ = flat[order].astype(I32)
+    ids = ids[order]
+    if occ.size == 0:
+        return occ, np.zeros(1, dtype=I32), np.zeros(0, dtype=I32)
+    uniq, start, counts = np.unique(ids, return_index=True, return_counts=True)
+    nch = (counts + chunk - 1) // chunk
+    first = np.arange(int(nch.sum())) - np.repeat(np.cumsum(nch) - nch, nch)
+    chunk_start = np.repeat(start, nch) + first * chunk
+    chunk_ptr = np.concatenate([chunk_start, [occ.size]]).astype(I32)
+    return occ, chunk_ptr, np.repeat(uniq, nch).astype(I32)
+
+
 def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -> Dict[str, Any]:
     """Disjoint union of graphs -> one `graph_data` dict of NumPy arrays."""
     B = len(graphs)
@@ -107,6 +133,8 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
     for g, o in zip(graphs, node_off[:-1]):
         token_ids[o : o + g.num_nodes, : g.token_ids.shape[1]] = g.token_ids
         token_lens[o : o + g.num_nodes] = g.token_lens
+
+    tok_occ, tok_chunk_ptr, tok_chunk_id = token_occurrence_chunks(token_ids, token_lens)
 
     srcs, tgts = [], []
     type_ptr = np.zeros(num_edge_types + 1, dtype=np.int64)
@@ -161,6 +189,9 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
         "loc_group_items": loc_items,
         "token_ids": token_ids,
         "token_lens": token_lens,
+        "tok_occ": tok_occ,
+        "tok_chunk_ptr": tok_chunk_ptr,
+        "tok_chunk_id": tok_chunk_id,
         "msg_src": msg_src,
         "msg_tgt": msg_tgt,
         "type_ptr": type_ptr.astype(I32),
@@ -268,7 +299,7 @@ _INT_KEYS_MB = (
     "repair_group_ptr",
     "repair_group_items",
 )
-_INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
+_INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "tok_occ", "tok_chunk_ptr", "tok_chunk_id", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
 
 
 def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:

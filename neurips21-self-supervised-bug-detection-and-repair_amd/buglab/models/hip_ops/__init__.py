@@ -43,6 +43,7 @@ _SIGNATURES = {
     "bl_last_error": ([], ctypes.c_char_p),
     "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
+    "bl_embed_subtoken_max_bwd_sorted": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows": ([POINTER(bl_rows_t), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
@@ -525,7 +526,7 @@ class GraphIndex(NamedTuple):
 
 class _EmbedSubtokenMax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, ids, lens, drop: Dropout):
+    def forward(ctx, table, ids, lens, drop: Dropout, tok_csr):
         _f32(table, "embedding table")
         N, S = ids.shape
         V, H = table.shape
@@ -535,24 +536,36 @@ class _EmbedSubtokenMax(torch.autograd.Function):
             load_library().bl_embed_subtoken_max_fwd(table.data_ptr(), V, H, _i32(ids).data_ptr(), _i32(lens).data_ptr(), N, S,
                                                      drop.c(), out.data_ptr(), out.stride(0), argsub.data_ptr(), _stream()),
             "bl_embed_subtoken_max_fwd")
-        ctx.saved = (ids, argsub, drop, V, H)
+        ctx.saved = (table, ids, argsub, drop, V, H, tok_csr)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        ids, argsub, drop, V, H = ctx.saved
+        table, ids, argsub, drop, V, H, tok_csr = ctx.saved
         g_out = g_out.contiguous()
         N, S = ids.shape
-        g_table = torch.zeros((V, H), dtype=torch.float32, device=g_out.device)
-        _check(
-            load_library().bl_embed_subtoken_max_bwd(g_out.data_ptr(), g_out.stride(0), ids.data_ptr(), argsub.data_ptr(), N, S, H,
-                                                     V, drop.c(), g_table.data_ptr(), _stream()),
-            "bl_embed_subtoken_max_bwd")
-        return g_table, None, None, None
+        direct = _direct_small(table)
+        g_table = direct if direct is not None else torch.zeros((V, H), dtype=torch.float32, device=g_out.device)
+        if tok_csr is not None:
+            occ, chunk_ptr, chunk_tok = tok_csr
+            _check(
+                load_library().bl_embed_subtoken_max_bwd_sorted(g_out.data_ptr(), g_out.stride(0), _i32(occ).data_ptr(),
+                                                                _i32(chunk_ptr).data_ptr(), _i32(chunk_tok).data_ptr(),
+                                                                int(chunk_tok.shape[0]), argsub.data_ptr(), S, H, drop.c(),
+                                                                g_table.data_ptr(), _stream()),
+                "bl_embed_subtoken_max_bwd_sorted")
+        else:
+            _check(
+                load_library().bl_embed_subtoken_max_bwd(g_out.data_ptr(), g_out.stride(0), ids.data_ptr(), argsub.data_ptr(), N, S, H,
+                                                         V, drop.c(), g_table.data_ptr(), _stream()),
+                "bl_embed_subtoken_max_bwd")
+        return (None if direct is not None else g_table), None, None, None, None
 
 
-def embed_subtoken_max(table, ids, lens, drop: Dropout = NO_DROPOUT):
-    return _EmbedSubtokenMax.apply(table, ids, lens, drop)
+def embed_subtoken_max(table, ids, lens, drop: Dropout = NO_DROPOUT, tok_csr=None):
+    """tok_csr = (occ, chunk_ptr, chunk_tok) from the collator (token-sorted subtoken occurrences): backward
+    then sums per token in registers instead of issuing one atomic per (node, channel)."""
+    return _EmbedSubtokenMax.apply(table, ids, lens, drop, tok_csr)
 
 
 class _MpLayer(torch.autograd.Function):

@@ -45,8 +45,8 @@ class SubtokenEmbedder(nn.Module):
         self.dropout_rate = dropout_rate
         self.table = nn.Parameter(torch.randn(vocabulary_size, embedding_size))
 
-    def forward(self, token_ids, token_lens, drop: Dropout):
-        return hip_ops.embed_subtoken_max(self.table, token_ids, token_lens, drop)
+    def forward(self, token_ids, token_lens, drop: Dropout, tok_csr=None):
+        return hip_ops.embed_subtoken_max(self.table, token_ids, token_lens, drop, tok_csr)
 
 
 class MlpMessagePassingLayer(nn.Module):
@@ -140,13 +140,15 @@ class GraphNeuralNetwork(nn.Module):
 
     def forward(self, *, token_ids, token_lens, msg_src, msg_tgt, type_ptr, tgt_ptr, tgt_msgs, src_ptr, src_msgs,
                 node_to_graph, reference_node_ids, reference_node_graph_idx, num_graphs, num_nodes, num_messages,
-                return_all_states: bool = False, dropout_seed: Optional[int] = None, **_unused) -> GnnOutput:
+                return_all_states: bool = False, dropout_seed: Optional[int] = None, tok_occ=None, tok_chunk_ptr=None,
+                tok_chunk_id=None, **_unused) -> GnnOutput:
         graph = GraphIndex(msg_src, msg_tgt, type_ptr, tgt_ptr, tgt_msgs, src_ptr, src_msgs, int(num_nodes),
                            int(num_messages), int(type_ptr.shape[0]) - 1)
         training = self.training and dropout_seed is not None
         seed = int(dropout_seed or 0)
         mk = lambda rate, stream: Dropout(rate if training else 0.0, seed, stream)
-        h0 = self.embed(token_ids, token_lens, mk(self.embed.dropout_rate, 0))
+        tok_csr = (tok_occ, tok_chunk_ptr, tok_chunk_id) if tok_occ is not None else None
+        h0 = self.embed(token_ids, token_lens, mk(self.embed.dropout_rate, 0), tok_csr)
         h = h0
         all_states = [h0]
         stash: Dict[int, torch.Tensor] = {}

@@ -59,6 +59,61 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   }
 }
 
+// The same gradient from a token-sorted occurrence list (built by the collator): one wave per chunk of
+// <= 256 occurrences (node, slot) of ONE token, channel sums kept in registers, one atomic per channel
+// and chunk.  Subtoken frequencies are Zipfian: with one atomic per (node, channel) the hottest table
+// rows receive ~10^4 same-address atomics, which serialise at the L2 (0.59 ms at c2); here the hottest
+// row gets ~10^2.
+template <int NV>
+__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __restrict__ g_out, int ld_g,
+                                                               const int* __restrict__ occ,
+                                                               const int* __restrict__ chunk_ptr,
+                                                               const int* __restrict__ chunk_tok, int nchunks,
+                                                               const int8_t* __restrict__ argsub, int S, int H,
+                                                               bl_drop_dev drop, float* __restrict__ g_table) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= nchunks) return;
+  const int beg = chunk_ptr[c], end = chunk_ptr[c + 1];
+  float acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+  for (int base = beg; base < end; base += 64) {
+    const int cnt = min(64, end - base);
+    const int mine = lane < cnt ? occ[base + lane] : 0;
+    for (int i0 = 0; i0 < cnt; i0 += 4) {
+      float g[4][NV];
+      int a[4][NV], n[4], sl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pos = __shfl(mine, min(i0 + u, cnt - 1), 64);
+        n[u] = pos / S;
+        sl[u] = i0 + u < cnt ? pos - n[u] * S : -2;  // -2 never equals an argsub value
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int h = lane + 64 * j;
+          g[u][j] = h < H ? g_out[(size_t)n[u] * ld_g + h] : 0.f;
+          a[u][j] = h < H ? (int)argsub[(size_t)n[u] * H + h] : -1;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          float v = g[u][j];
+          if (drop.thresh) v = bl_keep(drop, (uint32_t)n[u] * (uint32_t)H + (uint32_t)(lane + 64 * j)) ? v * drop.scale : 0.f;
+          if (a[u][j] == sl[u]) acc[j] += v;
+        }
+    }
+  }
+  const size_t row = (size_t)chunk_tok[c] * H;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int h = lane + 64 * j;
+    if (h < H && acc[j] != 0.f) unsafeAtomicAdd(&g_table[row + h], acc[j]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // M2 (+ LayerNorm of M3): segmented max with argmax, one wave per segment
 template <int NV, bool HAS_LN>
@@ -298,9 +353,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------
 // backward through y = drop(act(z + bias)) from y; column sums -> g_bias
-// 256 threads = (256 / tpr) rows x tpr float4-columns (tpr = power of two >= N/4), ACT_BWD_ROWS rows per
-// block, four independent rows of loads in flight per thread
+// 256 threads = (256 / tpr) rows x tpr float4-columns (tpr = power of two >= N/4); a block walks row
+// chunks of ACT_BWD_ROWS grid-stride with four independent rows of loads in flight per thread and
+// flushes its column sums ONCE: same-address fp32 atomics serialise at the L2 (~40 ns each), so the
+// number of blocks, not the row count, sets the cost of the bias gradient (<= 512 blocks).
 #define ACT_BWD_ROWS 64
+#define ACT_BWD_MAX_BLOCKS 512
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const float* __restrict__ y, int nrows, int N,
                                                       int ld, int act, bl_drop_dev drop, float* g_z,
                                                       float* __restrict__ g_bias, int tpr_log2) {
@@ -311,8 +369,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const fl
   const int c = (blockIdx.y * tpr + tx) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < N) {
-    const int r_end = min(nrows, (int)(blockIdx.x + 1) * ACT_BWD_ROWS);
-    for (int r0 = blockIdx.x * ACT_BWD_ROWS + ty; r0 < r_end; r0 += 4 * rows_per_iter) {
+    for (int chunk = blockIdx.x * ACT_BWD_ROWS; chunk < nrows; chunk += gridDim.x * ACT_BWD_ROWS) {
+    const int r_end = min(nrows, chunk + ACT_BWD_ROWS);
+    for (int r0 = chunk + ty; r0 < r_end; r0 += 4 * rows_per_iter) {
       float4 gin[4], yin[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -341,6 +400,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const fl
         *reinterpret_cast<float4*>(g_z + (size_t)r * ld + c) = g;
         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
       }
+    }
     }
   }
   if (g_bias) {
@@ -514,6 +574,20 @@ extern "C" int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const
   return BL_OK;
 }
 
+extern "C" int bl_embed_subtoken_max_bwd_sorted(const float* g_out, int32_t ld_g, const int32_t* occ,
+                                               const int32_t* chunk_ptr, const int32_t* chunk_tok, int32_t nchunks,
+                                               const int8_t* argsub, int32_t S, int32_t H, bl_dropout_t drop,
+                                               float* g_table, void* stream) {
+  if (nchunks == 0) return BL_OK;
+  BL_CHECK_ARG(g_out && occ && chunk_ptr && chunk_tok && argsub && g_table, "bl_embed_subtoken_max_bwd_sorted: null pointer");
+  BL_CHECK_ARG(H > 0 && H <= 512 && S >= 1 && S <= 127, "bl_embed_subtoken_max_bwd_sorted: H in 1..512, 1 <= S <= 127");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NV(H, hipLaunchKernelGGL((embed_bwd_sorted_kernel<NV>), dim3((nchunks + 3) / 4), dim3(256), 0, st, g_out, ld_g, occ,
+                                     chunk_ptr, chunk_tok, nchunks, argsub, S, H, bl_make_drop(drop), g_table))
+  BL_LAUNCH_CHECK("bl_embed_subtoken_max_bwd_sorted");
+  return BL_OK;
+}
+
 extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items,
                                   int32_t nseg, int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g,
                                   const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, float* dact,
@@ -558,7 +632,7 @@ extern "C" int bl_layernorm_bwd(const float* g_y, const float* x, const float* m
   BL_CHECK_ARG(g_y && x && mean && rstd && gamma && (g_x || g_x_packed) && g_gamma && g_beta, "bl_layernorm_bwd: null pointer");
   BL_CHECK_ARG(D > 0 && D <= 512 && D % 2 == 0, "bl_layernorm_bwd: D must be even and in 2..512 (got %d)", D);
   BL_CHECK_ARG(g_x_packed == nullptr || D % 8 == 0, "bl_layernorm_bwd: the packed output needs D %% 8 == 0");
-  const int blocks = min((nrows + 7) / 8, 2048);
+  const int blocks = min((nrows + 7) / 8, 1024);  // also bounds the same-address atomics on g_gamma / g_beta
   hipStream_t st = (hipStream_t)stream;
   uint32_t* gp = reinterpret_cast<uint32_t*>(g_x_packed);
 #define LN_BWD_GO(NP_) hipLaunchKernelGGL((layernorm_bwd_kernel<NP_>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd, gamma, nrows, D, g_x, g_gamma, g_beta, post_scale, gp)
@@ -577,7 +651,8 @@ extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32
   BL_CHECK_ARG(act != BL_ACT_GELU, "bl_act_bwd: GELU needs the pre-activation (use bl_segment_max_bwd)");
   int tpr_log2 = 0;
   while ((1 << tpr_log2) < N / 4 && tpr_log2 < 8) ++tpr_log2;
-  dim3 grid((nrows + ACT_BWD_ROWS - 1) / ACT_BWD_ROWS, (N / 4 + (1 << tpr_log2) - 1) >> tpr_log2);
+  const int gy = (N / 4 + (1 << tpr_log2) - 1) >> tpr_log2;
+  dim3 grid(min((nrows + ACT_BWD_ROWS - 1) / ACT_BWD_ROWS, max(1, ACT_BWD_MAX_BLOCKS / gy)), gy);
   hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g_y, y, nrows, N, ld, act,
                      bl_make_drop(drop), g_z, g_bias, tpr_log2);
   BL_LAUNCH_CHECK("bl_act_bwd");

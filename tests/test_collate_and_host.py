@@ -221,3 +221,23 @@ def test_ggnn_registry_recipe_shapes():
     assert len(gated) == 8 and len({id(l) for l in gated[:7]}) == 1 and len(nn._gnn.mp) == 2
     assert nn._gnn.mp[0].W.shape == (10, 32, 32) and nn._gnn.mp[1].W.shape == (10, 64, 32) and nn._gnn.mp[1].Wh.shape == (64, 192)
     assert nn._gnn.output_node_state_dim == 64 and nn._localization_module.Ws.shape == (64, 64)
+
+
+def test_token_occurrence_chunks():
+    from buglab.data.collate import token_occurrence_chunks
+
+    rng = np.random.default_rng(0)
+    N, S = 50, 4
+    ids = rng.integers(0, 9, (N, S)).astype(np.int32)
+    lens = rng.integers(0, S + 1, N).astype(np.int32)
+    occ, cptr, ctok = token_occurrence_chunks(ids, lens, chunk=5)
+    assert occ.size == int(lens.sum()) and cptr[0] == 0 and cptr[-1] == occ.size and (np.diff(cptr) > 0).all() and (np.diff(cptr) <= 5).all()
+    seen = set()
+    for c in range(len(ctok)):
+        for pos in occ[cptr[c]:cptr[c + 1]]:
+            n, s = divmod(int(pos), S)
+            assert s < lens[n] and ids[n, s] == ctok[c]
+            seen.add(int(pos))
+    assert len(seen) == occ.size  # every valid slot exactly once
+    e = token_occurrence_chunks(np.zeros((3, 2), np.int32), np.zeros(3, np.int32))
+    assert e[0].size == 0 and e[1].tolist() == [0] and e[2].size == 0

@@ -266,6 +266,17 @@ def test_embed_fwd_bwd(ops):
     out.backward(_dev(go))
     assert (out.detach().cpu() - ref.detach()).abs().max() < 1e-6
     assert (td.grad.cpu() - tr.grad).abs().max() < 1e-4
+    # token-sorted form of the gradient (collator-built occurrence chunks; a hot token spans several chunks)
+    from buglab.data.collate import token_occurrence_chunks
+
+    ids[: N // 2, 0] = 7
+    tr2 = table.clone().requires_grad_(True)
+    O.embed_nodes(tr2, ids, lens, 0.25, 42).backward(go)
+    occ, cptr, ctok = token_occurrence_chunks(ids, lens, chunk=16)
+    assert (np.diff(cptr) <= 16).all() and cptr[-1] == occ.size == int(lens.sum())
+    td2 = _dev(table).requires_grad_(True)
+    ops.embed_subtoken_max(td2, _dev(ids), _dev(lens), ops.Dropout(0.25, 42, 0), (_dev(occ), _dev(cptr), _dev(ctok))).backward(_dev(go))
+    assert (td2.grad.cpu() - tr2.grad).abs().max() < 1e-4
 
 
 def test_flat_adam_matches_oracle(ops):
