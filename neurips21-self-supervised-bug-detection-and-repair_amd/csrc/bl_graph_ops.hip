@@ -257,10 +257,11 @@ __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm backward: one wave per row, two rows in flight per wave (grid-stride); a lane owns the
+// LayerNorm backward: one wave per row, LN_RIF rows in flight per wave (grid-stride); a lane owns the
 // channel PAIRS 2*lane + 128*j (+0, +1): float2 loads/stores, and the optional bf16x3-packed copy of
 // the result (the operand form of the bf16x6 GEMMs) is written as 32-bit stores.  Column sums are
-// reduced per block, then atomics.
+// reduced per block, then atomics -- from few blocks: same-address atomics serialise (~40 ns each).
+#define LN_RIF 4
 template <int NP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g_y, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
@@ -283,11 +284,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
   const float invD = 1.0f / (float)D;
   const int halfD = D >> 1;
-  for (int r0 = (blockIdx.x * 4 + w) * 2; r0 < nrows; r0 += nw * 2) {
-    float2 gy[2][NP], xh[2][NP], ps[2][NP];
-    float mu[2], rs[2];
+  for (int r0 = (blockIdx.x * 4 + w) * LN_RIF; r0 < nrows; r0 += nw * LN_RIF) {
+    float2 gy[LN_RIF][NP], xh[LN_RIF][NP], ps[LN_RIF][NP];
+    float mu[LN_RIF], rs[LN_RIF];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < LN_RIF; ++q) {
       const int r = min(r0 + q, nrows - 1);
       mu[q] = mean[r];
       rs[q] = rstd[r];
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < LN_RIF; ++q) {
       const int r = r0 + q;
       if (r >= nrows) break;
       float a = 0.f, b = 0.f;
@@ -632,7 +633,7 @@ extern "C" int bl_layernorm_bwd(const float* g_y, const float* x, const float* m
   BL_CHECK_ARG(g_y && x && mean && rstd && gamma && (g_x || g_x_packed) && g_gamma && g_beta, "bl_layernorm_bwd: null pointer");
   BL_CHECK_ARG(D > 0 && D <= 512 && D % 2 == 0, "bl_layernorm_bwd: D must be even and in 2..512 (got %d)", D);
   BL_CHECK_ARG(g_x_packed == nullptr || D % 8 == 0, "bl_layernorm_bwd: the packed output needs D %% 8 == 0");
-  const int blocks = min((nrows + 7) / 8, 1024);  // also bounds the same-address atomics on g_gamma / g_beta
+  const int blocks = min((nrows + 4 * LN_RIF - 1) / (4 * LN_RIF), 512);  // also bounds the same-address atomics on g_gamma / g_beta
   hipStream_t st = (hipStream_t)stream;
   uint32_t* gp = reinterpret_cast<uint32_t*>(g_x_packed);
 #define LN_BWD_GO(NP_) hipLaunchKernelGGL((layernorm_bwd_kernel<NP_>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd, gamma, nrows, D, g_x, g_gamma, g_beta, post_scale, gp)
