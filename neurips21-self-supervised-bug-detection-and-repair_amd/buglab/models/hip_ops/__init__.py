@@ -19,7 +19,7 @@ import torch
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4
 _ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH, "gelu": ACT_GELU}
 LIB_NAME = "libbuglab_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+LIB_PATH = os.environ.get("BL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)  # BL_HIP_LIB: tuning builds
 
 
 class HipOpsUnavailable(RuntimeError):
