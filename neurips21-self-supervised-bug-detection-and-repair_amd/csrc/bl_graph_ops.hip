@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
 
 // ------------------------------------------------------------------------------------------------
 // M2 (+ LayerNorm of M3): segmented max with argmax, one wave per segment
-#define SEG_RIF 8
 template <int NV, bool HAS_LN>
 __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ x, int ldx,
                                                           const int* __restrict__ seg_ptr,
@@ -138,32 +137,40 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
   for (int base = beg; base < end; base += 64) {
     const int cnt = min(64, end - base);
     const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
-    // SEG_RIF rows in flight per step (independent loads; a typical node has ~5 incoming messages, so
-    // one round), compared in item order (ties -> first item); the validity tests are wave-uniform
-    for (int i = 0; i < cnt; i += SEG_RIF) {
-      int e[SEG_RIF];
-      float v[SEG_RIF][NV];
+    int i = 0;
+    // four rows in flight per step (independent loads), compared in item order (ties -> first item)
+    for (; i + 4 <= cnt; i += 4) {
+      int e[4];
+      float v[4][NV];
 #pragma unroll
-      for (int u = 0; u < SEG_RIF; ++u) {
-        if (i + u < cnt) {
-          e[u] = __shfl(mine, i + u, 64);
-          const float* __restrict__ row = x + (size_t)e[u] * ldx;
+      for (int u = 0; u < 4; ++u) {
+        e[u] = __shfl(mine, i + u, 64);
+        const float* __restrict__ row = x + (size_t)e[u] * ldx;
 #pragma unroll
-          for (int j = 0; j < NV; ++j) {
-            const int d = lane + 64 * j;
-            v[u][j] = d < D ? row[d] : NEG_INF;
-          }
+        for (int j = 0; j < NV; ++j) {
+          const int d = lane + 64 * j;
+          v[u][j] = d < D ? row[d] : NEG_INF;
         }
       }
 #pragma unroll
-      for (int u = 0; u < SEG_RIF; ++u) {
-        if (i + u < cnt) {
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int j = 0; j < NV; ++j) {
-            float t = v[u][j];
-            if (act == BL_ACT_GELU) t = bl_gelu(t);
-            if (t > best[j]) { best[j] = t; barg[j] = e[u]; }
-          }
+        for (int j = 0; j < NV; ++j) {
+          float t = v[u][j];
+          if (act == BL_ACT_GELU) t = bl_gelu(t);
+          if (t > best[j]) { best[j] = t; barg[j] = e[u]; }
+        }
+    }
+    for (; i < cnt; ++i) {
+      const int e = __shfl(mine, i, 64);
+      const float* __restrict__ row = x + (size_t)e * ldx;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int d = lane + 64 * j;
+        if (d < D) {
+          float t = row[d];
+          if (act == BL_ACT_GELU) t = bl_gelu(t);
+          if (t > best[j]) { best[j] = t; barg[j] = e; }
         }
       }
     }
@@ -432,42 +439,41 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
     const int d = lane + 64 * j;
     acc[j] = (accumulate && d < Din) ? g_h[(size_t)n * ld_gh + d] : 0.f;
   }
-  // both CSR rows are looked up before any message row is requested (one dependent latency, not two);
-  // SEG_RIF message rows in flight, summed in item order: all source-side rows, then the target side
-  const bool has_tgt = tgt_ptr != nullptr;  // source-only messages (GGNN) otherwise
-  const int beg0 = src_ptr[n], end0 = src_ptr[n + 1];
-  const int beg1 = has_tgt ? tgt_ptr[n] : 0, end1 = has_tgt ? tgt_ptr[n + 1] : 0;
-  int mine0 = lane < end0 - beg0 ? src_msgs[beg0 + lane] : 0;
-  int mine1 = lane < end1 - beg1 ? tgt_msgs[beg1 + lane] : 0;
 #pragma unroll
   for (int part = 0; part < 2; ++part) {
+    if (part == 1 && tgt_ptr == nullptr) continue;  // source-only messages (GGNN)
+    const int* __restrict__ ptr = part == 0 ? src_ptr : tgt_ptr;
     const int* __restrict__ items = part == 0 ? src_msgs : tgt_msgs;
     const int coff = part == 0 ? 0 : Din;
-    const int beg = part == 0 ? beg0 : beg1, end = part == 0 ? end0 : end1;
+    const int beg = ptr[n], end = ptr[n + 1];
     for (int base = beg; base < end; base += 64) {
       const int cnt = min(64, end - base);
-      int mine = part == 0 ? mine0 : mine1;
-      if (base != beg) mine = lane < cnt ? items[base + lane] : 0;
-      for (int i = 0; i < cnt; i += SEG_RIF) {
-        float v[SEG_RIF][NV];
+      const int mine = lane < cnt ? items[base + lane] : 0;
+      int i = 0;
+      for (; i + 4 <= cnt; i += 4) {  // four independent row loads in flight, summed in item order
+        float v[4][NV];
 #pragma unroll
-        for (int u = 0; u < SEG_RIF; ++u) {
-          if (i + u < cnt) {
-            const int e = __shfl(mine, i + u, 64);
-            const float* __restrict__ row = g_a + (size_t)e * ld_ga + coff;
+        for (int u = 0; u < 4; ++u) {
+          const int e = __shfl(mine, i + u, 64);
+          const float* __restrict__ row = g_a + (size_t)e * ld_ga + coff;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-              const int d = lane + 64 * j;
-              v[u][j] = d < Din ? row[d] : 0.f;
-            }
+          for (int j = 0; j < NV; ++j) {
+            const int d = lane + 64 * j;
+            v[u][j] = d < Din ? row[d] : 0.f;
           }
         }
 #pragma unroll
-        for (int u = 0; u < SEG_RIF; ++u) {
-          if (i + u < cnt) {
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int j = 0; j < NV; ++j) acc[j] += v[u][j];
-          }
+          for (int j = 0; j < NV; ++j) acc[j] += v[u][j];
+      }
+      for (; i < cnt; ++i) {
+        const int e = __shfl(mine, i, 64);
+        const float* __restrict__ row = g_a + (size_t)e * ld_ga + coff;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int d = lane + 64 * j;
+          if (d < Din) acc[j] += row[d];
         }
       }
     }
