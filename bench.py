@@ -162,6 +162,24 @@ def main():
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     last_loss = float(loss)
 
+    # forward-only ("predict": localization + repair log-probabilities, eval mode) on the same batch --
+    # SURVEY section 8d asks for it next to the training rate; outside the timed training region
+    module.eval()
+    with torch.no_grad():
+        def predict_pass():
+            _, _, gout, _ = module.compute_localization_logprobs(mb["graph_data"])
+            module._compute_repair_logprobs(gout, mb["target_rewrites"], mb["rewrite_to_location_group"],
+                                            mb["candidate_symbol_to_location_group"], mb["swapped_pair_to_call_location_group"],
+                                            mb["repair_group_ptr"], mb["repair_group_items"])
+        predict_pass()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            predict_pass()
+        torch.cuda.synchronize()
+        predict_elapsed = D.max_over_ranks(time.perf_counter() - tp, device)
+    module.train()
+
     if rank == 0:
         kern = timer.summary()
         total_graphs = args.graphs * world * args.steps
@@ -219,6 +237,7 @@ def main():
                 "parallelism": f"dp{world}",
                 "loss_last_step": round(last_loss, 5),
             },
+            "predict_graphs_per_s": round(args.graphs * world * args.steps / predict_elapsed, 1),  # forward-only, eval mode
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args),
         }

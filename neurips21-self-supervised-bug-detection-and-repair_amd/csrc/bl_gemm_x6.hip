@@ -15,8 +15,8 @@
 // planes back to back, [hi x D | mid x D | lo x D] (6 D bytes): a row's plane is contiguous, which
 // is what both the k-contiguous loads of this file's row GEMM (64 B per row, plane and 32-k stage)
 // and the feature-contiguous loads of the weight-gradient GEMM want.  In LDS a stage row of the row
-// GEMM is [k-group][plane][8] (row stride 208 B: b128 reads/writes conflict-free), so an MFMA
-// fragment (8 k's of one row) is three consecutive ds_read_b128.
+// GEMM is [plane][k-group][8] (row stride 208 B: b128 reads conflict-free, the 8-lane write groups
+// overlap in one of four slots), an MFMA fragment (8 k's of one row) is three ds_read_b128 64 B apart.
 //
 // Kernel shape is the fp32 one's (csrc/bl_gemm.hip): 128 x 128 tile, 4 waves 2 x 2, transposed
 // accumulators -> float4 epilogue stores, wave-cooperative group lookup, optional routed
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
       _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                         \
         uint4 a_ = ra[i][p];                                                                                  \
         a_.x &= keep_.x; a_.y &= keep_.y; a_.z &= keep_.z; a_.w &= keep_.w;                                   \
-        As[row_ * XROW + p_kg * 3 + p] = a_;                                                                  \
-        Bs[row_ * XROW + p_kg * 3 + p] = nok_ ? rb[i][p] : make_uint4(0u, 0u, 0u, 0u);                        \
+        As[row_ * XROW + p * 4 + p_kg] = a_;                                                                  \
+        Bs[row_ * XROW + p * 4 + p_kg] = nok_ ? rb[i][p] : make_uint4(0u, 0u, 0u, 0u);                        \
       }                                                                                                       \
     }                                                                                                         \
   }
@@ -256,17 +256,17 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
       bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti) {
-        const uint4* p = &As[(wm * 64 + ti * 32 + li) * XROW + kg * 3];
+        const uint4* p = &As[(wm * 64 + ti * 32 + li) * XROW + kg];
         ah[ti] = __builtin_bit_cast(bf16x8, p[0]);
-        am[ti] = __builtin_bit_cast(bf16x8, p[1]);
-        al[ti] = __builtin_bit_cast(bf16x8, p[2]);
+        am[ti] = __builtin_bit_cast(bf16x8, p[4]);
+        al[ti] = __builtin_bit_cast(bf16x8, p[8]);
       }
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
-        const uint4* p = &Bs[(wn * 64 + tj * 32 + li) * XROW + kg * 3];
+        const uint4* p = &Bs[(wn * 64 + tj * 32 + li) * XROW + kg];
         bh[tj] = __builtin_bit_cast(bf16x8, p[0]);
-        bm[tj] = __builtin_bit_cast(bf16x8, p[1]);
-        bl[tj] = __builtin_bit_cast(bf16x8, p[2]);
+        bm[tj] = __builtin_bit_cast(bf16x8, p[4]);
+        bl[tj] = __builtin_bit_cast(bf16x8, p[8]);
       }
       // swapped operands (B fragment in the A slot): the accumulator holds the transposed tile, so
       // a lane owns 4 consecutive columns of one row -> float4 epilogue stores.  Small terms first.

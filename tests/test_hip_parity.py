@@ -46,9 +46,9 @@ def _run_hip(module, mb_np, seed=None):
     return loss, mb
 
 
-def _check_against_oracle(cfg, mb_np, seed=None, train=True):
+def _check_against_oracle(cfg, mb_np, seed=None, train=True, grad_rtol=1e-4, oracle_dtype=torch.float32):
     params = O.init_params(cfg, seed=0)
-    out, grads = O.forward_backward(params, mb_np, cfg, seed=seed)
+    out, grads = O.forward_backward({k: v.to(oracle_dtype) for k, v in params.items()}, mb_np, cfg, seed=seed)
     module = Hh.build_module_like(cfg, params)
     module.train(train)
     module.reset_metrics()
@@ -66,7 +66,7 @@ def _check_against_oracle(cfg, mb_np, seed=None, train=True):
         d = Hh.maxdiff(g_hip[k], g_ref)
         scale = float(g_ref.abs().max())
         worst[k] = (d, scale)
-        assert d <= 1e-4 * scale + 1e-6, (k, d, scale)
+        assert d <= grad_rtol * scale + 1e-6, (k, d, scale)
     return module, out, worst
 
 
@@ -99,6 +99,22 @@ def test_power_law_hub_degree_512():
     deg = np.diff(mb["graph_data"]["tgt_ptr"])
     assert deg.max() >= 512
     _check_against_oracle(cfg, mb)
+
+
+def test_c3_c4_shapes_hidden_256_match_oracle():
+    """BASELINE configs c3 / c4 (hidden 256, 8 layers, 16 edge types; c4 = truncated power-law in-degree with a
+    512-hub) at a node count the oracle finishes in seconds.  Widths 256 / 512 / 1024 exercise the bf16x6
+    GEMMs with several column tiles and 8-32 k stages, and the 4-words-per-message routing bitmask."""
+    # Reference = the oracle in fp64.  Loss, log-probabilities and node states keep the 1e-4 bound.  The
+    # GRADIENT bound is 2e-2 of each tensor's largest entry here: with 256-512 channels x 8 layers some
+    # arg-max of the aggregation is a near-tie, and whichever fp32 rounding an implementation has decides
+    # which message receives that channel's gradient.  Measured on these two batches against fp64: the fp32
+    # CPU oracle is off by 7e-6 / 6.9e-3, this HIP path by 1.7e-3 / 1e-5 -- either one can be the outlier.
+    cfg, _, mb = Hh.make_case(B=2, n=300, E=1500, T=16, H=256, layers=8, C=10, seed=11)
+    _check_against_oracle(cfg, mb, grad_rtol=2e-2, oracle_dtype=torch.float64)
+    cfg, _, mb = Hh.make_case(B=2, n=400, E=2400, T=16, H=256, layers=8, C=10, degree="powerlaw", max_degree=512, dropout=0.2, seed=12)
+    assert np.diff(mb["graph_data"]["tgt_ptr"]).max() >= 512
+    _check_against_oracle(cfg, mb, seed=5, grad_rtol=2e-2, oracle_dtype=torch.float64)
 
 
 def test_no_buggy_graphs_and_empty_edge_types():
@@ -214,6 +230,38 @@ def test_full_size_properties_c2():
         mb2 = to_device(collate_samples(samples, 16), "cuda")
         loss2 = module(**mb2)
         assert abs(float(loss2) - float(loss)) < 1e-5
+
+
+def test_full_size_properties_c3_c4_per_gpu_shard():
+    """BASELINE configs c3 / c4 at the full per-GPU size (32 graphs x 2k nodes / 10k messages, hidden 256,
+    power-law in-degree with max 512): probabilities normalised, finite gradients, and one fused
+    clip+Adam training step lowers the loss on the same batch."""
+    from buglab.data.collate import collate_samples, to_device
+    from buglab.data.synthetic import make_samples
+    from buglab.models.gnn import build_gnn_mlp_module
+    from buglab.models import hip_ops
+    from buglab.runtime.optim import FlatAdam
+
+    samples = make_samples(32, seed=4, degree="powerlaw", max_degree=512)
+    torch.manual_seed(0)
+    module = build_gnn_mlp_module(hidden_state_size=256, dropout_rate=0.0).cuda()
+    opt = FlatAdam(module.parameters(), lr=1e-3, clip_gradient_norm=0.5, num_warmup_steps=0)
+    mb = to_device(collate_samples(samples, 16), "cuda")
+    assert int(np.diff(mb["graph_data"]["tgt_ptr"].cpu().numpy()).max()) >= 512
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = module(**mb)
+        loss.backward()
+        hip_ops.join_side_stream()
+        assert torch.isfinite(opt.flat_grad).all()
+        opt.step()
+        losses.append(float(loss))
+    assert all(math.isfinite(l) for l in losses) and losses[-1] < losses[0]
+    with torch.no_grad():
+        ids, lp, _, _ = module.compute_localization_logprobs(mb["graph_data"])
+        sums = torch.zeros(32, device="cuda").index_add_(0, ids.long(), lp.exp())
+        assert (sums - 1).abs().max() < 1e-4
 
 
 @pytest.mark.parametrize("loss_type", ["norm-kl", "norm-rmse", "classify-max-loss", "expectation"])
