@@ -1,0 +1,64 @@
+/* libbuglab_data -- native reader for BugLab's `*.msgpack.l.gz` shards.
+ *
+ * Replaces, for the graph part of a datapoint, the host-side decode chain of the reference:
+ *   gzip + msgpack.Unpacker + OrderedDict construction   buglab/utils/msgpackutils.py:11-14
+ *   add_open_vocab_nodes_and_edges                        buglab/representations/data.py:97-121
+ *   _as_np_array over every edge list                     buglab/representations/data.py:124-127, 152-155
+ *   subtoken splitting + vocabulary lookup of every node  ptgnn StrElementRepresentationModel.tensorize,
+ *                                                         configured at buglab/models/modelregistry.py:59-82
+ * Plain C ABI, host only (no HIP): the caller copies what it needs before the next call on the same reader.
+ * Everything that is NOT graph.nodes / graph.edges / graph.reference_nodes is handed back as one msgpack map
+ * (`rest`) for the Python side to decode -- those fields are small.  Re-entrant: one reader per thread. */
+#ifndef BUGLAB_DATA_H
+#define BUGLAB_DATA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bl_reader bl_reader;
+typedef struct bl_vocab bl_vocab;
+
+typedef struct {
+  int32_t is_nil;                    /* the stream element was msgpack nil (the reference skips those) */
+  int32_t num_nodes;                 /* including the subtoken nodes appended for HasSubtoken edges */
+  int32_t num_file_nodes;            /* nodes present in the file (the first num_file_nodes strings) */
+  int32_t created_has_subtoken;      /* 1: the last edge kind, "HasSubtoken", was created by this reader */
+  const char* node_text;             /* node strings, UTF-8, concatenated */
+  const int32_t* node_text_off;      /* [num_nodes + 1] byte offsets into node_text */
+  int32_t num_edge_kinds;
+  const char* const* edge_kind;      /* NUL-terminated names, file order; "HasSubtoken" appended if created here */
+  const int32_t* const* edge_pairs;  /* per kind: int32 [count][2] (source, target) */
+  const int32_t* const* edge_feat;   /* per kind: int32 [count], index into feat_text or -1 (edge has no 3rd element) */
+  const int32_t* edge_count;
+  const char* feat_text;             /* edge feature strings (3rd element of an edge), concatenated */
+  const int32_t* feat_text_off;      /* [num_feats + 1] */
+  int32_t num_feats;
+  const int32_t* reference_nodes;
+  int32_t num_reference_nodes;
+  int32_t non_ascii_identifier;      /* 1: an identifier token has non-ASCII bytes -- its subtokens were NOT
+                                        created here (Unicode lower-casing is left to the Python path) */
+  const uint8_t* rest;               /* msgpack map: every other top-level key; "graph" -> map of its other keys */
+  int64_t rest_len;
+} bl_datapoint_t;
+
+const char* bl_data_last_error(void);
+int32_t bl_data_version(void);
+
+bl_reader* bl_reader_open(const char* path);                 /* NULL on error */
+/* 1 = `out` filled, 0 = end of stream, < 0 = malformed input (message in bl_data_last_error()) */
+int32_t bl_reader_next(bl_reader* r, bl_datapoint_t* out);
+void bl_reader_close(bl_reader* r);
+
+/* vocabulary of subtokens: token i = text[off[i] .. off[i+1]) */
+bl_vocab* bl_vocab_create(const char* text, const int32_t* off, int32_t n);
+void bl_vocab_free(bl_vocab* v);
+/* ids[n][S] (zero-padded) and lens[n] = max(1, #subtokens kept) for node strings; subtokens = snake_case /
+ * camelCase parts, lower-cased, at most S.  needs_python[i] = 1 for strings with non-ASCII bytes (left zero). */
+int32_t bl_tensorize_nodes(const bl_vocab* v, int32_t unk_id, const char* text, const int32_t* off, int32_t n, int32_t S,
+                           int32_t* ids, int32_t* lens, uint8_t* needs_python);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

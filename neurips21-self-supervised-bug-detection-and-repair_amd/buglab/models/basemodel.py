@@ -61,9 +61,17 @@ class AbstractBugLabModel:
 
         call_args: Dict[int, List[int]] = defaultdict(list)  # Call node -> its `args` children, in order (:88-98)
         nodes = graph["nodes"]
-        for edge in graph["edges"].get("Child", ()):
-            if len(edge) == 3 and edge[2] == "args" and nodes[edge[0]] == "Call":
-                call_args[edge[0]].append(edge[1])
+        from buglab.data.native import NativeGraph
+
+        if isinstance(graph, NativeGraph):
+            # native reader: the labelled Child edges are a few entries of an int32 array -- no Python loop over all edges
+            for src, tgt in graph.edges.labelled("Child", "args"):
+                if nodes[src] == "Call":
+                    call_args[src].append(tgt)
+        else:
+            for edge in graph["edges"].get("Child", ()):
+                if len(edge) == 3 and edge[2] == "args" and nodes[edge[0]] == "Call":
+                    call_args[edge[0]].append(edge[1])
 
         # per family: location node -> (payloads, original rewrite ids); insertion-ordered like the reference's dicts
         fam_payload = {k: defaultdict(list) for k in ("text", "var", "swap")}

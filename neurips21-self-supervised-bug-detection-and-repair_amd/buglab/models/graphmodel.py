@@ -33,6 +33,7 @@ class StrElementRepresentationModel:
         self._counter: Optional[Counter] = Counter()
         self.vocabulary: Optional[Vocabulary] = None
         self._cache: Dict[str, np.ndarray] = {}
+        self._native_vocab = None  # buglab.data.native.NativeVocabulary, built on first use
 
     def update_metadata_from(self, node_str: str) -> None:
         self._counter.update(split_identifier_into_parts(node_str))
@@ -49,6 +50,18 @@ class StrElementRepresentationModel:
 
     def tensorize_nodes(self, node_strs: List[str]):
         S = self.max_num_subtokens
+        from buglab.data.native import NativeNodes, NativeVocabulary
+
+        if isinstance(node_strs, NativeNodes) and self.token_splitting == "subtoken":
+            # node strings still in the native reader's blob: split + look up in C++ (bl_tensorize_nodes)
+            if self._native_vocab is None:
+                self._native_vocab = NativeVocabulary(self.vocabulary.id_to_token, self.vocabulary.get_id_or_unk(self.vocabulary.get_unk()))
+            ids, lens, needs_python = self._native_vocab.tensorize(node_strs, S)
+            for i in np.flatnonzero(needs_python).tolist():  # non-ASCII strings: Unicode lower-casing in Python
+                row = [self.vocabulary.get_id_or_unk(t) for t in split_identifier_into_parts(node_strs[i])[:S]]
+                ids[i, : len(row)] = row
+                lens[i] = max(1, len(row))
+            return ids, lens
         ids = np.zeros((len(node_strs), S), dtype=np.int32)
         lens = np.ones(len(node_strs), dtype=np.int32)
         for i, s in enumerate(node_strs):
@@ -65,6 +78,7 @@ class StrElementRepresentationModel:
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_cache"] = {}
+        d["_native_vocab"] = None
         return d
 
 

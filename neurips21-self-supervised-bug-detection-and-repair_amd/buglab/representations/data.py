@@ -75,6 +75,18 @@ class BugLabData(TypedDict):
     @classmethod
     def as_graph_data(cls, data: "BugLabData") -> Tuple[GraphData, Optional[int]]:
         """reference data.py:139-167."""
+        from buglab.data.native import NativeGraph
+
+        if isinstance(data["graph"], NativeGraph):
+            # read by the native reader (buglab/data/native.py): subtoken nodes / HasSubtoken edges are already
+            # there and the edge lists already are int32 [E, 2] arrays
+            g = data["graph"]
+            candidate_node_idxs, inv = np.unique(g.reference_nodes_array, return_inverse=True)
+            target_node_idx = None
+            if data["target_fix_action_idx"] is not None:
+                target_node_idx = int(inv[data["target_fix_action_idx"]])
+            return (GraphData(node_information=g.nodes, edges=dict(g.edges.arrays),
+                              reference_nodes={"candidate_nodes": candidate_node_idxs.astype(np.int32)}), target_node_idx)
         candidate_node_idxs, inv = np.unique(data["graph"]["reference_nodes"], return_inverse=True)
         if data["target_fix_action_idx"] is not None:
             target_node_idx = int(inv[data["target_fix_action_idx"]])

@@ -11,7 +11,23 @@ import msgpack
 from buglab.runtime.richpath import RichPath
 
 
-def load_msgpack_l_gz(filename: PathLike) -> Iterator[Any]:
+def _use_native_reader() -> bool:
+    """The C++ reader (buglab/data/native.py) is used when its library is built, unless BUGLAB_NATIVE_READER=0."""
+    import os
+
+    if os.environ.get("BUGLAB_NATIVE_READER", "1") == "0":
+        return False
+    from buglab.data import native
+
+    return native.available()
+
+
+def load_msgpack_l_gz(filename: PathLike, native: Optional[bool] = None) -> Iterator[Any]:
+    if native if native is not None else _use_native_reader():
+        from buglab.data.native import load_msgpack_l_gz_native
+
+        yield from load_msgpack_l_gz_native(filename)
+        return
     with gzip.open(filename) as f:
         unpacker = msgpack.Unpacker(f, raw=False, object_pairs_hook=OrderedDict, strict_map_key=False)
         yield from unpacker
