@@ -108,6 +108,11 @@ class NativeNodes(Sequence):
     def __iter__(self):
         return iter(self.as_list())
 
+    def __eq__(self, other):
+        return isinstance(other, (list, tuple, NativeNodes)) and list(self) == list(other)
+
+    __hash__ = None
+
 
 class NativeEdges(Mapping):
     """`graph["edges"]`: edge kind -> list of `[src, tgt]` / `[src, tgt, feature]`, built on demand from

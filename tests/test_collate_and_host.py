@@ -186,7 +186,10 @@ def test_msgpack_roundtrip_and_split_identifier(tmp_path):
     data = make_buglab_dataset(3, seed=6)
     save_msgpack_l_gz(data, tmp_path / "a.msgpack.l.gz")
     back = list(load_all_msgpack_l_gz(str(tmp_path)))
-    assert len(back) == 3 and back[0]["graph"]["nodes"] == data[0]["graph"]["nodes"]
+    # (the native reader appends the subtoken nodes of data.py:97-121 right away; the Python reader's graph gets
+    # them when as_graph_data() mutates it, like the reference's -- the file's own nodes come first either way)
+    n0 = len(data[0]["graph"]["nodes"])
+    assert len(back) == 3 and list(back[0]["graph"]["nodes"])[:n0] == data[0]["graph"]["nodes"]
     assert split_identifier_into_parts("getHTTPResponse_code2") == ["get", "http", "response", "code", "2"]
     assert split_identifier_into_parts("__") == ["__"]
     v = Vocabulary.create_vocabulary(["a", "a", "b"], max_size=10, count_threshold=2, add_unk=True)
