@@ -215,6 +215,11 @@ int bl_rowdot_bwd(const float* g_y, const float* x, int32_t ldx, const float* w,
  * lookup in fixermodules.py:36. */
 int bl_scatter_add_rows(const float* src, int32_t ld_src, int32_t col_off, int32_t width, const int32_t* idx,
                         int32_t R, float* out, int32_t ld_out, void* stream);
+/* out[r, 0:width] = x[idx[r], 0:width]: ONE gather of every node row the heads reference
+ * (buglab/models/gnn.py:170-172, 261-289 gather `reprs[node_idx]` once per scorer); the scorers then work on
+ * the compact [R, H] copy, so backward has one [N, H] scatter instead of one per gather. */
+int bl_gather_rows(const float* x, int32_t ld_x, const int32_t* idx, int32_t R, int32_t width, float* out,
+                   int32_t ld_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * T1  optimiser on flat fp32 buffers: global-norm clip (buglab/models/train.py:104, clip 0.5) fused

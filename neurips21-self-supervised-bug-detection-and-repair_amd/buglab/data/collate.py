@@ -93,6 +93,9 @@ def segments_from_index(index: np.ndarray, num_segments: int):
     return _csr(np.asarray(index, dtype=np.int64), num_segments)
 
 
+# reference-node families the scoring heads gather (localizationmodule.py:54-60, fixermodules.py:31-39, 65-73, 110-124)
+HEAD_REFERENCE_KEYS = ("candidate_nodes", "target_rewrite_nodes", "varmisused_node_ids", "candidate_symbol_node_ids",
+                       "call_node_ids", "candidate_swapped_a", "candidate_swapped_b")
 TOKEN_CHUNK = 256  # occurrences of one token summed by one wave of the embedding-gradient kernel
 
 
@@ -176,6 +179,16 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
     ref_ids["candidate_swapped_a"] = np.ascontiguousarray(ref_ids[REFERENCE_KEY_PAIRS][:, 0])
     ref_ids["candidate_swapped_b"] = np.ascontiguousarray(ref_ids[REFERENCE_KEY_PAIRS][:, 1])
 
+    # one gather for all scoring heads: every referenced node row, key by key, and where each key's rows
+    # land in that compact copy (the heads then index 0..R-1 instead of 0..N-1)
+    head_spans, parts, pos = {}, [], 0
+    for key in HEAD_REFERENCE_KEYS:
+        r = ref_ids[key]
+        head_spans[key] = (pos, int(r.shape[0]))
+        parts.append(r)
+        pos += int(r.shape[0])
+    head_gather_idx = np.concatenate(parts).astype(I32) if parts else np.zeros(0, I32)
+
     node_to_graph = np.repeat(np.arange(B, dtype=I32), n_per_graph)
     cand_graph = ref_graph["candidate_nodes"]
     cand_ptr = np.zeros(B + 1, dtype=np.int64)
@@ -189,6 +202,9 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
         "loc_group_items": loc_items,
         "token_ids": token_ids,
         "token_lens": token_lens,
+        "head_gather_idx": head_gather_idx,
+        "head_local_idx": np.arange(head_gather_idx.shape[0], dtype=I32),
+        "head_spans": head_spans,
         "tok_occ": tok_occ,
         "tok_chunk_ptr": tok_chunk_ptr,
         "tok_chunk_id": tok_chunk_id,
@@ -299,7 +315,8 @@ _INT_KEYS_MB = (
     "repair_group_ptr",
     "repair_group_items",
 )
-_INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "tok_occ", "tok_chunk_ptr", "tok_chunk_id", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
+_INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "tok_occ", "tok_chunk_ptr", "tok_chunk_id",
+                "head_gather_idx", "head_local_idx", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
 
 
 def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
@@ -346,6 +363,7 @@ def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
         else:
             out[k] = t
     out["has_bug"] = out["has_bug"].bool()
+    out_gd["head_spans"] = dict(gd["head_spans"])
     out_gd["num_graphs"] = int(gd["num_graphs"])
     out_gd["num_nodes"] = int(gd["token_ids"].shape[0])
     out_gd["num_messages"] = int(gd["msg_src"].shape[0])

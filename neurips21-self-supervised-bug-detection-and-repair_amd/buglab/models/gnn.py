@@ -91,14 +91,28 @@ class GnnBugLabModule(ModuleWithMetrics):
         if self._use_all_gnn_layer_outputs:  # reference :118-121
             out = out._replace(output_node_representations=hip_ops.gather_linear(
                 [(out.output_node_representations, None)], self.summarization_W, self.summarization_b, "none"))
+        idx_all = graph_data.get("head_gather_idx")
+        if idx_all is not None and idx_all.shape[0] > 0:
+            # all scorers read node rows through ONE gather: backward then has a single [N, H] scatter
+            # instead of a zero-filled [N, H] buffer (and an accumulation) per gathered operand
+            local, spans = graph_data["head_local_idx"], graph_data["head_spans"]
+            out = out._replace(head_node_representations=hip_ops.gather_rows(out.output_node_representations, idx_all),
+                               head_idx_references={k: local[s : s + n] for k, (s, n) in spans.items()})
         return out
+
+    @staticmethod
+    def _head_inputs(gnn_output: GnnOutput):
+        if gnn_output.head_node_representations is not None:
+            return gnn_output.head_node_representations, gnn_output.head_idx_references
+        return gnn_output.output_node_representations, gnn_output.node_idx_references
 
     def compute_localization_logprobs(self, graph_data: Dict[str, Any], dropout_seed=None):
         """reference :125-142."""
         gnn_output = self._compute_gnn_output(graph_data, dropout_seed)
+        h, refs = self._head_inputs(gnn_output)
         ids, logprobs, arange = self._localization_module.compute_localization_logprobs(
-            gnn_output.output_node_representations,
-            gnn_output.node_idx_references["candidate_nodes"],
+            h,
+            refs["candidate_nodes"],
             gnn_output.node_graph_idx_reference["candidate_nodes"],
             gnn_output.num_graphs,
             graph_data["candidate_ptr"], graph_data["loc_group_ptr"], graph_data["loc_group_items"])
@@ -110,8 +124,7 @@ class GnnBugLabModule(ModuleWithMetrics):
         """reference :253-322.  One log-softmax over the location groups of ALL three scorers'
         logits; the CSR of the concatenated group ids comes from the collator (or is built here
         from the three id vectors when a caller does not supply it)."""
-        h = gnn_output.output_node_representations
-        refs = gnn_output.node_idx_references
+        h, refs = self._head_inputs(gnn_output)
         dev = h.device
         zeros = lambda: torch.zeros(0, dtype=torch.float32, device=dev)
         if target_rewrites.shape[0] > 0:
@@ -168,8 +181,9 @@ class GnnBugLabModule(ModuleWithMetrics):
         if rewrite_logprobs is not None:  # selector / generator branch, reference :189-219
             from buglab.models.utils import compute_generator_loss
 
+            h, refs = self._head_inputs(gnn_output)
             _, loc_lp, arange = self._localization_module.compute_localization_logprobs(
-                gnn_output.output_node_representations, gnn_output.node_idx_references["candidate_nodes"],
+                h, refs["candidate_nodes"],
                 gnn_output.node_graph_idx_reference["candidate_nodes"], has_bug.shape[0],
                 graph_data["candidate_ptr"], graph_data["loc_group_ptr"], graph_data["loc_group_items"])
             loss = compute_generator_loss(
@@ -181,9 +195,10 @@ class GnnBugLabModule(ModuleWithMetrics):
                                    torch.ones((), device=loss.device)])
                 self._acc = acc if self._acc is None else self._acc + acc
             return loss
+        h, refs = self._head_inputs(gnn_output)
         loc_loss = self._localization_module(
-            gnn_output.output_node_representations,
-            gnn_output.node_idx_references["candidate_nodes"],
+            h,
+            refs["candidate_nodes"],
             gnn_output.node_graph_idx_reference["candidate_nodes"],
             has_bug, correct_candidate_node_idxs,
             graph_data["candidate_ptr"], graph_data["loc_group_ptr"], graph_data["loc_group_items"])

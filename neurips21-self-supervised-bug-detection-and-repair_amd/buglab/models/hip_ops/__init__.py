@@ -64,6 +64,7 @@ _SIGNATURES = {
     "bl_rowdot_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_rowdot_bwd": ([c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_scatter_add_rows": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gather_rows": ([c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_sqnorm": ([c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
     "bl_adam_clip_step": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p], ctypes.c_int),
 }
@@ -751,6 +752,31 @@ def gated_mp_layer(h, W, Wi, bi, Wh, bh, graph: GraphIndex, drop: Dropout = NO_D
 
 def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu", drop: Dropout = NO_DROPOUT):
     return _MpLayer.apply(h.contiguous(), W, ln_g, ln_b, Wd, bd, graph, _ACTS[msg_act], drop)
+
+
+class _GatherRows(torch.autograd.Function):
+    """x[idx] as a compact copy; backward = one zero-filled [N, H] buffer + one scatter-add."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        _f32(x, "x")
+        R, H = idx.shape[0], x.shape[1]
+        out = torch.empty((R, H), dtype=torch.float32, device=x.device)
+        _check(load_library().bl_gather_rows(x.data_ptr(), x.stride(0), _i32(idx).data_ptr(), R, H, out.data_ptr(), out.stride(0), _stream()),
+               "bl_gather_rows")
+        ctx.saved = (idx, x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        idx, shape = ctx.saved
+        g_x = torch.zeros(shape, dtype=torch.float32, device=g_out.device)
+        scatter_add_rows(g_out.contiguous(), 0, shape[1], idx, g_x)
+        return g_x, None
+
+
+def gather_rows(x, idx):
+    return _GatherRows.apply(x, idx)
 
 
 class _GatherLinear(torch.autograd.Function):

@@ -29,6 +29,10 @@ class GnnOutput(NamedTuple):
     node_idx_references: Dict[str, torch.Tensor]
     node_graph_idx_reference: Dict[str, torch.Tensor]
     num_graphs: int
+    # compact copy of the node rows the heads reference (one gather for all scorers) and the references
+    # re-indexed into it; None -> the heads gather from output_node_representations themselves
+    head_node_representations: Optional[torch.Tensor] = None
+    head_idx_references: Optional[Dict[str, torch.Tensor]] = None
 
 
 def _uniform_(t: torch.Tensor, bound: float) -> torch.Tensor:

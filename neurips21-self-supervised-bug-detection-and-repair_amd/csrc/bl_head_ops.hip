@@ -95,6 +95,16 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
   unsafeAtomicAdd(&out[(size_t)idx[r] * ld_out + c], src[(size_t)r * ld_src + col_off + c]);
 }
 
+// out[r, :] = x[idx[r], 0:width]  (float4 per thread)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int ld_x, const int* __restrict__ idx,
+                                                          long long R, int width4, float* __restrict__ out, int ld_out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= R * width4) return;
+  const long long r = t / width4;
+  const int c = (int)(t % width4) * 4;
+  *reinterpret_cast<float4*>(out + (size_t)r * ld_out + c) = *reinterpret_cast<const float4*>(x + (size_t)idx[r] * ld_x + c);
+}
+
 // ------------------------------------------------------------------------------------------------
 // T1  flat-buffer optimiser
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
@@ -184,6 +194,18 @@ extern "C" int bl_scatter_add_rows(const float* src, int32_t ld_src, int32_t col
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      src, ld_src, col_off, width, idx, (long long)R, out, ld_out);
   BL_LAUNCH_CHECK("bl_scatter_add_rows");
+  return BL_OK;
+}
+
+extern "C" int bl_gather_rows(const float* x, int32_t ld_x, const int32_t* idx, int32_t R, int32_t width, float* out,
+                              int32_t ld_out, void* stream) {
+  if (R == 0) return BL_OK;
+  BL_CHECK_ARG(x && idx && out && bl_aligned16(x) && bl_aligned16(out), "bl_gather_rows: null or misaligned pointer");
+  BL_CHECK_ARG(width > 0 && width % 4 == 0 && ld_x % 4 == 0 && ld_out % 4 == 0, "bl_gather_rows: width / ld must be multiples of 4");
+  const long long total = (long long)R * (width / 4);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, idx,
+                     (long long)R, width / 4, out, ld_out);
+  BL_LAUNCH_CHECK("bl_gather_rows");
   return BL_OK;
 }
 

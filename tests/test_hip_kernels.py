@@ -371,3 +371,16 @@ def test_routed_gemms_bf16x6_match_fp64(ops, Din, Dm, sizes):
     assert err < 2e-6 * max(scale, 1.0) * 4 and err < 4 * err32 + 1e-6 * scale, (err, err32, scale)
     dA = ops.gemm_rows_x6([(gqp, d_tgt, Dm)], ops.pack_weights_x6(_dev(W), False), E, 2 * Din, group_ptr=d_ptr, G=T, win_bits=d_bits)
     assert float((dA.cpu().double() - ref_dA).abs().max()) < 2e-5
+
+
+def test_gather_rows_fwd_bwd(ops):
+    rng = np.random.default_rng(3)
+    x = torch.randn(300, 64)
+    idx = rng.integers(0, 300, 777).astype(np.int32)
+    xd = _dev(x).requires_grad_(True)
+    out = ops.gather_rows(xd, _dev(idx))
+    assert torch.equal(out.cpu(), x[idx.astype(np.int64)])
+    g = torch.randn(777, 64)
+    out.backward(_dev(g))
+    ref = torch.zeros(300, 64).index_add_(0, torch.from_numpy(idx.astype(np.int64)), g)
+    assert (xd.grad.cpu() - ref).abs().max() < 1e-5
