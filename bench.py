@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--messages", type=int, default=10000)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-predict", action="store_true", help="skip the forward-only passes after the timed training steps (profiling)")
     args = ap.parse_args()
 
     import torch
@@ -165,19 +166,21 @@ def main():
     # forward-only ("predict": localization + repair log-probabilities, eval mode) on the same batch --
     # SURVEY section 8d asks for it next to the training rate; outside the timed training region
     module.eval()
+    predict_elapsed = None
     with torch.no_grad():
         def predict_pass():
             _, _, gout, _ = module.compute_localization_logprobs(mb["graph_data"])
             module._compute_repair_logprobs(gout, mb["target_rewrites"], mb["rewrite_to_location_group"],
                                             mb["candidate_symbol_to_location_group"], mb["swapped_pair_to_call_location_group"],
                                             mb["repair_group_ptr"], mb["repair_group_items"])
-        predict_pass()
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for _ in range(args.steps):
+        if not args.no_predict:
             predict_pass()
-        torch.cuda.synchronize()
-        predict_elapsed = D.max_over_ranks(time.perf_counter() - tp, device)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(args.steps):
+                predict_pass()
+            torch.cuda.synchronize()
+            predict_elapsed = D.max_over_ranks(time.perf_counter() - tp, device)
     module.train()
 
     if rank == 0:
@@ -237,7 +240,7 @@ def main():
                 "parallelism": f"dp{world}",
                 "loss_last_step": round(last_loss, 5),
             },
-            "predict_graphs_per_s": round(args.graphs * world * args.steps / predict_elapsed, 1),  # forward-only, eval mode
+            "predict_graphs_per_s": None if predict_elapsed is None else round(args.graphs * world * args.steps / predict_elapsed, 1),  # forward-only, eval mode
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args),
         }
