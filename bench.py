@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=2000)
     ap.add_argument("--messages", type=int, default=10000)
     ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--degree", default="uniform", choices=["uniform", "powerlaw"], help="in-degree law (powerlaw = BASELINE config c4, max 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true", help="skip the forward-only passes after the timed training steps (profiling)")
     args = ap.parse_args()
@@ -134,7 +135,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     hip_ops.load_library()  # fail loudly if the HIP extension is missing
 
-    samples = make_samples(args.graphs, seed=1000 + rank, num_nodes=args.nodes, num_messages=args.messages, num_edge_types=args.types)
+    samples = make_samples(args.graphs, seed=1000 + rank, num_nodes=args.nodes, num_messages=args.messages, num_edge_types=args.types,
+                           degree=args.degree, max_degree=512)
     mb = to_device(collate_samples(samples, args.types), device)
     torch.manual_seed(0)  # identical initial weights on every rank
     module = build_gnn_mlp_module(args.hidden, args.layers, args.types, dropout_rate=args.dropout, dropout_base_seed=rank).to(device).train()
@@ -235,7 +237,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"gnn-mlp hidden={args.hidden} layers={args.layers} edge_types={args.types} "
-                            f"batch={args.graphs} graphs/GPU x ({args.nodes} nodes, {args.messages} msgs) dropout={args.dropout}",
+                            f"batch={args.graphs} graphs/GPU x ({args.nodes} nodes, {args.messages} msgs) dropout={args.dropout}"
+                            + (" power-law in-degree (max 512)" if args.degree == "powerlaw" else ""),
                 "global_batch": args.graphs * world,
                 "parallelism": f"dp{world}",
                 "loss_last_step": round(last_loss, 5),
