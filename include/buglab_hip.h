@@ -149,12 +149,15 @@ int bl_gemm_wgrad_routed(const bl_rows_t* a, const float* g_node, int32_t ld_g, 
  *   if dact != NULL also  dact[v, d] = act'(x[arg[v, d], d]) (0 for an empty segment): with it the
  *   backward pass needs only [nseg, D] arrays, never the [items, D] pre-activations again;
  *   if winbits != NULL also  winbits[item, w] bit b = (arg[seg(item), 32 w + b] == item), ceil(D/32)
- *   words per item: the routing table in the form the bf16x6 routed GEMMs read.
+ *   words per item: the routing table in the form the bf16x6 routed GEMMs read;
+ *   seg_order (optional): a permutation of 0..nseg-1 = the order segments are processed in (the collator puts
+ *   high-degree nodes first: one wave works through a 512-item hub for about as long as the whole launch takes).
  * Replaces torch_scatter.scatter_max at ptgnn's "max" aggregation (gnnlayerdefs.py:11,21) and at
  * buglab/models/layers/localizationmodule.py:56-58, plus ptgnn's nn.LayerNorm. */
 int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg,
                        int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g, const float* ln_b,
-                       float eps, float* ln_out, float* mean, float* rstd, float* dact, uint32_t* winbits, void* stream);
+                       float eps, float* ln_out, float* mean, float* rstd, float* dact, uint32_t* winbits,
+                       const int32_t* seg_order, void* stream);
 
 /* backward of the segmented max, gather form (deterministic, no atomics):
  *   g_x[i, d] = (arg[seg_of[i], d] == i) ? g_out[seg_of[i], d] * act'(x[i, d]) : 0      (g_x may alias x) */
@@ -181,7 +184,8 @@ int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32_t N, int32
  * tgt_ptr == tgt_msgs == NULL: source half only (messages built from h[src] alone, `ggnn`). */
 int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
                        const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din, int32_t accumulate,
-                       float* g_h, int32_t ld_gh, void* stream);
+                       float* g_h, int32_t ld_gh, const int32_t* node_order,
+                       void* stream);
 
 /* GRU cell of the gated (`ggnn`) node update -- the elementwise part of torch.nn.GRUCell (gate order
  * r | z | n) after gi = x W_i + b_i and gh = h W_h + b_h [N, 3D] were produced by bl_gemm_rows:

@@ -96,6 +96,7 @@ def segments_from_index(index: np.ndarray, num_segments: int):
 # reference-node families the scoring heads gather (localizationmodule.py:54-60, fixermodules.py:31-39, 65-73, 110-124)
 HEAD_REFERENCE_KEYS = ("candidate_nodes", "target_rewrite_nodes", "varmisused_node_ids", "candidate_symbol_node_ids",
                        "call_node_ids", "candidate_swapped_a", "candidate_swapped_b")
+HUB_DEGREE = 64  # nodes with more incident messages than this are processed first by the per-node kernels
 TOKEN_CHUNK = 256  # occurrences of one token summed by one wave of the embedding-gradient kernel
 
 
@@ -156,6 +157,17 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
     msg_tgt = np.concatenate(tgts).astype(I32) if tgts else np.zeros(0, dtype=I32)
     tgt_ptr, tgt_msgs = _csr(msg_tgt.astype(np.int64), N)
     src_ptr, src_msgs = _csr(msg_src.astype(np.int64), N)
+    # per-node kernels (one wave per node) take hubs first: a node with hundreds of messages keeps its wave busy
+    # for about as long as the whole launch lasts, so it has to start at t = 0 (BASELINE config c4)
+    deg = np.diff(tgt_ptr).astype(np.int64) + np.diff(src_ptr)
+    hubs = np.flatnonzero(deg > HUB_DEGREE)
+    if hubs.size:
+        hubs = hubs[np.argsort(-deg[hubs], kind="stable")]
+        rest = np.ones(N, dtype=bool)
+        rest[hubs] = False
+        node_order = np.concatenate([hubs, np.flatnonzero(rest)]).astype(I32)
+    else:
+        node_order = np.arange(N, dtype=I32)
 
     ref_ids: Dict[str, np.ndarray] = {}
     ref_graph: Dict[str, np.ndarray] = {}
@@ -202,6 +214,7 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
         "loc_group_items": loc_items,
         "token_ids": token_ids,
         "token_lens": token_lens,
+        "node_order": node_order,
         "head_gather_idx": head_gather_idx,
         "head_local_idx": np.arange(head_gather_idx.shape[0], dtype=I32),
         "head_spans": head_spans,
@@ -316,7 +329,7 @@ _INT_KEYS_MB = (
     "repair_group_items",
 )
 _INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "tok_occ", "tok_chunk_ptr", "tok_chunk_id",
-                "head_gather_idx", "head_local_idx", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
+                "head_gather_idx", "head_local_idx", "node_order", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
 
 
 def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:

@@ -52,11 +52,11 @@ _SIGNATURES = {
     "bl_gemm_wgrad_routed_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
-    "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gru_cell_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
     "bl_gru_cell_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_log_softmax_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p], ctypes.c_int),
@@ -355,7 +355,7 @@ def gemm_wgrad(sources, g_c, M, N, gw, *, gw_group_stride=0, group_ptr=None, gro
     return gw
 
 
-def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5, want_dact=False, want_bits=False):
+def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5, want_dact=False, want_bits=False, seg_order=None):
     """-> (out [nseg, D], arg int32 [nseg, D], ln_out | None, mean | None, rstd | None[, dact][, winbits])
 
     winbits: int32 [items, ceil(D/32)], bit d of row i set iff item i won channel d of its segment
@@ -375,7 +375,7 @@ def segment_max(x, seg_ptr, seg_items, nseg, act=ACT_NONE, ln=None, eps=1e-5, wa
     _check(
         load_library().bl_segment_max_fwd(x.data_ptr(), x.stride(0), _i32(seg_ptr).data_ptr(), _p(seg_items), int(nseg), int(D),
                                           int(act), out.data_ptr(), arg.data_ptr(), _p(ln[0]) if ln else None,
-                                          _p(ln[1]) if ln else None, float(eps), _p(ln_out), _p(mean), _p(rstd), _p(dact), _p(bits), _stream()),
+                                          _p(ln[1]) if ln else None, float(eps), _p(ln_out), _p(mean), _p(rstd), _p(dact), _p(bits), _p(seg_order), _stream()),
         "bl_segment_max_fwd")
     res = (out, arg, ln_out, mean, rstd)
     if want_dact:
@@ -523,6 +523,7 @@ class GraphIndex(NamedTuple):
     num_nodes: int
     num_messages: int
     num_types: int
+    node_order: Optional[torch.Tensor] = None  # processing order of the per-node kernels: high-degree nodes first
 
 
 class _EmbedSubtokenMax(torch.autograd.Function):
@@ -598,7 +599,8 @@ class _MpLayer(torch.autograd.Function):
             pre = gemm_rows([(h, g.msg_src), (h, g.msg_tgt)], _f32(W, "W"), E, Dm, b_group_stride=K2 * Dm, ldb=Dm,
                             group_ptr=g.type_ptr, G=T)
         use_bits = x6_ok(Din, Dm)
-        res = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)), want_dact=True, want_bits=use_bits)
+        res = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)), want_dact=True, want_bits=use_bits,
+                          seg_order=g.node_order)
         agg, arg, ln_out, mean, rstd, dact = res[:6]
         bits = res[6] if use_bits else None
         if use_bits and WGRAD_X6:
@@ -671,7 +673,7 @@ class _MpLayer(torch.autograd.Function):
         _check(
             load_library().bl_mp_scatter_grad(g_a.data_ptr(), g_a.stride(0), g.src_ptr.data_ptr(), g.src_msgs.data_ptr(),
                                               g.tgt_ptr.data_ptr(), g.tgt_msgs.data_ptr(), N, Din, 0, g_h.data_ptr(),
-                                              g_h.stride(0), _stream()),
+                                              g_h.stride(0), _p(g.node_order), _stream()),
             "bl_mp_scatter_grad")
         if W_direct is not None and Wd_direct is not None:
             # gradients land in param.grad behind the main chain; joined by join_side_stream()
@@ -702,7 +704,7 @@ class _GatedMpLayer(torch.autograd.Function):
         E = g.num_messages
         assert Din == D and Wi.shape == (Dm, 3 * D) and Wh.shape == (D, 3 * D)
         msgs = gemm_rows([(h, g.msg_src)], _f32(W, "W"), E, Dm, b_group_stride=D * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
-        agg, arg, _, _, _ = segment_max(msgs, g.tgt_ptr, g.tgt_msgs, N)
+        agg, arg, _, _, _ = segment_max(msgs, g.tgt_ptr, g.tgt_msgs, N, seg_order=g.node_order)
         del msgs
         gi = gemm_rows([(agg, None)], _f32(Wi), N, 3 * D, bias=_f32(bi))
         gh = gemm_rows([(h, None)], _f32(Wh), N, 3 * D, bias=_f32(bh))
@@ -739,7 +741,7 @@ class _GatedMpLayer(torch.autograd.Function):
         g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, D, b_group_stride=D * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
         _check(
             load_library().bl_mp_scatter_grad(g_a.data_ptr(), g_a.stride(0), g.src_ptr.data_ptr(), g.src_msgs.data_ptr(), None, None,
-                                              N, D, 1, g_h.data_ptr(), g_h.stride(0), _stream()),
+                                              N, D, 1, g_h.data_ptr(), g_h.stride(0), _p(g.node_order), _stream()),
             "bl_mp_scatter_grad")
         side.join()
         side.join()

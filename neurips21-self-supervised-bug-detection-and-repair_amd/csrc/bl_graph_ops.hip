@@ -124,10 +124,14 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           float eps, float* __restrict__ ln_out,
                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                          float* __restrict__ dact, uint32_t* __restrict__ winbits) {
+                                                          float* __restrict__ dact, uint32_t* __restrict__ winbits,
+                                                          const int* __restrict__ seg_order) {
   const int lane = threadIdx.x & 63;
-  const int seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (seg >= nseg) return;
+  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= nseg) return;
+  // seg_order (optional): processing order, long segments first -- a 512-item hub takes one wave about as
+  // long as the whole launch, so it must start at t = 0 instead of wherever its node id falls
+  const int seg = seg_order ? seg_order[slot] : slot;
   const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
   float best[NV];
   int barg[NV];
@@ -429,10 +433,12 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
                                                               const int* __restrict__ src_msgs,
                                                               const int* __restrict__ tgt_ptr,
                                                               const int* __restrict__ tgt_msgs, int N, int Din,
-                                                              int accumulate, float* __restrict__ g_h, int ld_gh) {
+                                                              int accumulate, float* __restrict__ g_h, int ld_gh,
+                                                              const int* __restrict__ node_order) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (n >= N) return;
+  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= N) return;
+  const int n = node_order ? node_order[slot] : slot;  // hubs first (see segment_max_kernel)
   float acc[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -592,7 +598,7 @@ extern "C" int bl_embed_subtoken_max_bwd_sorted(const float* g_out, int32_t ld_g
 extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items,
                                   int32_t nseg, int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g,
                                   const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, float* dact,
-                                  uint32_t* winbits, void* stream) {
+                                  uint32_t* winbits, const int32_t* seg_order, void* stream) {
   if (nseg == 0) return BL_OK;
   BL_CHECK_ARG(seg_ptr && out && arg, "bl_segment_max_fwd: null pointer");
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
@@ -603,10 +609,10 @@ extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* se
   hipStream_t st = (hipStream_t)stream;
   if (has_ln) {
     DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, true>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
-                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits))
+                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order))
   } else {
     DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, false>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
-                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits))
+                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order))
   }
   BL_LAUNCH_CHECK("bl_segment_max_fwd");
   return BL_OK;
@@ -662,13 +668,13 @@ extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32
 
 extern "C" int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
                                   const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din,
-                                  int32_t accumulate, float* g_h, int32_t ld_gh, void* stream) {
+                                  int32_t accumulate, float* g_h, int32_t ld_gh, const int32_t* node_order, void* stream) {
   if (N == 0) return BL_OK;
   BL_CHECK_ARG(g_a && src_ptr && src_msgs && g_h && (tgt_ptr == nullptr) == (tgt_msgs == nullptr), "bl_mp_scatter_grad: null pointer");
   BL_CHECK_ARG(Din > 0 && Din <= 512 && ld_ga >= (tgt_ptr ? 2 : 1) * Din, "bl_mp_scatter_grad: Din in 1..512, ld_ga >= (1 or 2)*Din");
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_a, ld_ga,
-                                       src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh))
+                                       src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh, node_order))
   BL_LAUNCH_CHECK("bl_mp_scatter_grad");
   return BL_OK;
 }

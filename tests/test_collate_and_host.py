@@ -244,3 +244,15 @@ def test_token_occurrence_chunks():
     assert len(seen) == occ.size  # every valid slot exactly once
     e = token_occurrence_chunks(np.zeros((3, 2), np.int32), np.zeros(3, np.int32))
     assert e[0].size == 0 and e[1].tolist() == [0] and e[2].size == 0
+
+
+def test_node_order_puts_hubs_first():
+    samples = make_samples(2, seed=3, num_nodes=300, num_messages=2000, num_edge_types=4, degree="powerlaw", max_degree=512)
+    gd = C.collate_samples(samples, 4)["graph_data"]
+    order = gd["node_order"]
+    N = gd["token_ids"].shape[0]
+    assert sorted(order.tolist()) == list(range(N))
+    deg = np.diff(gd["tgt_ptr"]) + np.diff(gd["src_ptr"])
+    k = int((deg > C.HUB_DEGREE).sum())
+    assert k > 0 and (deg[order[:k]] > C.HUB_DEGREE).all() and (np.diff(deg[order[:k]]) <= 0).all()
+    assert (np.diff(order[k:]) > 0).all()  # everyone else keeps the natural order

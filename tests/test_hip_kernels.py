@@ -130,6 +130,11 @@ def test_segment_max_layernorm_fwd_bwd(ops, D, act):
     wpad[:, :D] = won
     ref_bits = np.packbits(wpad.reshape(E, W32, 32), axis=-1, bitorder="little").view(np.uint32).reshape(E, W32)
     assert (wbits.cpu().numpy().view(np.uint32) == ref_bits).all()
+    # a processing order (hubs first in the collator) changes nothing
+    perm = _dev(np.random.default_rng(5).permutation(nseg).astype(np.int32))
+    o2 = ops.segment_max(_dev(x), _dev(ptr), _dev(order), nseg, act=ops._ACTS[act], ln=(_dev(g), _dev(b)), want_dact=True, want_bits=True, seg_order=perm)
+    for t1, t2 in zip((out, a, ln_out, mean, rstd, dact, wbits), o2):
+        assert torch.equal(t1, t2)
     # backward of the max (gather form) against autograd through the oracle
     if D % 4 == 0:
         go = torch.randn(nseg, D)
@@ -208,9 +213,16 @@ def test_mp_scatter_grad(ops):
     lib = ops.load_library()
     d_ga, d_sp, d_sm, d_tp, d_tm = (_dev(a) for a in (ga, sp, sm, tp, tm))  # keep the device copies alive
     ops._check(lib.bl_mp_scatter_grad(d_ga.data_ptr(), 2 * Din, d_sp.data_ptr(), d_sm.data_ptr(), d_tp.data_ptr(),
-                                      d_tm.data_ptr(), N, Din, 0, gh.data_ptr(), Din, torch.cuda.current_stream().cuda_stream), "scatter")
+                                      d_tm.data_ptr(), N, Din, 0, gh.data_ptr(), Din, None, torch.cuda.current_stream().cuda_stream), "scatter")
     torch.cuda.synchronize()
     assert (gh.cpu().double() - ref).abs().max() < 1e-4
+    # any processing order (the collator puts hubs first) gives the same rows
+    order = _dev(np.random.default_rng(1).permutation(N).astype(np.int32))
+    gh2 = torch.full_like(gh, float("nan"))
+    ops._check(lib.bl_mp_scatter_grad(d_ga.data_ptr(), 2 * Din, d_sp.data_ptr(), d_sm.data_ptr(), d_tp.data_ptr(),
+                                      d_tm.data_ptr(), N, Din, 0, gh2.data_ptr(), Din, order.data_ptr(), torch.cuda.current_stream().cuda_stream), "scatter")
+    torch.cuda.synchronize()
+    assert torch.equal(gh2, gh)
 
 
 def test_segment_log_softmax_fwd_bwd(ops):
