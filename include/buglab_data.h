@@ -58,6 +58,11 @@ void bl_vocab_free(bl_vocab* v);
 int32_t bl_tensorize_nodes(const bl_vocab* v, int32_t unk_id, const char* text, const int32_t* off, int32_t n, int32_t S,
                            int32_t* ids, int32_t* lens, uint8_t* needs_python);
 
+/* Stable counting sort of keys in [0, K): perm[E] = item indices ordered by key (ties keep input order),
+ * ptr[K + 1] = where each key's run starts.  The collator's CSRs and per-type target order
+ * (reference gnn.py:463-542 builds these with Python lists; here: one pass). */
+int32_t bl_counting_sort(const int32_t* keys, int64_t E, int32_t K, int32_t* ptr, int32_t* perm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,11 +80,9 @@ REFERENCE_KEY_PAIRS = "candidate_swapped_node_ids"
 
 def _csr(keys: np.ndarray, n: int):
     """CSR over `keys` (values in [0, n)): ptr int32[n+1], items int32[len(keys)] ascending inside a segment."""
-    items = np.argsort(keys, kind="stable").astype(I32)
-    ptr = np.zeros(n + 1, dtype=np.int64)
-    if keys.size:
-        np.cumsum(np.bincount(keys, minlength=n), out=ptr[1:])
-    return ptr.astype(I32), items
+    from buglab.data.native import counting_sort  # one native pass when libbuglab_data is built, NumPy otherwise
+
+    return counting_sort(keys, n)
 
 
 def segments_from_index(index: np.ndarray, num_segments: int):
@@ -110,12 +108,15 @@ def token_occurrence_chunks(token_ids: np.ndarray, token_lens: np.ndarray, chunk
     valid = np.arange(S)[None, :] < token_lens[:, None]
     flat = np.flatnonzero(valid.reshape(-1))
     ids = token_ids.reshape(-1)[flat]
-    order = np.argsort(ids, kind="stable")
+    if ids.size == 0:
+        return np.zeros(0, dtype=I32), np.zeros(1, dtype=I32), np.zeros(0, dtype=I32)
+    from buglab.data.native import counting_sort
+
+    tptr, order = counting_sort(ids, int(ids.max()) + 1)
     occ = flat[order].astype(I32)
-    ids = ids[order]
-    if occ.size == 0:
-        return occ, np.zeros(1, dtype=I32), np.zeros(0, dtype=I32)
-    uniq, start, counts = np.unique(ids, return_index=True, return_counts=True)
+    counts_all = np.diff(tptr)
+    uniq = np.flatnonzero(counts_all)
+    start, counts = tptr[:-1][uniq].astype(np.int64), counts_all[uniq].astype(np.int64)
     nch = (counts + chunk - 1) // chunk
     first = np.arange(int(nch.sum())) - np.repeat(np.cumsum(nch) - nch, nch)
     chunk_start = np.repeat(start, nch) + first * chunk
@@ -140,23 +141,30 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
 
     tok_occ, tok_chunk_ptr, tok_chunk_id = token_occurrence_chunks(token_ids, token_lens)
 
-    srcs, tgts = [], []
-    type_ptr = np.zeros(num_edge_types + 1, dtype=np.int64)
-    for t in range(num_edge_types):
-        parts = [g.adjacency_lists[t].astype(np.int64) + o for g, o in zip(graphs, node_off[:-1]) if t < len(g.adjacency_lists) and g.adjacency_lists[t].shape[0]]
-        if parts:
-            adj = np.concatenate(parts, axis=0)
-            order = np.argsort(adj[:, 1], kind="stable")  # target-sorted inside the type
-            adj = adj[order]
-            srcs.append(adj[:, 0])
-            tgts.append(adj[:, 1])
-            type_ptr[t + 1] = type_ptr[t] + adj.shape[0]
-        else:
-            type_ptr[t + 1] = type_ptr[t]
-    msg_src = np.concatenate(srcs).astype(I32) if srcs else np.zeros(0, dtype=I32)
-    msg_tgt = np.concatenate(tgts).astype(I32) if tgts else np.zeros(0, dtype=I32)
-    tgt_ptr, tgt_msgs = _csr(msg_tgt.astype(np.int64), N)
-    src_ptr, src_msgs = _csr(msg_src.astype(np.int64), N)
+    # all messages of the batch at once: per graph one concatenation (edge lists in type order), then two stable
+    # counting sorts -- by target, then by type -- give "type-major, target-sorted inside a type" with ties in
+    # (graph, list) order, exactly what sorting each type's concatenated list by target gives
+    srcs, tgts, typs = [], [], []
+    for g, o in zip(graphs, node_off[:-1]):
+        lists = [a for a in g.adjacency_lists[:num_edge_types]]
+        counts = [a.shape[0] for a in lists]
+        if sum(counts) == 0:
+            continue
+        adj = np.concatenate(lists, axis=0).astype(I32, copy=False)
+        srcs.append(adj[:, 0] + I32(o))
+        tgts.append(adj[:, 1] + I32(o))
+        typs.append(np.repeat(np.arange(len(lists), dtype=I32), counts))
+    if srcs:
+        all_src, all_tgt, all_typ = np.concatenate(srcs), np.concatenate(tgts), np.concatenate(typs)
+        _, by_tgt = _csr(all_tgt, N)
+        type_ptr, by_typ = _csr(all_typ[by_tgt], num_edge_types)
+        order = by_tgt[by_typ]
+        msg_src, msg_tgt = np.ascontiguousarray(all_src[order], dtype=I32), np.ascontiguousarray(all_tgt[order], dtype=I32)
+    else:
+        msg_src = msg_tgt = np.zeros(0, dtype=I32)
+        type_ptr = np.zeros(num_edge_types + 1, dtype=I32)
+    tgt_ptr, tgt_msgs = _csr(msg_tgt, N)
+    src_ptr, src_msgs = _csr(msg_src, N)
     # per-node kernels (one wave per node) take hubs first: a node with hundreds of messages keeps its wave busy
     # for about as long as the whole launch lasts, so it has to start at t = 0 (BASELINE config c4)
     deg = np.diff(tgt_ptr).astype(np.int64) + np.diff(src_ptr)

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "bl_vocab_create": ([c_char_p, c_void_p, c_int32], c_void_p),
     "bl_vocab_free": ([c_void_p], None),
     "bl_tensorize_nodes": ([c_void_p, c_int32, c_char_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p], c_int32),
+    "bl_counting_sort": ([c_void_p, c_int64, c_int32, c_void_p, c_void_p], c_int32),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
@@ -69,6 +70,25 @@ def load_library():
 
 def available() -> bool:
     return os.path.exists(LIB_PATH)
+
+
+def counting_sort(keys: np.ndarray, num_keys: int):
+    """Stable sort of integer `keys` in [0, num_keys): -> (ptr int32 [num_keys + 1], perm int32 [E]).  Native when the
+    library is built, NumPy otherwise (same result)."""
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    E = int(keys.shape[0])
+    if available():
+        lib = load_library()
+        ptr = np.empty(num_keys + 1, dtype=np.int32)
+        perm = np.empty(E, dtype=np.int32)
+        rc = lib.bl_counting_sort(keys.ctypes.data, E, int(num_keys), ptr.ctypes.data, perm.ctypes.data)
+        if rc != 0:
+            raise ValueError(lib.bl_data_last_error().decode())
+        return ptr, perm
+    ptr = np.zeros(num_keys + 1, dtype=np.int32)
+    if E:
+        np.cumsum(np.bincount(keys, minlength=num_keys), out=ptr[1:])
+    return ptr, np.argsort(keys, kind="stable").astype(np.int32)
 
 
 def _copy_i32(ptr, n: int) -> np.ndarray:

@@ -534,3 +534,20 @@ extern "C" int32_t bl_tensorize_nodes(const bl_vocab* v, int32_t unk_id, const c
   }
   return 0;
 }
+
+// Stable counting sort of `keys` in [0, K): the collator's CSRs (node -> incoming / outgoing messages),
+// the target order inside an edge type and the token-sorted subtoken occurrences are all this primitive;
+// NumPy's stable argsort on 64-bit keys (timsort) took 150 of the 160 ms a config-c2 minibatch needs.
+extern "C" int32_t bl_counting_sort(const int32_t* keys, int64_t E, int32_t K, int32_t* ptr, int32_t* perm) {
+  if ((E > 0 && (!keys || !perm)) || !ptr || K < 0 || E < 0 || E > 0x7fffffffLL) { set_err("bl_counting_sort: bad argument"); return -1; }
+  for (int32_t k = 0; k <= K; ++k) ptr[k] = 0;
+  for (int64_t i = 0; i < E; ++i) {
+    const int32_t k = keys[i];
+    if (k < 0 || k >= K) { set_err("bl_counting_sort: key %d outside [0, %d)", k, K); return -2; }
+    ++ptr[k + 1];
+  }
+  for (int32_t k = 0; k < K; ++k) ptr[k + 1] += ptr[k];
+  std::vector<int32_t> next(ptr, ptr + K);
+  for (int64_t i = 0; i < E; ++i) perm[next[keys[i]]++] = (int32_t)i;
+  return 0;
+}

@@ -256,3 +256,20 @@ def test_node_order_puts_hubs_first():
     k = int((deg > C.HUB_DEGREE).sum())
     assert k > 0 and (deg[order[:k]] > C.HUB_DEGREE).all() and (np.diff(deg[order[:k]]) <= 0).all()
     assert (np.diff(order[k:]) > 0).all()  # everyone else keeps the natural order
+
+
+def test_parallel_minibatch_iterator_preserves_order(tmp_path):
+    """Collation runs in several worker threads (runtime/neuralmodel.py): same minibatches, same order."""
+    from buglab.models.modelregistry import load_model
+
+    data = make_buglab_dataset(37, seed=2)
+    model, _, _ = load_model({"modelName": "gnn-mlp"}, tmp_path / "m.pkl.gz")
+    for d in copy.deepcopy(data):
+        model.update_metadata_from(d)
+    model.finalize_metadata()
+    tensors = [(model.tensorize(d), i) for i, d in enumerate(copy.deepcopy(data))]
+    seq = list(model.minibatch_iterator(iter(tensors), "cpu", 5, parallelize=False))
+    par = list(model.minibatch_iterator(iter(tensors), "cpu", 5, parallelize=True))
+    assert len(seq) == len(par) == 8 and [o for _, o in seq] == [o for _, o in par] == [list(range(i, min(i + 5, 37))) for i in range(0, 37, 5)]
+    for (a, _), (b, _) in zip(seq, par):
+        assert torch.equal(a["graph_data"]["msg_src"], b["graph_data"]["msg_src"]) and torch.equal(a["graph_data"]["token_ids"], b["graph_data"]["token_ids"])
