@@ -58,6 +58,34 @@ void bl_vocab_free(bl_vocab* v);
 int32_t bl_tensorize_nodes(const bl_vocab* v, int32_t unk_id, const char* text, const int32_t* off, int32_t n, int32_t S,
                            int32_t* ids, int32_t* lens, uint8_t* needs_python);
 
+/* ---- native collator of the graph part of a minibatch (buglab/data/collate.py::collate_graphs) ----
+ * replaces GnnBugLabModel.initialize/extend/finalize_minibatch's Python list appends, gnn.py:431-604. */
+typedef struct {
+  int32_t num_nodes;
+  int32_t token_stride;           /* columns of token_ids (<= S of the minibatch) */
+  const int32_t* token_ids;       /* [num_nodes][token_stride] */
+  const int32_t* token_lens;      /* [num_nodes] */
+  const int32_t* const* adj;      /* T pointers to int32 [count][2] (source, target), graph-local node ids */
+  const int32_t* adj_count;       /* [T] */
+} bl_graph_in_t;
+
+typedef struct {                  /* caller-allocated outputs; N = sum of num_nodes, E = sum of all adj_count */
+  int64_t num_nodes, num_messages;
+  int32_t* token_ids;             /* [N][S] */
+  int32_t* token_lens;            /* [N] */
+  int32_t* msg_src; int32_t* msg_tgt;   /* [E] type-major, target-sorted inside a type */
+  int32_t* type_ptr;              /* [T + 1] */
+  int32_t* tgt_ptr; int32_t* tgt_msgs;  /* [N + 1], [E] */
+  int32_t* src_ptr; int32_t* src_msgs;  /* [N + 1], [E] */
+  int32_t* node_order;            /* [N] nodes with more than hub_degree incident messages first (by degree), then the rest */
+  int64_t occ_capacity;           /* >= number of valid subtoken slots; sizes tok_occ, tok_chunk_id, tok_chunk_ptr (+1) */
+  int32_t* tok_occ; int32_t* tok_chunk_ptr; int32_t* tok_chunk_id;
+  int64_t num_occ, num_chunks;    /* written by the call */
+} bl_collated_t;
+
+int32_t bl_collate_graphs(const bl_graph_in_t* graphs, int32_t B, int32_t T, int32_t S, int32_t hub_degree,
+                          int32_t token_chunk, bl_collated_t* out);
+
 /* Stable counting sort of keys in [0, K): perm[E] = item indices ordered by key (ties keep input order),
  * ptr[K + 1] = where each key's run starts.  The collator's CSRs and per-type target order
  * (reference gnn.py:463-542 builds these with Python lists; here: one pass). */

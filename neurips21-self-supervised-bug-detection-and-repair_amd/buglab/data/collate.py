@@ -26,6 +26,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, NamedTuple, Optional, Sequence
 
+import os
+
 import numpy as np
 
 I32 = np.int32
@@ -124,14 +126,9 @@ def token_occurrence_chunks(token_ids: np.ndarray, token_lens: np.ndarray, chunk
     return occ, chunk_ptr, np.repeat(uniq, nch).astype(I32)
 
 
-def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -> Dict[str, Any]:
-    """Disjoint union of graphs -> one `graph_data` dict of NumPy arrays."""
-    B = len(graphs)
-    n_per_graph = np.array([g.num_nodes for g in graphs], dtype=np.int64)
-    node_off = np.zeros(B + 1, dtype=np.int64)
-    np.cumsum(n_per_graph, out=node_off[1:])
-    N = int(node_off[-1])
-
+def _collate_graph_arrays_numpy(graphs, num_edge_types: int, node_off: np.ndarray, N: int) -> Dict[str, np.ndarray]:
+    """NumPy version of `buglab.data.native.collate_graph_arrays` (used when the native library is not built, and as
+    its test reference)."""
     S = max((g.token_ids.shape[1] for g in graphs), default=1)
     token_ids = np.zeros((N, S), dtype=I32)
     token_lens = np.zeros(N, dtype=I32)
@@ -176,6 +173,30 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
         node_order = np.concatenate([hubs, np.flatnonzero(rest)]).astype(I32)
     else:
         node_order = np.arange(N, dtype=I32)
+
+    return {"token_ids": token_ids, "token_lens": token_lens, "msg_src": msg_src, "msg_tgt": msg_tgt, "type_ptr": np.asarray(type_ptr, dtype=I32),
+            "tgt_ptr": tgt_ptr, "tgt_msgs": tgt_msgs, "src_ptr": src_ptr, "src_msgs": src_msgs, "node_order": node_order,
+            "tok_occ": tok_occ, "tok_chunk_ptr": tok_chunk_ptr, "tok_chunk_id": tok_chunk_id}
+
+
+def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -> Dict[str, Any]:
+    """Disjoint union of graphs -> one `graph_data` dict of NumPy arrays."""
+    B = len(graphs)
+    n_per_graph = np.array([g.num_nodes for g in graphs], dtype=np.int64)
+    node_off = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(n_per_graph, out=node_off[1:])
+    N = int(node_off[-1])
+
+    from buglab.data import native
+
+    if native.available() and os.environ.get("BUGLAB_NATIVE_COLLATE", "1") != "0":
+        arr = native.collate_graph_arrays(graphs, num_edge_types, HUB_DEGREE, TOKEN_CHUNK)  # one GIL-free native call
+    else:
+        arr = _collate_graph_arrays_numpy(graphs, num_edge_types, node_off, N)
+    token_ids, token_lens, node_order = arr["token_ids"], arr["token_lens"], arr["node_order"]
+    tok_occ, tok_chunk_ptr, tok_chunk_id = arr["tok_occ"], arr["tok_chunk_ptr"], arr["tok_chunk_id"]
+    msg_src, msg_tgt, type_ptr = arr["msg_src"], arr["msg_tgt"], arr["type_ptr"]
+    tgt_ptr, tgt_msgs, src_ptr, src_msgs = arr["tgt_ptr"], arr["tgt_msgs"], arr["src_ptr"], arr["src_msgs"]
 
     ref_ids: Dict[str, np.ndarray] = {}
     ref_graph: Dict[str, np.ndarray] = {}

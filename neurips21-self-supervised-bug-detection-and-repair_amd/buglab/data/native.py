@@ -40,6 +40,18 @@ class bl_datapoint_t(Structure):
     ]
 
 
+class bl_graph_in_t(Structure):
+    _fields_ = [("num_nodes", c_int32), ("token_stride", c_int32), ("token_ids", c_void_p), ("token_lens", c_void_p),
+                ("adj", c_void_p), ("adj_count", c_void_p)]
+
+
+class bl_collated_t(Structure):
+    _fields_ = [("num_nodes", c_int64), ("num_messages", c_int64), ("token_ids", c_void_p), ("token_lens", c_void_p),
+                ("msg_src", c_void_p), ("msg_tgt", c_void_p), ("type_ptr", c_void_p), ("tgt_ptr", c_void_p), ("tgt_msgs", c_void_p),
+                ("src_ptr", c_void_p), ("src_msgs", c_void_p), ("node_order", c_void_p), ("occ_capacity", c_int64),
+                ("tok_occ", c_void_p), ("tok_chunk_ptr", c_void_p), ("tok_chunk_id", c_void_p), ("num_occ", c_int64), ("num_chunks", c_int64)]
+
+
 _SIGNATURES = {
     "bl_data_last_error": ([], c_char_p),
     "bl_data_version": ([], c_int32),
@@ -50,6 +62,7 @@ _SIGNATURES = {
     "bl_vocab_free": ([c_void_p], None),
     "bl_tensorize_nodes": ([c_void_p, c_int32, c_char_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p], c_int32),
     "bl_counting_sort": ([c_void_p, c_int64, c_int32, c_void_p, c_void_p], c_int32),
+    "bl_collate_graphs": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(bl_collated_t)], c_int32),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
@@ -89,6 +102,48 @@ def counting_sort(keys: np.ndarray, num_keys: int):
     if E:
         np.cumsum(np.bincount(keys, minlength=num_keys), out=ptr[1:])
     return ptr, np.argsort(keys, kind="stable").astype(np.int32)
+
+
+def collate_graph_arrays(graphs, num_edge_types: int, hub_degree: int, token_chunk: int) -> Dict[str, np.ndarray]:
+    """The node / message / CSR / order / token-chunk arrays of `buglab.data.collate.collate_graphs`, built by
+    `bl_collate_graphs` in one GIL-free call.  `graphs`: TensorizedGraphData (token_ids, token_lens, adjacency_lists)."""
+    lib = load_library()
+    B, T = len(graphs), int(num_edge_types)
+    S = max((g.token_ids.shape[1] for g in graphs), default=1)
+    gin = (bl_graph_in_t * max(B, 1))()
+    keep = []  # arrays referenced by raw pointers must outlive the call
+    N = E = 0
+    empty = np.zeros((0, 2), dtype=np.int32)
+    for b, g in enumerate(graphs):
+        ids = np.ascontiguousarray(g.token_ids, dtype=np.int32)
+        lens = np.ascontiguousarray(g.token_lens, dtype=np.int32)
+        lists = [np.ascontiguousarray(g.adjacency_lists[t] if t < len(g.adjacency_lists) else empty, dtype=np.int32).reshape(-1, 2)
+                 for t in range(T)]
+        counts = np.array([a.shape[0] for a in lists], dtype=np.int32)
+        ptrs = (c_void_p * T)(*[a.ctypes.data for a in lists])
+        keep.append((ids, lens, lists, counts, ptrs))
+        gin[b].num_nodes, gin[b].token_stride = ids.shape[0], max(1, ids.shape[1])
+        gin[b].token_ids, gin[b].token_lens = ids.ctypes.data, lens.ctypes.data
+        gin[b].adj, gin[b].adj_count = ctypes.cast(ptrs, c_void_p), counts.ctypes.data
+        N += ids.shape[0]
+        E += int(counts.sum())
+    cap = N * S
+    o = {"token_ids": np.empty((N, S), np.int32), "token_lens": np.empty(N, np.int32), "msg_src": np.empty(E, np.int32),
+         "msg_tgt": np.empty(E, np.int32), "type_ptr": np.empty(T + 1, np.int32), "tgt_ptr": np.empty(N + 1, np.int32),
+         "tgt_msgs": np.empty(E, np.int32), "src_ptr": np.empty(N + 1, np.int32), "src_msgs": np.empty(E, np.int32),
+         "node_order": np.empty(N, np.int32), "tok_occ": np.empty(cap, np.int32), "tok_chunk_ptr": np.empty(cap + 1, np.int32),
+         "tok_chunk_id": np.empty(cap, np.int32)}
+    c = bl_collated_t()
+    c.num_nodes, c.num_messages, c.occ_capacity = N, E, cap
+    for k, a in o.items():
+        setattr(c, k, a.ctypes.data)
+    rc = lib.bl_collate_graphs(ctypes.cast(gin, c_void_p), B, T, S, int(hub_degree), int(token_chunk), ctypes.byref(c))
+    if rc != 0:
+        raise ValueError(lib.bl_data_last_error().decode())
+    o["tok_occ"] = o["tok_occ"][: c.num_occ]
+    o["tok_chunk_ptr"] = o["tok_chunk_ptr"][: c.num_chunks + 1]
+    o["tok_chunk_id"] = o["tok_chunk_id"][: c.num_chunks]
+    return o
 
 
 def _copy_i32(ptr, n: int) -> np.ndarray:

@@ -551,3 +551,133 @@ extern "C" int32_t bl_counting_sort(const int32_t* keys, int64_t E, int32_t K, i
   for (int64_t i = 0; i < E; ++i) perm[next[keys[i]]++] = (int32_t)i;
   return 0;
 }
+
+// ---- native collator for the graph part of a minibatch (buglab/data/collate.py::collate_graphs) ------------------
+// Disjoint union of B tensorised graphs: node arrays concatenated, messages merged type-major and target-sorted
+// inside a type (ties in (graph, list) order), both CSRs, the hub-first node order and the token-sorted
+// subtoken occurrence chunks -- all in one pass-structured function without Python objects, so several
+// minibatches collate concurrently in worker threads (ctypes releases the GIL for the call).
+// reference: GnnBugLabModel.initialize/extend/finalize_minibatch, gnn.py:431-604 (Python list appends).
+extern "C" int32_t bl_collate_graphs(const bl_graph_in_t* graphs, int32_t B, int32_t T, int32_t S, int32_t hub_degree,
+                                     int32_t token_chunk, bl_collated_t* out) {
+  if (!graphs || !out || B < 0 || T < 1 || S < 1 || token_chunk < 1) { set_err("bl_collate_graphs: bad argument"); return -1; }
+  // node offsets, token arrays
+  int64_t N = 0, E = 0;
+  std::vector<int64_t> node_off((size_t)B + 1, 0);
+  for (int32_t b = 0; b < B; ++b) {
+    const bl_graph_in_t& g = graphs[b];
+    if (g.num_nodes < 0 || g.token_stride < 1 || g.token_stride > S) { set_err("bl_collate_graphs: graph %d: bad node count / token stride", b); return -1; }
+    node_off[b + 1] = node_off[b] + g.num_nodes;
+    for (int32_t t = 0; t < T; ++t) E += g.adj_count ? g.adj_count[t] : 0;
+  }
+  N = node_off[B];
+  if (N != out->num_nodes || E != out->num_messages) { set_err("bl_collate_graphs: output sized for N=%lld E=%lld, inputs hold N=%lld E=%lld", (long long)out->num_nodes, (long long)out->num_messages, (long long)N, (long long)E); return -1; }
+  if (N > 0x7fffffffLL || E > 0x7fffffffLL) { set_err("bl_collate_graphs: more than 2^31 nodes or messages"); return -1; }
+  int64_t n_occ = 0;
+  for (int32_t b = 0; b < B; ++b) {
+    const bl_graph_in_t& g = graphs[b];
+    for (int32_t i = 0; i < g.num_nodes; ++i) {
+      int32_t* row = out->token_ids + (size_t)(node_off[b] + i) * S;
+      const int32_t* in = g.token_ids + (size_t)i * g.token_stride;
+      for (int32_t k = 0; k < g.token_stride; ++k) row[k] = in[k];
+      for (int32_t k = g.token_stride; k < S; ++k) row[k] = 0;
+      const int32_t len = g.token_lens[i];
+      out->token_lens[node_off[b] + i] = len;
+      n_occ += len < 0 ? 0 : (len > S ? S : len);
+    }
+  }
+  // messages: per type, gather in graph order, then a stable counting sort by target inside the type
+  std::vector<int32_t> tsrc, ttgt, cnt((size_t)N + 1);
+  int64_t pos = 0;
+  out->type_ptr[0] = 0;
+  for (int32_t t = 0; t < T; ++t) {
+    tsrc.clear(); ttgt.clear();
+    for (int32_t b = 0; b < B; ++b) {
+      const bl_graph_in_t& g = graphs[b];
+      const int32_t c = g.adj_count ? g.adj_count[t] : 0;
+      const int32_t* a = g.adj ? g.adj[t] : nullptr;
+      const int32_t off = (int32_t)node_off[b];
+      for (int32_t e = 0; e < c; ++e) {
+        const int32_t u = a[2 * e], v = a[2 * e + 1];
+        if (u < 0 || u >= g.num_nodes || v < 0 || v >= g.num_nodes) { set_err("bl_collate_graphs: graph %d type %d edge %d: node id out of range", b, t, e); return -2; }
+        tsrc.push_back(u + off);
+        ttgt.push_back(v + off);
+      }
+    }
+    const size_t m = ttgt.size();
+    if (m) {
+      // counting sort over the target ids that occur: min..max window keeps the histogram small per type
+      int32_t lo = ttgt[0], hi = ttgt[0];
+      for (size_t i = 1; i < m; ++i) { lo = std::min(lo, ttgt[i]); hi = std::max(hi, ttgt[i]); }
+      const size_t span = (size_t)(hi - lo) + 2;
+      std::fill(cnt.begin(), cnt.begin() + span, 0);
+      for (size_t i = 0; i < m; ++i) ++cnt[(size_t)(ttgt[i] - lo) + 1];
+      for (size_t k = 1; k < span; ++k) cnt[k] += cnt[k - 1];
+      for (size_t i = 0; i < m; ++i) {
+        const int32_t p = cnt[(size_t)(ttgt[i] - lo)]++;
+        out->msg_src[pos + p] = tsrc[i];
+        out->msg_tgt[pos + p] = ttgt[i];
+      }
+    }
+    pos += (int64_t)m;
+    out->type_ptr[t + 1] = (int32_t)pos;
+  }
+  // CSRs node -> incoming / outgoing message ids (ascending)
+  auto csr = [&](const int32_t* keys, int32_t* ptr, int32_t* items) {
+    for (int64_t k = 0; k <= N; ++k) ptr[k] = 0;
+    for (int64_t i = 0; i < E; ++i) ++ptr[keys[i] + 1];
+    for (int64_t k = 0; k < N; ++k) ptr[k + 1] += ptr[k];
+    std::copy(ptr, ptr + N, cnt.begin());
+    for (int64_t i = 0; i < E; ++i) items[cnt[keys[i]]++] = (int32_t)i;
+  };
+  csr(out->msg_tgt, out->tgt_ptr, out->tgt_msgs);
+  csr(out->msg_src, out->src_ptr, out->src_msgs);
+  // hub-first processing order of the per-node kernels
+  {
+    std::vector<int32_t> hubs;
+    auto deg = [&](int32_t n) { return (out->tgt_ptr[n + 1] - out->tgt_ptr[n]) + (out->src_ptr[n + 1] - out->src_ptr[n]); };
+    for (int32_t n = 0; n < (int32_t)N; ++n)
+      if (deg(n) > hub_degree) hubs.push_back(n);
+    std::stable_sort(hubs.begin(), hubs.end(), [&](int32_t a, int32_t b) { return deg(a) > deg(b); });
+    int64_t w = 0;
+    for (int32_t h : hubs) out->node_order[w++] = h;
+    for (int32_t n = 0; n < (int32_t)N; ++n)
+      if (deg(n) <= hub_degree) out->node_order[w++] = n;
+  }
+  // token-sorted subtoken occurrences, cut in chunks of one token each
+  if (n_occ > out->occ_capacity) { set_err("bl_collate_graphs: occ_capacity %lld < %lld occurrences", (long long)out->occ_capacity, (long long)n_occ); return -1; }
+  {
+    int32_t vmax = -1;
+    for (int64_t n = 0; n < N; ++n) {
+      const int32_t len = std::min(std::max(out->token_lens[n], 0), S);
+      for (int32_t k = 0; k < len; ++k) {
+        const int32_t id = out->token_ids[(size_t)n * S + k];
+        if (id < 0) { set_err("bl_collate_graphs: negative token id"); return -2; }
+        vmax = std::max(vmax, id);
+      }
+    }
+    std::vector<int32_t> tcnt((size_t)vmax + 2, 0);
+    for (int64_t n = 0; n < N; ++n) {
+      const int32_t len = std::min(std::max(out->token_lens[n], 0), S);
+      for (int32_t k = 0; k < len; ++k) ++tcnt[(size_t)out->token_ids[(size_t)n * S + k] + 1];
+    }
+    for (int32_t v = 0; v <= vmax; ++v) tcnt[(size_t)v + 1] += tcnt[v];
+    std::vector<int32_t> tstart(tcnt.begin(), tcnt.end());
+    for (int64_t n = 0; n < N; ++n) {
+      const int32_t len = std::min(std::max(out->token_lens[n], 0), S);
+      for (int32_t k = 0; k < len; ++k) out->tok_occ[tcnt[out->token_ids[(size_t)n * S + k]]++] = (int32_t)(n * S + k);
+    }
+    int64_t nchunks = 0;
+    for (int32_t v = 0; v <= vmax; ++v) {
+      for (int32_t beg = tstart[v]; beg < tstart[(size_t)v + 1]; beg += token_chunk) {
+        out->tok_chunk_ptr[nchunks] = beg;
+        out->tok_chunk_id[nchunks] = v;
+        ++nchunks;
+      }
+    }
+    out->tok_chunk_ptr[nchunks] = (int32_t)n_occ;
+    out->num_occ = n_occ;
+    out->num_chunks = nchunks;
+  }
+  return 0;
+}

@@ -135,3 +135,25 @@ def test_bad_files_are_reported_and_skipped(tmp_path, capsys):
     assert "Error loading" in capsys.readouterr().out
     with pytest.raises((OSError, ValueError)):
         list(native.load_msgpack_l_gz_native(str(tmp_path / "missing.msgpack.l.gz")))
+
+
+@pytest.mark.parametrize("degree", ["uniform", "powerlaw"])
+def test_native_collator_equals_numpy_collator(degree, monkeypatch):
+    """bl_collate_graphs (one GIL-free call) against the NumPy collator, array by array."""
+    from buglab.data import collate as C
+    from buglab.data.synthetic import make_samples
+
+    samples = make_samples(7, seed=11, num_nodes=180, num_messages=1100, num_edge_types=5, degree=degree, max_degree=300)
+    samples[3].graph_data.adjacency_lists[2] = np.zeros((0, 2), np.int32)   # an empty edge type in one graph
+    samples[5].graph_data.token_lens[:7] = 0                                # nodes without subtokens
+    monkeypatch.setenv("BUGLAB_NATIVE_COLLATE", "1")
+    a = C.collate_samples(samples, 6)["graph_data"]                         # 6 presented types: the last one is empty everywhere
+    monkeypatch.setenv("BUGLAB_NATIVE_COLLATE", "0")
+    b = C.collate_samples(samples, 6)["graph_data"]
+    for k in ("token_ids", "token_lens", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_order",
+              "tok_occ", "tok_chunk_ptr", "tok_chunk_id"):
+        assert a[k].dtype == np.int32 and np.array_equal(a[k], b[k]), k
+    assert (np.diff(a["tgt_ptr"]) + np.diff(a["src_ptr"])).max() > C.HUB_DEGREE or degree == "uniform"
+    # an empty minibatch of graphs without edges
+    empty = C.collate_graphs([], 4)
+    assert empty["msg_src"].size == 0 and empty["type_ptr"].tolist() == [0] * 5
