@@ -334,9 +334,13 @@ class GnnBugLabModel(AbstractNeuralModel, AbstractBugLabModel):
         partial_minibatch["num_nodes"] += tensorized_datapoint.graph_data.num_nodes
         return partial_minibatch["num_nodes"] < self._gnn_model.stop_extending_minibatch_after_num_nodes
 
+    def collate_minibatch(self, accumulated_minibatch_data: Dict[str, Any]) -> Dict[str, Any]:
+        """The host half of `finalize_minibatch`: NumPy arrays only, so loader processes can run it
+        (runtime/shardloader.py) and ship whole minibatches."""
+        return C.collate_samples(accumulated_minibatch_data["samples"], self._gnn_model.num_presented_edge_types)
+
     def finalize_minibatch(self, accumulated_minibatch_data: Dict[str, Any], device: Union[str, torch.device]) -> Dict[str, Any]:
-        mb = C.collate_samples(accumulated_minibatch_data["samples"], self._gnn_model.num_presented_edge_types)
-        return C.to_device(mb, device)
+        return C.to_device(self.collate_minibatch(accumulated_minibatch_data), device)
 
     def predict(self, data: Iterator[BugLabData], trained_nn: GnnBugLabModule, device, parallelize: bool
                 ) -> Iterator[Tuple[BugLabData, Dict[int, float], List[float]]]:

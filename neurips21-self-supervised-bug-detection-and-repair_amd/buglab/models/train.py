@@ -36,6 +36,7 @@ from buglab.models.modelregistry import load_model
 from buglab.models.utils import LinearWarmupScheduler, optimizer
 from buglab.runtime import distributed as D
 from buglab.runtime.richpath import RichPath, run_and_debug
+from buglab.runtime.shardloader import ShardDataset
 from buglab.runtime.trainer import LazyDataIterable, ModelTrainer
 from buglab.utils.msgpackutils import load_all_msgpack_l_gz
 
@@ -57,11 +58,11 @@ def run(arguments):
     if max_files_per_fold is not None:
         max_files_per_fold = int(max_files_per_fold)
     training_data_path = RichPath.create(arguments["TRAIN_DATA_PATH"])
-    training_data = LazyDataIterable(construct_data_loading_callable(
-        training_data_path, shuffle=True, max_files_per_fold=max_files_per_fold,
-        limit_num_yielded_elements=int(arguments["--validate-after"])))
-    validation_data = LazyDataIterable(construct_data_loading_callable(
-        RichPath.create(arguments["VALID_DATA_PATH"]), max_files_per_fold=max_files_per_fold))
+    # same datapoints as the reference's LazyDataIterable(load_all_msgpack_l_gz(...)) (train.py:76-91), plus the
+    # list of shard files so that reading + tensorising can run in worker processes (runtime/shardloader.py)
+    training_data = ShardDataset(training_data_path, shuffle=True, take_only_first_n_files=max_files_per_fold,
+                                 limit_num_yielded_elements=int(arguments["--validate-after"]))
+    validation_data = ShardDataset(RichPath.create(arguments["VALID_DATA_PATH"]), take_only_first_n_files=max_files_per_fold)
     model_path = Path(arguments["MODEL_FILENAME"])
     model_spec = {"modelName": arguments["MODEL_NAME"]}
     if arguments.get("--model-spec"):
@@ -80,7 +81,7 @@ def run(arguments):
                                                                               limit_num_yielded_elements=250_000))
         trainer.load_metadata_and_create_network(data_for_metadata, not arguments["--sequential"], not arguments["--quiet"])
     trainer.train(training_data, validation_data, show_progress_bar=not arguments["--quiet"], initialize_metadata=False,
-                  parallelize=not arguments["--sequential"], patience=10)
+                  parallelize=not arguments["--sequential"], use_multiprocessing=not arguments["--sequential"], patience=10)
 
 
 def parse_args(argv=None):

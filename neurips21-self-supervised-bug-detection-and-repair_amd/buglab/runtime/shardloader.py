@@ -1,0 +1,154 @@
+"""Multi-process shard loading: worker processes read `*.msgpack.l.gz` shards (native reader), tensorise the
+datapoints and hand the tensorised samples to the trainer, which only collates (native collator) and drives the GPU.
+
+Why: reading + tensorising on the fly is Python-bound at ~500-600 graphs/s per process, the device consumes
+~3 000 graphs/s (config c2).  The reference parallelises the same stage with threads (`parallelize=True`,
+ptgnn) or ptgnn's `use_multiprocessing`; here the unit of parallelism is the shard file, so no datapoint is
+pickled -- only the (NumPy) tensorised samples cross the process boundary.
+
+Host-only; nothing here touches the HIP extension (workers never initialise a GPU)."""
+import multiprocessing as mp
+import os
+import queue as queue_mod
+import random
+from typing import Iterable, Iterator, List, Optional, Sequence
+
+from buglab.runtime.richpath import RichPath
+from buglab.utils.msgpackutils import load_all_msgpack_l_gz, load_msgpack_l_gz
+
+_DONE = "__shard_worker_done__"
+
+
+class ShardDataset:
+    """The datapoints of a directory of shards -- iterable like the reference's `LazyDataIterable(load_all_msgpack_l_gz...)`
+    (train.py:76-91), and additionally aware of its files so that loading can be spread over processes."""
+
+    def __init__(self, path, shuffle: bool = False, take_only_first_n_files: Optional[int] = None,
+                 limit_num_yielded_elements: Optional[int] = None):
+        self.path = path if isinstance(path, RichPath) else RichPath.create(str(path))
+        self.shuffle, self.take_only_first_n_files = shuffle, take_only_first_n_files
+        self.limit_num_yielded_elements = limit_num_yielded_elements
+
+    def shard_files(self) -> List[str]:
+        files = sorted(self.path.iterate_filtered_files_in_dir("*.msgpack.l.gz"))
+        if self.take_only_first_n_files is not None:
+            files = files[: self.take_only_first_n_files]
+        files = [f.to_local_path().path for f in files]
+        if self.shuffle:
+            random.shuffle(files)
+        return files
+
+    def __iter__(self):
+        return iter(load_all_msgpack_l_gz(self.path, shuffle=self.shuffle, take_only_first_n_files=self.take_only_first_n_files,
+                                          limit_num_yielded_elements=self.limit_num_yielded_elements))
+
+
+def default_num_workers() -> int:
+    """BUGLAB_LOADER_WORKERS (0 = load in the trainer process); default: up to 8, leaving cores for the ranks of a node."""
+    env = os.environ.get("BUGLAB_LOADER_WORKERS")
+    if env is not None:
+        return max(0, int(env))
+    cores = os.cpu_count() or 1
+    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return max(0, min(8, cores // max(1, world) - 1))
+
+
+def _worker(model, files: Sequence[str], rank: int, world: int, out_q, stop) -> None:
+    try:
+        for f in files:
+            try:
+                for i, d in enumerate(load_msgpack_l_gz(f)):
+                    if stop.is_set():
+                        return
+                    if d is None or i % world != rank:
+                        continue
+                    t = model.tensorize(d)
+                    if t is not None:  # dropped sample (reference gnn.py:404-405)
+                        out_q.put(t)
+            except Exception as e:  # reference msgpackutils.py:45-46: bad files are reported and skipped
+                print(f"Error loading {f}: {e}.")
+    finally:
+        out_q.put(_DONE)
+
+
+def _minibatch_worker(model, files: Sequence[str], rank: int, world: int, max_minibatch_size: int, out_q, stop) -> None:
+    try:
+        mb, n = model.initialize_minibatch(), 0
+        for f in files:
+            try:
+                for i, d in enumerate(load_msgpack_l_gz(f)):
+                    if stop.is_set():
+                        return
+                    if d is None or i % world != rank:
+                        continue
+                    t = model.tensorize(d)
+                    if t is None:
+                        continue
+                    keep = model.extend_minibatch_with(t, mb)
+                    n += 1
+                    if not keep or n >= max_minibatch_size:
+                        out_q.put(model.collate_minibatch(mb))
+                        mb, n = model.initialize_minibatch(), 0
+            except Exception as e:
+                print(f"Error loading {f}: {e}.")
+        if n > 0:
+            out_q.put(model.collate_minibatch(mb))
+    finally:
+        out_q.put(_DONE)
+
+
+def collated_minibatches_parallel(model, files: Sequence[str], num_workers: int, max_minibatch_size: int, rank: int = 0,
+                                  world: int = 1) -> Iterator:
+    """Collated (NumPy) minibatches of `files`: every worker process reads its shard files, tensorises and collates;
+    the consumer only copies a minibatch to the device (`buglab.data.collate.to_device`).  One pickle per minibatch
+    crosses the process boundary instead of one per sample."""
+    yield from _run_workers(_minibatch_worker, model, files, num_workers, (rank, world, max_minibatch_size), 8, None)
+
+
+def tensorize_shards_parallel(model, files: Sequence[str], num_workers: int, rank: int = 0, world: int = 1,
+                              limit_num_yielded_elements: Optional[int] = None) -> Iterator:
+    """Tensorised samples of `files`, produced by `num_workers` forked processes (worker w takes files w, w + W, ...).
+    Under data parallelism every rank keeps the datapoints with index % world == rank of each file, like the in-process
+    loader.  Sample order across files is not deterministic (files are shuffled by the trainer anyway)."""
+    yield from _run_workers(_worker, model, files, num_workers, (rank, world), 512, limit_num_yielded_elements)
+
+
+def _run_workers(target, model, files: Sequence[str], num_workers: int, extra_args, queue_size: int, limit: Optional[int]) -> Iterator:
+    files = list(files)
+    num_workers = max(1, min(num_workers, len(files))) if files else 0
+    if num_workers == 0:
+        return
+    ctx = mp.get_context("fork")  # the model (vocabulary, caches) is shared copy-on-write; nothing is pickled to start
+    out_q = ctx.Queue(maxsize=queue_size)
+    stop = ctx.Event()
+    procs = [ctx.Process(target=target, args=(model, files[w::num_workers], *extra_args, out_q, stop), daemon=True)
+             for w in range(num_workers)]
+    for p in procs:
+        p.start()
+    done, n = 0, 0
+    try:
+        while done < num_workers:
+            try:
+                item = out_q.get(timeout=1.0)
+            except queue_mod.Empty:
+                if not any(p.is_alive() for p in procs) and out_q.empty():
+                    break  # a worker died without its sentinel
+                continue
+            if isinstance(item, str) and item == _DONE:
+                done += 1
+                continue
+            yield item
+            n += 1
+            if limit is not None and n >= limit:
+                break
+    finally:
+        stop.set()
+        try:  # unblock workers stuck on a full queue, then reap them
+            while True:
+                out_q.get_nowait()
+        except queue_mod.Empty:
+            pass
+        for p in procs:
+            p.join(timeout=2.0)
+            if p.is_alive():
+                p.terminate()

@@ -55,6 +55,7 @@ class ModelTrainer:
         if enable_amp:
             raise NotImplementedError("AMP is out of scope for the fp32-parity HIP path (SURVEY.md section 5)")
         self._nn = None
+        self._use_multiprocessing = False
         self._train_epoch_end_hooks: List[Callable] = []
         self._validation_epoch_end_hooks: List[Callable] = []
         self._training_start_hooks: List[Callable] = []
@@ -99,6 +100,22 @@ class ModelTrainer:
                 yield d
 
     def _iter_minibatches(self, data, device, parallelize, shuffle_key=None):
+        from buglab.runtime.shardloader import collated_minibatches_parallel, default_num_workers
+
+        workers = default_num_workers() if (parallelize and self._use_multiprocessing) else 0
+        if workers > 0 and hasattr(data, "shard_files") and hasattr(self.model, "collate_minibatch"):
+            # shard files are read, tensorised and collated by worker processes; this process copies whole
+            # minibatches to the device and drives the GPU
+            from buglab.data.collate import to_device
+
+            rank, world = self._world()
+            limit, seen = getattr(data, "limit_num_yielded_elements", None), 0
+            for mb_np in collated_minibatches_parallel(self.model, data.shard_files(), workers, self._minibatch_size, rank, world):
+                yield to_device(mb_np, device)
+                seen += int(mb_np["graph_data"]["num_graphs"]) * world
+                if limit is not None and seen >= limit:
+                    break
+            return
         tensors = self.model.tensorize_dataset(self._rank_share(data), parallelize=parallelize)
         for mb, _ in self.model.minibatch_iterator(tensors, device, self._minibatch_size, parallelize=parallelize):
             yield mb
@@ -169,6 +186,7 @@ class ModelTrainer:
     def train(self, training_data: Iterable, validation_data: Iterable, *, show_progress_bar: bool = True,
               initialize_metadata: bool = True, parallelize: bool = True, use_multiprocessing: bool = False, patience: int = 5,
               device=None):
+        self._use_multiprocessing = bool(use_multiprocessing)
         if initialize_metadata:
             self.load_metadata_and_create_network(training_data, parallelize, show_progress_bar)
         if device is None:

@@ -273,3 +273,53 @@ def test_parallel_minibatch_iterator_preserves_order(tmp_path):
     assert len(seq) == len(par) == 8 and [o for _, o in seq] == [o for _, o in par] == [list(range(i, min(i + 5, 37))) for i in range(0, 37, 5)]
     for (a, _), (b, _) in zip(seq, par):
         assert torch.equal(a["graph_data"]["msg_src"], b["graph_data"]["msg_src"]) and torch.equal(a["graph_data"]["token_ids"], b["graph_data"]["token_ids"])
+
+
+def test_shard_loader_processes_yield_every_sample_once(tmp_path):
+    """runtime/shardloader.py: worker processes read + tensorise whole shard files; together (and over the ranks of a
+    data-parallel job) they yield exactly the samples of the in-process loader."""
+    from buglab.models.modelregistry import load_model
+    from buglab.runtime.shardloader import ShardDataset, tensorize_shards_parallel
+    from buglab.utils.msgpackutils import save_msgpack_l_gz
+
+    data = make_buglab_dataset(45, seed=4)
+    for i in range(5):
+        save_msgpack_l_gz(data[9 * i : 9 * i + 9], tmp_path / f"s{i}.msgpack.l.gz")
+    ds = ShardDataset(str(tmp_path))
+    assert len(ds.shard_files()) == 5 and len(list(ds)) == 45
+    model, _, _ = load_model({"modelName": "gnn-mlp"}, tmp_path / "m.pkl.gz")
+    for d in ds:
+        model.update_metadata_from(d)
+    model.finalize_metadata()
+
+    def key(t):
+        return (t.graph_data.token_ids.tobytes(), tuple(a.tobytes() for a in t.graph_data.adjacency_lists))
+
+    ref = sorted(key(model.tensorize(d)) for d in ds)
+    got = sorted(key(t) for t in tensorize_shards_parallel(model, ds.shard_files(), num_workers=3))
+    assert got == ref
+    shares = [list(tensorize_shards_parallel(model, ds.shard_files(), num_workers=2, rank=r, world=2)) for r in range(2)]
+    assert sorted(key(t) for s in shares for t in s) == ref and abs(len(shares[0]) - len(shares[1])) <= 5
+    assert len(list(tensorize_shards_parallel(model, ds.shard_files(), num_workers=2, limit_num_yielded_elements=7))) == 7
+
+
+def test_shard_loader_collated_minibatches(tmp_path):
+    """Worker processes can also collate: whole NumPy minibatches cross the process boundary, every sample exactly once."""
+    from buglab.models.modelregistry import load_model
+    from buglab.runtime.shardloader import ShardDataset, collated_minibatches_parallel
+    from buglab.utils.msgpackutils import save_msgpack_l_gz
+
+    data = make_buglab_dataset(40, seed=9)
+    for i in range(4):
+        save_msgpack_l_gz(data[10 * i : 10 * i + 10], tmp_path / f"s{i}.msgpack.l.gz")
+    ds = ShardDataset(str(tmp_path))
+    model, _, _ = load_model({"modelName": "gnn-mlp"}, tmp_path / "m.pkl.gz")
+    for d in ds:
+        model.update_metadata_from(d)
+    model.finalize_metadata()
+    mbs = list(collated_minibatches_parallel(model, ds.shard_files(), num_workers=2, max_minibatch_size=4))
+    assert sum(int(m["graph_data"]["num_graphs"]) for m in mbs) == 40 and all(int(m["graph_data"]["num_graphs"]) <= 4 for m in mbs)
+    ref_nodes = sorted(model.tensorize(d).graph_data.num_nodes for d in ds)
+    assert sorted(int(n) for m in mbs for n in m["graph_data"]["num_nodes_per_graph"]) == ref_nodes
+    dev = C.to_device(mbs[0], "cpu")
+    assert dev["graph_data"]["msg_src"].dtype == torch.int32
