@@ -23,6 +23,32 @@ from buglab.runtime.optim import FlatAdam
 LOGGER = logging.getLogger(__name__)
 
 
+def _prefetch(iterator, depth: int = 2):
+    """Runs `iterator` in a background thread, `depth` items ahead; exceptions are re-raised in the consumer."""
+    import queue
+    import threading
+
+    q: "queue.Queue" = queue.Queue(maxsize=depth)
+    end = object()
+
+    def work():
+        try:
+            for x in iterator:
+                q.put(x)
+            q.put(end)
+        except BaseException as e:
+            q.put(e)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        x = q.get()
+        if x is end:
+            return
+        if isinstance(x, BaseException):
+            raise x
+        yield x
+
+
 class AbstractScheduler:
     def step(self, epoch_idx: int, epoch_step: int) -> None:
         raise NotImplementedError
@@ -109,12 +135,17 @@ class ModelTrainer:
             from buglab.data.collate import to_device
 
             rank, world = self._world()
-            limit, seen = getattr(data, "limit_num_yielded_elements", None), 0
-            for mb_np in collated_minibatches_parallel(self.model, data.shard_files(), workers, self._minibatch_size, rank, world):
-                yield to_device(mb_np, device)
-                seen += int(mb_np["graph_data"]["num_graphs"]) * world
-                if limit is not None and seen >= limit:
-                    break
+            limit = getattr(data, "limit_num_yielded_elements", None)
+
+            def received():  # runs in a prefetch thread: pipe reads / unpickling / the pinned H2D copy overlap the
+                seen = 0     # trainer thread's kernel launches
+                for mb_np in collated_minibatches_parallel(self.model, data.shard_files(), workers, self._minibatch_size, rank, world):
+                    yield to_device(mb_np, device)
+                    seen += int(mb_np["graph_data"]["num_graphs"]) * world
+                    if limit is not None and seen >= limit:
+                        break
+
+            yield from _prefetch(received(), depth=3)
             return
         tensors = self.model.tensorize_dataset(self._rank_share(data), parallelize=parallelize)
         for mb, _ in self.model.minibatch_iterator(tensors, device, self._minibatch_size, parallelize=parallelize):
