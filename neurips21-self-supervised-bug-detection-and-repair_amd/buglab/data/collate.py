@@ -361,13 +361,10 @@ _INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "
                 "head_gather_idx", "head_local_idx", "node_order", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
 
 
-def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
-    """NumPy minibatch -> torch tensors on `device` with ONE host->device copy for all int32 arrays.
-
-    Host-side copies that kernels' launch geometry needs (`type_ptr_host`, counts) stay as
-    Python/NumPy values so no device->host sync is ever needed to size a grid."""
-    import torch
-
+def pack_minibatch(mb: Dict[str, Any], out: Optional[np.ndarray] = None):
+    """Host half of `to_device`: every int32 array of a collated minibatch laid out in ONE int32 blob (16-byte aligned
+    pieces) + the small metadata needed to take it apart again.  -> (blob int32 [total], meta dict).  `out`: write into
+    this buffer (e.g. a shared-memory segment of a loader process) instead of allocating; it must hold `packed_size(mb)`."""
     gd = mb["graph_data"]
     arrays = []
     for k in _INT_KEYS_GD:
@@ -379,23 +376,54 @@ def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
     for k in _INT_KEYS_MB + (("gen_group_ptr", "gen_group_items") if "gen_group_ptr" in mb else ()):
         arrays.append(("mb", k, np.ascontiguousarray(mb[k], dtype=I32)))
     arrays.append(("mb", "has_bug", np.ascontiguousarray(mb["has_bug"], dtype=I32)))
-    # 16-byte align every array inside the blob
-    offs, total = [], 0
-    for _, _, a in arrays:
-        offs.append(total)
-        total += (a.size + 3) // 4 * 4
-    blob = torch.empty(max(total, 4), dtype=torch.int32)
+    layout, total = [], 0
+    for where, k, a in arrays:
+        layout.append((where, k, tuple(a.shape), total))
+        total += (a.size + 3) // 4 * 4  # 16-byte align every array inside the blob
+    total = max(total, 4)
+    blob = np.empty(total, dtype=I32) if out is None else out[:total]
+    for (_, _, a), (_, _, _, o) in zip(arrays, layout):
+        blob[o : o + a.size] = a.reshape(-1)
+    meta = {
+        "layout": layout, "total": total, "head_spans": dict(gd["head_spans"]), "num_graphs": int(gd["num_graphs"]),
+        "num_nodes": int(gd["token_ids"].shape[0]), "num_messages": int(gd["msg_src"].shape[0]),
+        "type_ptr_host": np.asarray(gd["type_ptr"], dtype=np.int64), "num_nodes_per_graph": np.asarray(gd["num_nodes_per_graph"]),
+        "num_repair_groups": int(mb["num_repair_groups"]),
+        "original_idxs": {k: mb[k] for k in ("text_rewrite_original_idxs", "candidate_rewrite_original_idxs", "pair_rewrite_original_idx")},
+    }
+    if "rewrite_logprobs" in mb:
+        meta["rewrite_logprobs"] = np.asarray(mb["rewrite_logprobs"], dtype=np.float32)
+        meta["gen_num_groups"] = int(mb["gen_num_groups"])
+    return blob, meta
+
+
+def packed_size(mb: Dict[str, Any]) -> int:
+    """Upper bound (int32 elements) of the blob `pack_minibatch` writes."""
+    gd = mb["graph_data"]
+    n = sum(int(np.size(gd[k])) + 3 for k in _INT_KEYS_GD)
+    n += sum(int(np.size(v)) + 3 for v in gd["reference_node_ids"].values()) + sum(int(np.size(v)) + 3 for v in gd["reference_node_graph_idx"].values())
+    n += sum(int(np.size(mb[k])) + 3 for k in _INT_KEYS_MB + (("gen_group_ptr", "gen_group_items") if "gen_group_ptr" in mb else ()))
+    return n + int(np.size(mb["has_bug"])) + 8
+
+
+def upload_packed(blob: np.ndarray, meta: Dict[str, Any], device) -> Dict[str, Any]:
+    """Device half of `to_device`: ONE (pinned, non-blocking) host->device copy, then views.
+
+    Host-side copies that kernels' launch geometry needs (`type_ptr_host`, counts) stay as
+    Python/NumPy values so no device->host sync is ever needed to size a grid."""
+    import torch
+
     dev = torch.device(device)
+    total = int(meta["total"])
+    staging = torch.empty(total, dtype=torch.int32)
     if dev.type == "cuda":
-        blob = blob.pin_memory()
-    bnp = blob.numpy()
-    for (_, _, a), o in zip(arrays, offs):
-        bnp[o : o + a.size] = a.reshape(-1)
-    dblob = blob.to(dev, non_blocking=True)
+        staging = staging.pin_memory()
+    staging.numpy()[:] = blob[:total]
+    dblob = staging.to(dev, non_blocking=True)
     out_gd: Dict[str, Any] = {"reference_node_ids": {}, "reference_node_graph_idx": {}}
     out: Dict[str, Any] = {"graph_data": out_gd}
-    for (where, k, a), o in zip(arrays, offs):
-        t = dblob[o : o + a.size].view(a.shape)
+    for where, k, shape, o in meta["layout"]:
+        t = dblob[o : o + int(np.prod(shape, dtype=np.int64))].view(shape)
         if where == "gd":
             out_gd[k] = t
         elif where == "ref":
@@ -405,17 +433,18 @@ def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
         else:
             out[k] = t
     out["has_bug"] = out["has_bug"].bool()
-    out_gd["head_spans"] = dict(gd["head_spans"])
-    out_gd["num_graphs"] = int(gd["num_graphs"])
-    out_gd["num_nodes"] = int(gd["token_ids"].shape[0])
-    out_gd["num_messages"] = int(gd["msg_src"].shape[0])
-    out_gd["type_ptr_host"] = np.asarray(gd["type_ptr"], dtype=np.int64)
-    out_gd["num_nodes_per_graph"] = np.asarray(gd["num_nodes_per_graph"])
+    out_gd["head_spans"] = dict(meta["head_spans"])
+    for k in ("num_graphs", "num_nodes", "num_messages", "type_ptr_host", "num_nodes_per_graph"):
+        out_gd[k] = meta[k]
     out_gd["_blob"] = dblob  # keeps the single allocation alive
-    out["num_repair_groups"] = int(mb["num_repair_groups"])
-    for k in ("text_rewrite_original_idxs", "candidate_rewrite_original_idxs", "pair_rewrite_original_idx"):
-        out[k] = mb[k]
-    if "rewrite_logprobs" in mb:
-        out["rewrite_logprobs"] = torch.from_numpy(np.asarray(mb["rewrite_logprobs"], dtype=np.float32)).to(dev)
-        out["gen_num_groups"] = int(mb["gen_num_groups"])
+    out["num_repair_groups"] = meta["num_repair_groups"]
+    out.update(meta["original_idxs"])
+    if "rewrite_logprobs" in meta:
+        out["rewrite_logprobs"] = torch.from_numpy(meta["rewrite_logprobs"]).to(dev)
+        out["gen_num_groups"] = meta["gen_num_groups"]
     return out
+
+
+def to_device(mb: Dict[str, Any], device) -> Dict[str, Any]:
+    """NumPy minibatch -> torch tensors on `device` with ONE host->device copy for all int32 arrays."""
+    return upload_packed(*pack_minibatch(mb), device)

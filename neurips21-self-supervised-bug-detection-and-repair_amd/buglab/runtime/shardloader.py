@@ -71,7 +71,7 @@ def _worker(model, files: Sequence[str], rank: int, world: int, out_q, stop) -> 
         out_q.put(_DONE)
 
 
-def _minibatch_worker(model, files: Sequence[str], rank: int, world: int, max_minibatch_size: int, out_q, stop) -> None:
+def _minibatch_worker(model, files: Sequence[str], rank: int, world: int, max_minibatch_size: int, packed: bool, out_q, stop) -> None:
     try:
         mb, n = model.initialize_minibatch(), 0
         for f in files:
@@ -87,22 +87,60 @@ def _minibatch_worker(model, files: Sequence[str], rank: int, world: int, max_mi
                     keep = model.extend_minibatch_with(t, mb)
                     n += 1
                     if not keep or n >= max_minibatch_size:
-                        out_q.put(model.collate_minibatch(mb))
+                        out_q.put(_ship(model.collate_minibatch(mb), packed))
                         mb, n = model.initialize_minibatch(), 0
             except Exception as e:
                 print(f"Error loading {f}: {e}.")
         if n > 0:
-            out_q.put(model.collate_minibatch(mb))
+            out_q.put(_ship(model.collate_minibatch(mb), packed))
     finally:
         out_q.put(_DONE)
 
 
+def _ship(mb_np, packed: bool):
+    """What a loader process puts on the queue for one minibatch.  packed: the int32 blob of `pack_minibatch` goes through a
+    POSIX shared-memory segment (written here, mapped + unlinked by the consumer) and only its name and the small metadata
+    are pickled -- a c2 minibatch is ~7.5 MB, and reading + unpickling it from the queue's pipe in the trainer process cost as
+    much as a whole device step."""
+    if not packed:
+        return mb_np
+    from multiprocessing import shared_memory
+
+    import numpy as np
+
+    from buglab.data.collate import pack_minibatch, packed_size
+
+    shm = shared_memory.SharedMemory(create=True, size=4 * packed_size(mb_np))
+    try:
+        _, meta = pack_minibatch(mb_np, out=np.ndarray((shm.size // 4,), dtype=np.int32, buffer=shm.buf))
+        return ("__packed__", shm.name, meta)
+    finally:
+        shm.close()  # the segment lives on until the consumer unlinks it
+
+
+def receive_packed(item, device):
+    """Consumer side of `_ship(..., packed=True)`: map the segment, stage + upload it, unlink it."""
+    from multiprocessing import shared_memory
+
+    import numpy as np
+
+    from buglab.data.collate import upload_packed
+
+    _, name, meta = item
+    shm = shared_memory.SharedMemory(name=name)
+    try:
+        return upload_packed(np.ndarray((int(meta["total"]),), dtype=np.int32, buffer=shm.buf), meta, device)
+    finally:
+        shm.close()
+        shm.unlink()
+
+
 def collated_minibatches_parallel(model, files: Sequence[str], num_workers: int, max_minibatch_size: int, rank: int = 0,
-                                  world: int = 1) -> Iterator:
-    """Collated (NumPy) minibatches of `files`: every worker process reads its shard files, tensorises and collates;
-    the consumer only copies a minibatch to the device (`buglab.data.collate.to_device`).  One pickle per minibatch
-    crosses the process boundary instead of one per sample."""
-    yield from _run_workers(_minibatch_worker, model, files, num_workers, (rank, world, max_minibatch_size), 8, None)
+                                  world: int = 1, packed: bool = False) -> Iterator:
+    """Collated minibatches of `files`: every worker process reads its shard files, tensorises and collates; the
+    consumer only copies a minibatch to the device.  packed = False: NumPy dicts (`buglab.data.collate.to_device` them);
+    packed = True: items for `receive_packed` (the int32 blob travels through shared memory, not the queue's pipe)."""
+    yield from _run_workers(_minibatch_worker, model, files, num_workers, (rank, world, max_minibatch_size, packed), 8, None)
 
 
 def tensorize_shards_parallel(model, files: Sequence[str], num_workers: int, rank: int = 0, world: int = 1,
@@ -113,11 +151,29 @@ def tensorize_shards_parallel(model, files: Sequence[str], num_workers: int, ran
     yield from _run_workers(_worker, model, files, num_workers, (rank, world), 512, limit_num_yielded_elements)
 
 
+def _discard(item) -> None:
+    if isinstance(item, tuple) and len(item) == 3 and item[0] == "__packed__":
+        from multiprocessing import shared_memory
+
+        try:
+            shm = shared_memory.SharedMemory(name=item[1])
+            shm.close()
+            shm.unlink()
+        except FileNotFoundError:
+            pass
+
+
 def _run_workers(target, model, files: Sequence[str], num_workers: int, extra_args, queue_size: int, limit: Optional[int]) -> Iterator:
     files = list(files)
     num_workers = max(1, min(num_workers, len(files))) if files else 0
     if num_workers == 0:
         return
+    # One resource tracker for the consumer and all workers: started BEFORE the fork so that the children inherit it.
+    # (A worker forked earlier would start its own tracker, which "cleans up" -- unlinks -- the shared-memory segments
+    # the worker created as soon as the worker exits, i.e. while its last minibatches are still waiting in the queue.)
+    from multiprocessing import resource_tracker
+
+    resource_tracker.ensure_running()
     ctx = mp.get_context("fork")  # the model (vocabulary, caches) is shared copy-on-write; nothing is pickled to start
     out_q = ctx.Queue(maxsize=queue_size)
     stop = ctx.Event()
@@ -143,12 +199,17 @@ def _run_workers(target, model, files: Sequence[str], num_workers: int, extra_ar
                 break
     finally:
         stop.set()
-        try:  # unblock workers stuck on a full queue, then reap them
+        try:  # unblock workers stuck on a full queue (dropping their shared-memory segments), then reap them
             while True:
-                out_q.get_nowait()
+                _discard(out_q.get_nowait())
         except queue_mod.Empty:
             pass
         for p in procs:
             p.join(timeout=2.0)
             if p.is_alive():
                 p.terminate()
+        try:  # whatever the workers still managed to enqueue while shutting down
+            while True:
+                _discard(out_q.get(timeout=0.05))
+        except queue_mod.Empty:
+            pass

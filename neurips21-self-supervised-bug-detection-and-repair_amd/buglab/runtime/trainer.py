@@ -132,16 +132,17 @@ class ModelTrainer:
         if workers > 0 and hasattr(data, "shard_files") and hasattr(self.model, "collate_minibatch"):
             # shard files are read, tensorised and collated by worker processes; this process copies whole
             # minibatches to the device and drives the GPU
-            from buglab.data.collate import to_device
+            from buglab.runtime.shardloader import receive_packed
 
             rank, world = self._world()
             limit = getattr(data, "limit_num_yielded_elements", None)
 
-            def received():  # runs in a prefetch thread: pipe reads / unpickling / the pinned H2D copy overlap the
-                seen = 0     # trainer thread's kernel launches
-                for mb_np in collated_minibatches_parallel(self.model, data.shard_files(), workers, self._minibatch_size, rank, world):
-                    yield to_device(mb_np, device)
-                    seen += int(mb_np["graph_data"]["num_graphs"]) * world
+            def received():  # runs in a prefetch thread: the staging copy + pinned H2D copy overlap the trainer
+                seen = 0     # thread's kernel launches; the int32 blob comes through shared memory, not the pipe
+                for item in collated_minibatches_parallel(self.model, data.shard_files(), workers, self._minibatch_size, rank, world,
+                                                          packed=True):
+                    yield receive_packed(item, device)
+                    seen += int(item[2]["num_graphs"]) * world
                     if limit is not None and seen >= limit:
                         break
 

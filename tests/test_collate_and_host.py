@@ -323,3 +323,36 @@ def test_shard_loader_collated_minibatches(tmp_path):
     assert sorted(int(n) for m in mbs for n in m["graph_data"]["num_nodes_per_graph"]) == ref_nodes
     dev = C.to_device(mbs[0], "cpu")
     assert dev["graph_data"]["msg_src"].dtype == torch.int32
+
+
+def test_shard_loader_packed_minibatches_through_shared_memory(tmp_path):
+    """packed=True: the int32 blob of every minibatch travels through a shared-memory segment; the result equals
+    to_device() of the NumPy minibatch, and segments dropped by an early stop are unlinked."""
+    import glob
+
+    from buglab.models.modelregistry import load_model
+    from buglab.runtime.shardloader import ShardDataset, collated_minibatches_parallel, receive_packed
+    from buglab.utils.msgpackutils import save_msgpack_l_gz
+
+    data = make_buglab_dataset(24, seed=10)
+    for i in range(3):
+        save_msgpack_l_gz(data[8 * i : 8 * i + 8], tmp_path / f"s{i}.msgpack.l.gz")
+    ds = ShardDataset(str(tmp_path))
+    model, _, _ = load_model({"modelName": "gnn-mlp"}, tmp_path / "m.pkl.gz")
+    for d in ds:
+        model.update_metadata_from(d)
+    model.finalize_metadata()
+    before = set(glob.glob("/dev/shm/psm_*"))
+    plain = {int(m["graph_data"]["msg_src"].sum()): C.to_device(m, "cpu") for m in collated_minibatches_parallel(model, ds.shard_files(), 1, 4)}
+    got = [receive_packed(it, "cpu") for it in collated_minibatches_parallel(model, ds.shard_files(), 1, 4, packed=True)]
+    assert len(got) == len(plain) == 6
+    for g in got:
+        ref = plain[int(g["graph_data"]["msg_src"].sum())]
+        for k in ("msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "token_ids", "node_order", "head_gather_idx"):
+            assert torch.equal(g["graph_data"][k], ref["graph_data"][k]), k
+        assert torch.equal(g["has_bug"], ref["has_bug"]) and g["num_repair_groups"] == ref["num_repair_groups"]
+        assert g["graph_data"]["head_spans"] == ref["graph_data"]["head_spans"]
+    it = collated_minibatches_parallel(model, ds.shard_files(), 2, 2, packed=True)
+    receive_packed(next(it), "cpu")
+    it.close()  # early stop: pending segments are unlinked
+    assert set(glob.glob("/dev/shm/psm_*")) <= before

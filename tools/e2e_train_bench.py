@@ -47,12 +47,11 @@ def main():
     model.finalize_metadata()
     n_graphs = per * a.shards
     if a.dry_run:
-        from buglab.data.collate import to_device
+        from buglab.runtime.shardloader import receive_packed
 
         t0, n = time.perf_counter(), 0
-        for mb in collated_minibatches_parallel(model, ds.shard_files(), a.workers, a.minibatch_size):
-            to_device(mb, "cpu")
-            n += int(mb["graph_data"]["num_graphs"])
+        for item in collated_minibatches_parallel(model, ds.shard_files(), a.workers, a.minibatch_size, packed=True):
+            n += int(receive_packed(item, "cpu")["graph_data"]["num_graphs"])
         dt = time.perf_counter() - t0
         print(f"host pipeline only: {n} graphs, {n / dt:.0f} graphs/s with {a.workers} loader processes ({os.cpu_count()} cores)")
         return
