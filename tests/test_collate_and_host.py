@@ -355,4 +355,10 @@ def test_shard_loader_packed_minibatches_through_shared_memory(tmp_path):
     it = collated_minibatches_parallel(model, ds.shard_files(), 2, 2, packed=True)
     receive_packed(next(it), "cpu")
     it.close()  # early stop: pending segments are unlinked
+    import time
+
+    for _ in range(40):  # the workers' last puts drain asynchronously
+        if set(glob.glob("/dev/shm/psm_*")) <= before:
+            break
+        time.sleep(0.05)
     assert set(glob.glob("/dev/shm/psm_*")) <= before
