@@ -24,29 +24,57 @@ LOGGER = logging.getLogger(__name__)
 
 
 def _prefetch(iterator, depth: int = 2):
-    """Runs `iterator` in a background thread, `depth` items ahead; exceptions are re-raised in the consumer."""
+    """Runs `iterator` in a background thread, `depth` items ahead; exceptions are re-raised in the consumer.
+    Closing the returned generator (or dropping it) stops the thread and closes `iterator`, so that a consumer
+    that stops early -- a rank whose peers ran out of minibatches -- does not leave loader processes behind."""
     import queue
     import threading
 
     q: "queue.Queue" = queue.Queue(maxsize=depth)
     end = object()
+    stop = threading.Event()
+
+    def put(x) -> bool:
+        while not stop.is_set():
+            try:
+                q.put(x, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def work():
         try:
             for x in iterator:
-                q.put(x)
-            q.put(end)
+                if not put(x):
+                    break
+            else:
+                put(end)
         except BaseException as e:
-            q.put(e)
+            put(e)
+        finally:
+            close = getattr(iterator, "close", None)
+            if close is not None:
+                close()
 
-    threading.Thread(target=work, daemon=True).start()
-    while True:
-        x = q.get()
-        if x is end:
-            return
-        if isinstance(x, BaseException):
-            raise x
-        yield x
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    try:
+        while True:
+            x = q.get()
+            if x is end:
+                return
+            if isinstance(x, BaseException):
+                raise x
+            yield x
+    finally:
+        stop.set()
+        try:
+            while True:
+                q.get_nowait()
+        except queue.Empty:
+            pass
+        t.join(timeout=5.0)
 
 
 class AbstractScheduler:
@@ -166,19 +194,22 @@ class ModelTrainer:
         nn.reset_metrics()
         it = iter(self._iter_minibatches(training_data, device, parallelize))
         step, num_graphs, t0 = 0, 0, time.time()
-        while True:
-            mb = next(it, None)
-            if not self._all_ranks_have(mb is not None, device):
-                break
-            optimizer.zero_grad()
-            loss = nn(**mb)
-            loss.backward()
-            B = int(mb["has_bug"].shape[0])
-            optimizer.step(D.global_batch_weight(B, device))
-            if scheduler is not None:
-                scheduler.step(epoch_idx=epoch, epoch_step=step)
-            step += 1
-            num_graphs += B
+        try:
+            while True:
+                mb = next(it, None)
+                if not self._all_ranks_have(mb is not None, device):
+                    break
+                optimizer.zero_grad()
+                loss = nn(**mb)
+                loss.backward()
+                B = int(mb["has_bug"].shape[0])
+                optimizer.step(D.global_batch_weight(B, device))
+                if scheduler is not None:
+                    scheduler.step(epoch_idx=epoch, epoch_step=step)
+                step += 1
+                num_graphs += B
+        finally:
+            it.close()  # a rank that stops before its loader is exhausted shuts the loader processes down
         metrics = nn.report_metrics()
         elapsed = time.time() - t0
         LOGGER.info("Epoch %s: %s steps, %.1f graphs/s (this rank). Train metrics: %s", epoch, step, num_graphs / max(elapsed, 1e-9), metrics)
@@ -193,12 +224,15 @@ class ModelTrainer:
         total, n = torch.zeros((), device=device), 0
         with torch.no_grad():
             it = iter(self._iter_minibatches(validation_tensors, device, parallelize))
-            while True:
-                mb = next(it, None)
-                if not self._all_ranks_have(mb is not None, device):
-                    break
-                total += nn(**mb).detach()
-                n += 1
+            try:
+                while True:
+                    mb = next(it, None)
+                    if not self._all_ranks_have(mb is not None, device):
+                        break
+                    total += nn(**mb).detach()
+                    n += 1
+            finally:
+                it.close()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             t = torch.stack([total, torch.tensor(float(n), device=device)])
             dist.all_reduce(t)

@@ -362,3 +362,101 @@ def test_shard_loader_packed_minibatches_through_shared_memory(tmp_path):
             break
         time.sleep(0.05)
     assert set(glob.glob("/dev/shm/psm_*")) <= before
+
+
+def test_prefetch_thread_stops_and_closes_its_source():
+    import threading
+    import time
+
+    from buglab.runtime.trainer import _prefetch
+
+    closed = threading.Event()
+
+    def source():
+        try:
+            i = 0
+            while True:
+                yield i
+                i += 1
+        finally:
+            closed.set()
+
+    it = _prefetch(source(), depth=2)
+    assert [next(it) for _ in range(5)] == [0, 1, 2, 3, 4]
+    it.close()  # early stop (a rank whose peers ran out of minibatches)
+    assert closed.wait(2.0)
+    assert list(_prefetch(iter(range(7)), depth=3)) == list(range(7))
+
+    def failing():
+        yield 1
+        raise ValueError("boom")
+
+    it = _prefetch(failing())
+    assert next(it) == 1
+    with pytest.raises(ValueError):
+        next(it)
+
+
+def test_trainer_epoch_loop_with_loader_processes_on_cpu(tmp_path, monkeypatch):
+    """ModelTrainer._run_training / _run_validation control flow with the multi-process loader, driven by a stand-in
+    module on CPU tensors (the real module needs the GPU): every graph is seen once, loaders are shut down."""
+    import glob
+
+    from buglab.models.modelregistry import load_model
+    from buglab.runtime.shardloader import ShardDataset
+    from buglab.runtime.trainer import ModelTrainer
+    from buglab.utils.msgpackutils import save_msgpack_l_gz
+
+    data = make_buglab_dataset(30, seed=12)
+    for i in range(3):
+        save_msgpack_l_gz(data[10 * i : 10 * i + 10], tmp_path / f"s{i}.msgpack.l.gz")
+    ds = ShardDataset(str(tmp_path), shuffle=True)
+    model, _, _ = load_model({"modelName": "gnn-mlp"}, tmp_path / "m.pkl.gz")
+    for d in ds:
+        model.update_metadata_from(d)
+    model.finalize_metadata()
+
+    class FakeModule(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(()))
+            self.graphs = 0
+
+        def forward(self, *, graph_data, has_bug, **_):
+            assert graph_data["msg_src"].dtype == torch.int32 and graph_data["num_graphs"] == has_bug.shape[0]
+            self.graphs += int(has_bug.shape[0])
+            return self.w * 0.0 + float(graph_data["num_nodes"])
+
+        def reset_metrics(self):
+            pass
+
+        def report_metrics(self):
+            return {"Loss": 0.0}
+
+    class FakeOpt:
+        def __init__(self):
+            self.steps = 0
+
+        def zero_grad(self):
+            pass
+
+        def step(self, weight=1.0):
+            self.steps += 1
+
+    monkeypatch.setenv("BUGLAB_LOADER_WORKERS", "2")
+    trainer = ModelTrainer(model, tmp_path / "m.pkl.gz", minibatch_size=4)
+    trainer.neural_module = FakeModule()
+    trainer._use_multiprocessing = True
+    before = set(glob.glob("/dev/shm/psm_*"))
+    opt = FakeOpt()
+    trainer._run_training(ds, 0, torch.device("cpu"), opt, None, True)
+    assert trainer.neural_module.graphs == 30 and opt.steps >= 8
+    trainer.neural_module.graphs = 0
+    trainer._run_validation(ds, 0, float("inf"), torch.device("cpu"), True, False)
+    assert trainer.neural_module.graphs == 30
+    assert set(glob.glob("/dev/shm/psm_*")) <= before
+    # the in-process path (loader workers off) sees the same graphs
+    monkeypatch.setenv("BUGLAB_LOADER_WORKERS", "0")
+    trainer.neural_module.graphs = 0
+    trainer._run_training(ds, 1, torch.device("cpu"), FakeOpt(), None, True)
+    assert trainer.neural_module.graphs == 30
