@@ -72,3 +72,25 @@ def test_generator_loss_matches_reference(golden_dir, loss_type):
     assert abs(float(loss.detach()) - float(z["loss_" + loss_type])) < 2e-6
     loss.backward()
     np.testing.assert_allclose(h.grad.numpy(), z["grad_node_states_" + loss_type], atol=2e-6, rtol=1e-4)
+
+
+def test_config_c1_plumbing_on_cpu_oracle():
+    """BASELINE.json configs[0]: gnn-mlp, hidden 128, 4 layers, ONE graph of ~500 nodes, CPU.  The product has no CPU path
+    (it fails loudly without the GPU), so the CPU-runnable case is the oracle's: a few clip + Adam steps on that batch
+    lower the loss, log-probabilities stay normalised."""
+    from buglab.data.collate import collate_samples
+    from buglab.data.synthetic import make_samples
+
+    cfg = O.OracleConfig(hidden=128, num_layers=4, num_edge_types=16, vocab_size=2000)
+    mb = collate_samples(make_samples(1, seed=21, num_nodes=500, num_messages=2500, num_edge_types=16, vocab_size=2000, buggy=True), 16)
+    params = O.init_params(cfg, seed=0)
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(v) for k, v in params.items()}
+    losses = []
+    for step in range(1, 5):
+        out, grads = O.forward_backward(params, mb, cfg)
+        losses.append(float(out["loss"]))
+        O.adam_clip_step(params, grads, m, v, step, lr=1e-2, warmup=0)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    lp = out["loc_logprobs"]
+    assert abs(float(torch.logsumexp(lp, 0))) < 1e-5  # one graph: candidates + NO_BUG form one distribution
