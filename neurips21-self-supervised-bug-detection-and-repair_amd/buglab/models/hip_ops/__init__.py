@@ -189,6 +189,10 @@ class KernelTimer:
         return out
 
 
+# Debug tap for the parity tests: when set to a list, every message-passing layer's forward appends its
+# winner table (int32 [N, Dm]: id of the message that won each channel's max at each node, -1 = none).
+WINNER_SINK: Optional[list] = None
+
 _overlap_depth = 0
 _free_running = False  # weight-gradient GEMMs of earlier layers may still be running on the side stream
 
@@ -603,6 +607,8 @@ class _MpLayer(torch.autograd.Function):
                           seg_order=g.node_order)
         agg, arg, ln_out, mean, rstd, dact = res[:6]
         bits = res[6] if use_bits else None
+        if WINNER_SINK is not None:
+            WINNER_SINK.append(arg.clone())
         if use_bits and WGRAD_X6:
             arg = None  # the bf16x6 backward routes with the per-message bitmask only
         del pre, res

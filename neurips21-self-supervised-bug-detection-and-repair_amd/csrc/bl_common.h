@@ -100,6 +100,11 @@ __device__ __forceinline__ uint16_t f2bf_rne(float f) {
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
   h = f2bf_rne(x);
+  if ((h & 0x7F80u) == 0x7F80u || x != x) {  // +-inf / NaN (or a value that rounds to inf): keep it in `hi` alone
+    if (x != x) h = 0x7FC0u;                   // (inf - inf would put NaN into the other planes)
+    m = l = 0;
+    return;
+  }
   const float r1 = x - bf2f(h);  // exact
   m = f2bf_rne(r1);
   const float r2 = r1 - bf2f(m);  // exact

@@ -9,6 +9,10 @@
 #include "bl_common.h"
 
 #define NEG_INF (-__builtin_huge_valf())
+// strict '>' keeps the first of equal values (torch_scatter's tie rule); a NaN message wins once and then
+// sticks (nothing compares greater than it, and the second clause needs a non-NaN incumbent), so a
+// diverged run shows up in the aggregate like it does with torch's amax instead of being dropped
+#define BL_MAX_WINS(t, best) ((t) > (best) || ((t) != (t) && (best) == (best)))
 
 // ------------------------------------------------------------------------------------------------
 // M0 embedder
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
         for (int j = 0; j < NV; ++j) {
           float t = v[u][j];
           if (act == BL_ACT_GELU) t = bl_gelu(t);
-          if (t > best[j]) { best[j] = t; barg[j] = e[u]; }
+          if (BL_MAX_WINS(t, best[j])) { best[j] = t; barg[j] = e[u]; }
         }
     }
     for (; i < cnt; ++i) {
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
         if (d < D) {
           float t = row[d];
           if (act == BL_ACT_GELU) t = bl_gelu(t);
-          if (t > best[j]) { best[j] = t; barg[j] = e; }
+          if (BL_MAX_WINS(t, best[j])) { best[j] = t; barg[j] = e; }
         }
       }
     }

@@ -122,6 +122,8 @@ class OracleConfig:
     dropout: float = 0.0
     msg_act: str = "gelu"
     buggy_samples_weight: float = 1.0
+    abstain_weight: float = 0.0  # LocalizationModule(abstain_weight=...), localizationmodule.py:15,95-100
+    use_all_gnn_layer_outputs: bool = False  # gnn.py:68-74,118-121
 
 
 # ----------------------------------------------------------------------------
@@ -156,6 +158,11 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32) -> Dict[s
         p[f"mp.{li}.Wd"] = uni((dm, dout), math.sqrt(6.0 / (dm + dout)))  # xavier uniform
         p[f"mp.{li}.bd"] = uni((dout,), 1.0 / math.sqrt(dm))
 
+    if cfg.use_all_gnn_layer_outputs:  # nn.Linear(H + sum of layer output widths -> output width), gnn.py:68-74
+        assert cfg.model != "ggnn"
+        in_f = cfg.hidden * (1 + cfg.num_layers)
+        p["summarization_W"] = uni((in_f, H), 1.0 / math.sqrt(in_f))
+        p["summarization_b"] = uni((H,), 1.0 / math.sqrt(in_f))
     b = 1.0 / math.sqrt(H)
     p["loc.Ws"] = uni((H, H), b)
     p["loc.bs"] = uni((H,), b)
@@ -237,7 +244,7 @@ def _gelu(x):
 # ----------------------------------------------------------------------------
 # M1-M3  one MlpMessagePassingLayer (spec: MpSpec)
 # ----------------------------------------------------------------------------
-def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_drop, seed, stream, trace=None):
+def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_drop, seed, stream, trace=None, force_arg=None):
     N = h.shape[0]
     src = torch.as_tensor(msg_src, dtype=torch.int64)
     tgt = torch.as_tensor(msg_tgt, dtype=torch.int64)
@@ -249,11 +256,17 @@ def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_dr
     pre = torch.cat(msgs, dim=0) if msgs else h.new_zeros((0, W.shape[2]))
     m = _gelu(pre) if msg_act == "gelu" else pre
     agg, arg = scatter_max_with_arg(m, tgt, N)
+    if force_arg is not None:
+        # routing injected by a test: take the given message per (node, channel) instead of this layer's own
+        # arg-max (value and gradient follow that message; E marks an empty segment -> 0)
+        E = m.shape[0]
+        fa = torch.as_tensor(force_arg, dtype=torch.int64)
+        agg = torch.where(fa >= E, torch.zeros_like(agg), m.gather(0, fa.clamp(max=max(E - 1, 0)))) if E else agg
     ln = torch.nn.functional.layer_norm(agg, (agg.shape[1],), ln_g, ln_b, eps=1e-5)
     out = torch.tanh(ln @ Wd + bd)
     out = apply_dropout(out, p_drop, seed, stream)
     if trace is not None:
-        trace.append({"pre": pre, "agg": agg, "arg": arg, "ln": ln, "out": out})
+        trace.append({"pre": pre, "m": m, "agg": agg, "arg": arg, "ln": ln, "out": out})
     return out
 
 
@@ -279,10 +292,13 @@ def gated_mp_layer(h, W, Wi, bi, Wh, bh, msg_src, msg_tgt, type_ptr, p_drop, see
 # ----------------------------------------------------------------------------
 # M4-M5  GNN stack (gnnlayerdefs.py:26-39; ConcatResidualLayer = [stash ; current])
 # ----------------------------------------------------------------------------
-def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None):
+def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None, force_arg=None):
+    """force_arg: optional list (one int64 [N, Dm] table per MP layer) of winners to use instead of the
+    layer's own arg-max -- the tie-aware parity tests inject the HIP path's routing (see mp_layer)."""
     h = embed_nodes(params["embed.table"], gd["token_ids"], gd["token_lens"], cfg.dropout, seed)
     if trace is not None:
         trace.append({"embed": h})
+    all_states = [h]
     stash = {}
     napplied = 0
     for op in (gnn_mlp_stack(cfg.hidden, cfg.num_layers) if cfg.model != "ggnn" else ggnn_stack(cfg.hidden)):
@@ -312,7 +328,12 @@ def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None):
                 seed,
                 stream=1 + li,
                 trace=trace,
+                force_arg=None if force_arg is None else force_arg[li],
             )
+        if op[0] in ("gg", "mp"):
+            all_states.append(h)
+    if cfg.use_all_gnn_layer_outputs:  # return_all_states=True -> summarisation Linear (gnn.py:117-121)
+        return torch.cat(all_states, dim=-1) @ params["summarization_W"] + params["summarization_b"]
     return h
 
 
@@ -334,12 +355,14 @@ def localization_logprobs(params, cand_reprs, cand_to_graph, num_graphs):
 # ----------------------------------------------------------------------------
 # H2  LocalizationModule.forward (localizationmodule.py:81-124)
 # ----------------------------------------------------------------------------
-def localization_loss(params, cand_reprs, cand_to_graph, has_bug, correct_candidate_idxs, buggy_weight=1.0):
+def localization_loss(params, cand_reprs, cand_to_graph, has_bug, correct_candidate_idxs, buggy_weight=1.0, abstain_weight=0.0):
     has_bug = torch.as_tensor(has_bug, dtype=torch.bool)
     B = has_bug.shape[0]
     all_idx, logprobs, arange = localization_logprobs(params, cand_reprs, cand_to_graph, B)
     correct = torch.where(has_bug, torch.as_tensor(correct_candidate_idxs, dtype=torch.int64), arange + cand_reprs.shape[0])
     lp = logprobs[correct].clamp(max=math.log(0.995))  # :92-93
+    if abstain_weight > 0:  # :95-100
+        lp = lp + torch.where(has_bug, abstain_weight * logprobs[arange + cand_reprs.shape[0]], torch.zeros_like(lp))
     if buggy_weight == 1.0:
         loss = -lp.mean()  # :116-117
     else:
@@ -416,10 +439,10 @@ def repair_logprobs(params, h, refs, target_rewrites, rewrite_to_group, symbol_t
 # ----------------------------------------------------------------------------
 # H8  GnnBugLabModule.forward, detector branch (gnn.py:168-187, 221-251)
 # ----------------------------------------------------------------------------
-def forward_loss(params, mb, cfg: OracleConfig, seed=None, trace=None):
+def forward_loss(params, mb, cfg: OracleConfig, seed=None, trace=None, force_arg=None):
     gd = mb["graph_data"]
     L = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
-    h = gnn_forward(params, gd, cfg, seed=seed, trace=trace)
+    h = gnn_forward(params, gd, cfg, seed=seed, trace=trace, force_arg=force_arg)
     refs = gd["reference_node_ids"]
     cand_reprs = h[L(refs["candidate_nodes"])]  # :170-172
     swap_lp, text_lp, var_lp, sel, all_logits = repair_logprobs(
@@ -438,6 +461,7 @@ def forward_loss(params, mb, cfg: OracleConfig, seed=None, trace=None):
         mb["has_bug"],
         mb["correct_candidate_node_idxs"],
         cfg.buggy_samples_weight,
+        cfg.abstain_weight,
     )
     text_loss = -text_lp[L(mb["correct_rewrite_idxs"])]  # fixermodules.py:53
     var_loss = -var_lp[L(mb["correct_candidate_symbols"])]  # :98
@@ -522,10 +546,10 @@ def generator_forward_loss(params, mb, cfg: OracleConfig, loss_type: str, node_r
                                   mb["text_rewrite_idxs"], var_lp)
 
 
-def forward_backward(params, mb, cfg: OracleConfig, seed=None):
+def forward_backward(params, mb, cfg: OracleConfig, seed=None, trace=None, force_arg=None):
     """loss + grads for every parameter (dict, same names)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    out = forward_loss(leaves, mb, cfg, seed=seed)
+    out = forward_loss(leaves, mb, cfg, seed=seed, trace=trace, force_arg=force_arg)
     out["loss"].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return out, grads

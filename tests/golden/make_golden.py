@@ -113,15 +113,20 @@ def _install_stubs():
 class TableGnn(nn.Module):
     """Stand-in for ptgnn.GraphNeuralNetwork: returns fixed node states as a Parameter."""
 
-    def __init__(self, node_states, refs, ref_graph, num_graphs):
+    def __init__(self, node_states, refs, ref_graph, num_graphs, mp_dims=()):
+        """mp_dims: output widths of pretend message-passing layers; the table is then the concatenation
+        [input states | layer outputs...] that `return_all_states=True` hands to the summarisation layer
+        (reference gnn.py:68-74,118-121)."""
         super().__init__()
         self.table = nn.Parameter(node_states.clone())
         self.refs, self.ref_graph, self.num_graphs = refs, ref_graph, num_graphs
-        self.input_node_state_dim = node_states.shape[1]
-        self.output_node_state_dim = node_states.shape[1]
-        self.message_passing_layers = []
+        H = node_states.shape[1] - sum(mp_dims)
+        self.input_node_state_dim = H
+        self.output_node_state_dim = mp_dims[-1] if mp_dims else H
+        self.message_passing_layers = [types.SimpleNamespace(output_state_dimension=d) for d in mp_dims]
 
     def forward(self, return_all_states=False, **_):
+        assert return_all_states == bool(self.message_passing_layers)
         return GNN_OUTPUT(self.table, self.table, None, self.refs, self.ref_graph, self.num_graphs)
 
 
@@ -142,11 +147,15 @@ def main():
     np.savez(os.path.join(OUT, "heads_logsoftmax.npz"), src=src.numpy(), index=idx.numpy(), out=scatter_log_softmax(src, idx).numpy())
 
     # ---- case 2..3: full detector forward of GnnBugLabModule over a table GNN ------------
-    for case, (H, B, n, C, seed, weight) in {"a": (16, 5, 30, 6, 11, 1.0), "b": (32, 3, 25, 4, 12, 0.7)}.items():
+    # case c: abstain_weight > 0 (localizationmodule.py:95-100; the reference's GnnBugLabModule never passes it, so
+    # it is set on the built LocalizationModule); case d: use_all_gnn_layer_outputs (gnn.py:68-74,118-121)
+    cases = {"a": (16, 5, 30, 6, 11, 1.0, 0.0, ()), "b": (32, 3, 25, 4, 12, 0.7, 0.0, ()),
+             "c": (16, 4, 20, 5, 13, 0.8, 0.35, ()), "d": (16, 4, 20, 5, 14, 1.0, 0.0, (16, 16, 16))}
+    for case, (H, B, n, C, seed, weight, abstain, mp_dims) in cases.items():
         g = torch.Generator().manual_seed(seed)
         rng = np.random.default_rng(seed)
         N = B * n
-        node_states = torch.randn(N, H, generator=g)
+        node_states = torch.randn(N, H + sum(mp_dims), generator=g)
         cand, cand_g, has_bug, correct_cand = [], [], [], []
         tr_nodes, tr_ids, tr_grp, correct_tr = [], [], [], []
         vm_nodes, vm_cands, vm_grp, correct_vm = [], [], [], []
@@ -194,11 +203,13 @@ def main():
         ref_graph = {"candidate_nodes": L(cand_g)}
         torch.manual_seed(seed)
         module = GnnBugLabModule(
-            TableGnn(node_states, refs, ref_graph, B),
+            TableGnn(node_states, refs, ref_graph, B, mp_dims),
             rewrite_vocabulary_size=48,
+            use_all_gnn_layer_outputs=bool(mp_dims),
             buggy_samples_weight_schedule=(lambda _e, w=weight: w),
         )
         module._argswap_module._input_dim = H  # reference defect fixermodules.py:120 (see docstring)
+        module._GnnBugLabModule__localization_module._abstain_weight = abstain
         for m in module.modules():
             if hasattr(m, "_reset_module_metrics"):
                 m._reset_module_metrics()
@@ -227,6 +238,8 @@ def main():
             "H": H,
             "B": B,
             "buggy_weight": weight,
+            "abstain_weight": abstain,
+            "mp_dims": np.asarray(mp_dims, dtype=np.int64),
             "node_states": node_states.numpy(),
             "loss": loss.detach().numpy(),
             "loc_logprobs": loc_lp.numpy(),

@@ -17,11 +17,19 @@ def test_scatter_log_softmax_matches_reference(golden_dir):
     np.testing.assert_allclose(out.numpy(), z["out"], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
 def test_heads_forward_backward_match_reference(golden_dir, case):
+    """a, b: default configuration (b with a buggy-sample weight); c: abstain_weight > 0
+    (localizationmodule.py:95-100); d: use_all_gnn_layer_outputs -- the summarisation Linear over the
+    concatenated layer states (gnn.py:68-74,118-121)."""
     z = np.load(os.path.join(golden_dir, f"heads_forward_{case}.npz"))
     params = {k: v.requires_grad_(True) for k, v in head_params_from_golden(z).items()}
-    h = torch.from_numpy(z["node_states"]).requires_grad_(True)
+    table = torch.from_numpy(z["node_states"]).requires_grad_(True)
+    h = table
+    if len(z["mp_dims"]):
+        sW = torch.from_numpy(np.ascontiguousarray(z["w__GnnBugLabModule__summarization_layer.weight"].T)).requires_grad_(True)
+        sb = torch.from_numpy(z["w__GnnBugLabModule__summarization_layer.bias"]).requires_grad_(True)
+        h = table @ sW + sb
     mb = golden_minibatch(z)
     refs = mb["graph_data"]["reference_node_ids"]
     L = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
@@ -30,7 +38,7 @@ def test_heads_forward_backward_match_reference(golden_dir, case):
         mb["candidate_symbol_to_location_group"], mb["swapped_pair_to_call_location_group"])
     loc_loss, loc_lp, stats = O.localization_loss(
         params, h[L(refs["candidate_nodes"])], mb["graph_data"]["reference_node_graph_idx"]["candidate_nodes"],
-        mb["has_bug"], mb["correct_candidate_node_idxs"], float(z["buggy_weight"]))
+        mb["has_bug"], mb["correct_candidate_node_idxs"], float(z["buggy_weight"]), float(z["abstain_weight"]))
     repair = -(text_lp[L(mb["correct_rewrite_idxs"])].sum() + var_lp[L(mb["correct_candidate_symbols"])].sum()
                + swap_lp[L(mb["correct_swapped_pair"])].sum()) * float(z["buggy_weight"])
     loss = loc_loss + repair / int(z["B"])
@@ -41,7 +49,10 @@ def test_heads_forward_backward_match_reference(golden_dir, case):
     assert abs(float(loss) - float(z["loss"])) < 2e-6
     assert abs(stats["num_correct"] / int(z["B"]) - float(z["metrics_loc_accuracy"])) < 1e-9
     loss.backward()
-    np.testing.assert_allclose(h.grad.numpy(), z["grad_node_states"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(table.grad.numpy(), z["grad_node_states"], atol=2e-6, rtol=1e-5)
+    if len(z["mp_dims"]):
+        np.testing.assert_allclose(sW.grad.numpy(), z["g__GnnBugLabModule__summarization_layer.weight"].T, atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(sb.grad.numpy(), z["g__GnnBugLabModule__summarization_layer.bias"], atol=2e-6, rtol=1e-5)
     for ours, (ref, how) in MAP.items():
         np.testing.assert_allclose(params[ours].grad.numpy(), _tx(z["g_" + ref], how), atol=2e-6, rtol=1e-5, err_msg=ours)
 
