@@ -112,6 +112,10 @@ typedef struct {
   int32_t nsrc;
 } bl_rows_packed_t;
 int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, uint16_t* out, void* stream);
+/* the same into the columns col_off .. col_off + D of a packed matrix whose rows are D_total wide: how the
+ * [stash ; current] input of a ConcatResidual layer (gnnlayerdefs.py:24-38) is packed without a concatenated copy */
+int bl_pack_bf16x3_cols(const float* x, int32_t ld, int64_t R, int32_t D, int32_t D_total, int32_t col_off, uint16_t* out,
+                        void* stream);
 /* Weights of the bf16x6 row GEMM, packed and TILED: per group ceil(N/128) * (K/32) blocks of 24 KB
  * (12288 uint16), block (tile, stage) = [i (2)][plane (3)][row_lo (64)][k-group (4)][8] for column
  * n = 128 tile + 64 i + row_lo and k = 32 stage + 8 k-group + 0..7; columns past N are zero.
@@ -187,6 +191,13 @@ int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, 
                        float* g_h, int32_t ld_gh, const int32_t* node_order,
                        void* stream);
 
+/* the same with the columns 0..split-1 written to g_h_lo and split..Din-1 to g_h_hi: the gradients of the two
+ * inputs of a folded ConcatResidual ([stash ; current]), each in its own contiguous matrix */
+int bl_mp_scatter_grad_split(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
+                             const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din, int32_t split,
+                             float* g_h_lo, int32_t ld_lo, float* g_h_hi, int32_t ld_hi, const int32_t* node_order,
+                             void* stream);
+
 /* GRU cell of the gated (`ggnn`) node update -- the elementwise part of torch.nn.GRUCell (gate order
  * r | z | n) after gi = x W_i + b_i and gh = h W_h + b_h [N, 3D] were produced by bl_gemm_rows:
  *   h' = drop((1 - z) * tanh(gi_n + r * gh_n) + z * h).  Replaces ptgnn GatedMessagePassingLayer's
@@ -196,6 +207,58 @@ int bl_gru_cell_fwd(const float* gi, const float* gh, const float* h, int32_t ld
                     bl_dropout_t drop, float* out, void* stream);
 int bl_gru_cell_bwd(const float* g_out, const float* gi, const float* gh, const float* h, int32_t ld_h, int32_t N,
                     int32_t D, bl_dropout_t drop, float* g_gi, float* g_gh, float* g_h, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ONE MlpMessagePassingLayer per call (SURVEY.md section 8b's minimum set).  Replaces ptgnn's
+ * MlpMessagePassingLayer.forward and its autograd; kwargs of the reference call site
+ * buglab/models/gnnlayerdefs.py:6-23 map to Din = input_state_dimension, Dm = message_dimension,
+ * Dout = output_state_dimension, T = num_edge_types, aggregation "max", drop.p = dropout_rate.
+ *   m_e = act_msg([h_src ; h_tgt] . W[type(e)]);  a_v = max_{e -> v} m_e (0 if none);
+ *   h'_v = Dropout(tanh(LayerNorm(a_v; ln_g, ln_b, ln_eps) . Wd + bd))
+ * Widths: Din, Dm multiples of 32 (the message GEMMs run as bf16x6), Dm <= 512.  Messages are type-major
+ * (type_ptr [T+1]) and target-sorted inside a type; tgt_ptr/tgt_msgs and src_ptr/src_msgs are the CSRs node ->
+ * incoming / outgoing message ids; node_order (optional) = processing order of the per-node kernels. */
+typedef struct {
+  int32_t N, E, T, Din, Dm, Dout;
+  const int32_t *msg_src, *msg_tgt, *type_ptr, *tgt_ptr, *tgt_msgs, *src_ptr, *src_msgs, *node_order;
+  const float* W;                 /* [T, 2 Din, Dm] */
+  const float *ln_g, *ln_b;       /* [Dm] */
+  const float* Wd;                /* [Dm, Dout] */
+  const float* bd;                /* [Dout] */
+  int32_t msg_act;                /* BL_ACT_GELU or BL_ACT_NONE */
+  float ln_eps;
+  bl_dropout_t drop;
+} bl_mp_layer_t;
+
+/* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call */
+int64_t bl_mp_layer_saved_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t msg_act);
+int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t Dout, int32_t backward);
+/* uint16 elements of the packed weights a layer call takes: bl_pack_weights_x6(W, T, 2 Din, Dm, w_is_kn = 1) for
+ * forward, bl_pack_weights_x6(W, T, Dm, 2 Din, w_is_kn = 0) for backward (pack once per optimiser step) */
+int64_t bl_mp_layer_packed_weight_elems(int32_t T, int32_t Din, int32_t Dm, int32_t for_backward);
+
+/* forward.  The layer input is h_lo [N, width_lo] alone (h_hi NULL, width_lo == Din) or the virtual concatenation
+ * [h_lo ; h_hi] of a ConcatResidual layer (gnnlayerdefs.py:24-38), never materialised.  winner_out (optional,
+ * int32 [N, Dm]): the arg-max message per (node, channel), -1 = none. */
+int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_t ld_lo, int32_t width_lo, const float* h_hi,
+                    int32_t ld_hi, const uint16_t* w_packed, float* h_out, int32_t* winner_out, void* saved, void* ws,
+                    void* stream);
+/* backward.  g_h_lo / g_h_hi are written; g_W, g_ln_g, g_ln_b, g_Wd, g_bd are ACCUMULATED into (fp32 atomics):
+ * hand in zeroed buffers or the running gradients.  side_stream (optional): the two weight-gradient GEMMs run
+ * there next to the input-gradient chain; with join_side == 0 they are left running (the caller joins the
+ * streams before it reads the weight gradients, and keeps `saved` / `ws` alive until then). */
+int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const float* g_out, const uint16_t* w_packed_bwd,
+                    const void* saved, void* ws, float* g_h_lo, int32_t ld_lo, int32_t width_lo, float* g_h_hi,
+                    int32_t ld_hi, float* g_W, float* g_ln_g, float* g_ln_b, float* g_Wd, float* g_bd, void* stream,
+                    void* side_stream, int32_t join_side);
+
+/* optional per-kernel timing of the launches made inside bl_mp_layer_fwd / _bwd (HIP events on the stream each
+ * kernel is launched on); read after a device synchronisation.  bench.py's roofline numbers come from here. */
+int bl_prof_enable(int32_t on);
+int bl_prof_reset(void);
+int bl_prof_num_kinds(void);
+const char* bl_prof_kind_name(int32_t kind);
+int bl_prof_read(int32_t kind, double* ms, double* flop, int64_t* launches, int32_t* overlapped);
 
 /* ---------------------------------------------------------------------------------------------
  * Heads.

@@ -38,6 +38,14 @@ class bl_dropout_t(Structure):
     _fields_ = [("p", c_float), ("seed", c_uint32), ("stream", c_uint32)]
 
 
+class bl_mp_layer_t(Structure):
+    _fields_ = [("N", c_int32), ("E", c_int32), ("T", c_int32), ("Din", c_int32), ("Dm", c_int32), ("Dout", c_int32),
+                ("msg_src", c_void_p), ("msg_tgt", c_void_p), ("type_ptr", c_void_p), ("tgt_ptr", c_void_p), ("tgt_msgs", c_void_p),
+                ("src_ptr", c_void_p), ("src_msgs", c_void_p), ("node_order", c_void_p),
+                ("W", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p), ("Wd", c_void_p), ("bd", c_void_p),
+                ("msg_act", c_int32), ("ln_eps", c_float), ("drop", bl_dropout_t)]
+
+
 _SIGNATURES = {
     "bl_version": ([], ctypes.c_int),
     "bl_last_error": ([], ctypes.c_char_p),
@@ -52,6 +60,19 @@ _SIGNATURES = {
     "bl_gemm_wgrad_routed_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
+    "bl_pack_bf16x3_cols": ([c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_mp_scatter_grad_split": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_mp_layer_saved_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_mp_layer_workspace_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_mp_layer_packed_weight_elems": ([c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_mp_layer_fwd": ([POINTER(bl_mp_layer_t), c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_mp_layer_bwd": ([POINTER(bl_mp_layer_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32], ctypes.c_int),
+    "bl_prof_enable": ([c_int32], ctypes.c_int),
+    "bl_prof_reset": ([], ctypes.c_int),
+    "bl_prof_num_kinds": ([], ctypes.c_int),
+    "bl_prof_kind_name": ([c_int32], ctypes.c_char_p),
+    "bl_prof_read": ([c_int32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), POINTER(c_int32)], ctypes.c_int),
     "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
@@ -170,10 +191,14 @@ class KernelTimer:
 
     def __enter__(self):
         KernelTimer.active = self
+        lib = load_library()
+        lib.bl_prof_reset()
+        lib.bl_prof_enable(1)  # kernels launched inside the fused per-layer calls are timed on the C side
         return self
 
     def __exit__(self, *exc):
         KernelTimer.active = None
+        load_library().bl_prof_enable(0)
 
     def summary(self):
         """{kind: {launches, ms, flop, overlapped}}.  `overlapped` kinds were launched while a kernel
@@ -186,6 +211,13 @@ class KernelTimer:
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flop"] += flop
+        lib = load_library()
+        for k in range(lib.bl_prof_num_kinds()):
+            ms, flop, n, ov = ctypes.c_double(), ctypes.c_double(), c_int64(), c_int32()
+            _check(lib.bl_prof_read(k, ctypes.byref(ms), ctypes.byref(flop), ctypes.byref(n), ctypes.byref(ov)), "bl_prof_read")
+            if n.value:
+                out[lib.bl_prof_kind_name(k).decode()] = {"launches": int(n.value), "ms": ms.value, "flop": flop.value,
+                                                           "overlapped": bool(ov.value)}
         return out
 
 
@@ -439,10 +471,12 @@ def scatter_add_rows(src, col_off, width, idx, out):
 _side_streams = {}
 USE_SIDE_STREAM = os.environ.get("BL_SIDE_STREAM", "1") != "0"
 # Weight gradients of the message-passing layers are accumulated (fp32 atomics in the kernel)
-# straight into `param.grad` when it already exists (FlatAdam pre-binds every .grad to a view of the
-# flat gradient buffer), on the side stream, WITHOUT joining at the end of the layer's backward:
-# the side stream runs one weight-gradient GEMM after the other behind the main chain and is
-# joined once, by `join_side_stream()`, before the gradients are consumed (FlatAdam.step / tests).
+# straight into `param.grad` for parameters whose owner OPTED IN (`param._bl_direct_grad = True`, set by
+# FlatAdam, which pre-binds every .grad to a view of its flat gradient buffer), on the side stream, WITHOUT
+# joining at the end of the layer's backward: the side stream runs one weight-gradient GEMM after the other
+# behind the main chain and is joined once, by `join_side_stream()`, before the gradients are consumed
+# (FlatAdam.zero_grad / .step).  Parameters of any other optimiser get ordinary autograd gradients, complete
+# when backward() returns (the side stream is joined inside the layer's backward).
 DIRECT_PARAM_GRAD = os.environ.get("BL_DIRECT_GRAD", "1") != "0"
 
 
@@ -460,14 +494,16 @@ def _direct_small(param):
     """.grad of a small (bias / LayerNorm) parameter when the kernels may accumulate into it directly
     (FlatAdam's flat gradient buffer): no zero-fill, no autograd accumulation kernel."""
     g = getattr(param, "grad", None)
-    if DIRECT_PARAM_GRAD and g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
+    if (DIRECT_PARAM_GRAD and getattr(param, "_bl_direct_grad", False) and g is not None and g.is_cuda and g.dtype == torch.float32
+            and g.is_contiguous()):
         return g
     return None
 
 
 def _direct_grad_target(param):
     g = getattr(param, "grad", None)
-    if DIRECT_PARAM_GRAD and USE_SIDE_STREAM and g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
+    if (DIRECT_PARAM_GRAD and USE_SIDE_STREAM and getattr(param, "_bl_direct_grad", False) and g is not None and g.is_cuda
+            and g.dtype == torch.float32 and g.is_contiguous()):
         return g
     return None
 
@@ -687,6 +723,7 @@ class _MpLayer(torch.autograd.Function):
             _free_running = True
             side2.detach(h, gq, arg, bits, hp, gqp)
             side1.detach(ln_out, g_z)
+            pair.__exit__(None, None, None)
             return g_h, None, g_lng, g_lnb, None, g_bd, None, None, None
         side2.join()
         side1.join()
@@ -696,6 +733,133 @@ class _MpLayer(torch.autograd.Function):
         if Wd_direct is not None:
             g_Wd = None
         return g_h, g_W, g_lng, g_lnb, g_Wd, g_bd, None, None, None
+
+
+
+# ------------------------------------------------------------------------------------------------
+# One C call per message-passing layer and direction (bl_mp_layer_fwd / bl_mp_layer_bwd).
+FUSED_LAYER = os.environ.get("BL_FUSED_LAYER", "1") != "0"
+_weights_epoch = 0          # bumped by whoever changes parameters behind autograd's back (FlatAdam's kernel)
+_pack_cache = {}            # id(W) -> (weakref(W), version, epoch, packed [T, *] forward form, packed backward form | None)
+
+
+def invalidate_weight_packs():
+    """Parameters were updated in place by a kernel (no `_version` bump): packed copies are stale."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _packed_layer_weights(W: torch.Tensor, need_bwd: bool):
+    """bf16x3-packed, tiled copies of a layer's per-type weights: the forward form (C = A . W[t]) and, when a
+    backward pass will follow, the form of the routed input-gradient GEMM (C = G . W[t]^T).  Packed once per
+    parameter value: eval / predict passes re-use them, a training step packs each form once."""
+    import weakref
+
+    key = id(W)
+    ent = _pack_cache.get(key)
+    if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == _weights_epoch and ent[5] == W.data_ptr():
+        if not need_bwd or ent[4] is not None:
+            return ent[3], ent[4]
+        ent = (ent[0], ent[1], ent[2], ent[3], pack_weights_x6(W.detach(), False), ent[5])
+        _pack_cache[key] = ent
+        return ent[3], ent[4]
+    if len(_pack_cache) > 256:
+        for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
+            del _pack_cache[k]
+    wd = W.detach()
+    ent = (weakref.ref(W), W._version, _weights_epoch, pack_weights_x6(wd, True), pack_weights_x6(wd, False) if need_bwd else None,
+           W.data_ptr())
+    _pack_cache[key] = ent
+    return ent[3], ent[4]
+
+
+def _layer_desc(g: "GraphIndex", W, ln_g, ln_b, Wd, bd, Din, msg_act, drop: Dropout) -> bl_mp_layer_t:
+    L = bl_mp_layer_t()
+    L.N, L.E, L.T, L.Din, L.Dm, L.Dout = g.num_nodes, g.num_messages, W.shape[0], Din, W.shape[2], Wd.shape[1]
+    L.msg_src, L.msg_tgt, L.type_ptr = g.msg_src.data_ptr(), g.msg_tgt.data_ptr(), g.type_ptr.data_ptr()
+    L.tgt_ptr, L.tgt_msgs, L.src_ptr, L.src_msgs = g.tgt_ptr.data_ptr(), g.tgt_msgs.data_ptr(), g.src_ptr.data_ptr(), g.src_msgs.data_ptr()
+    L.node_order = _p(g.node_order)
+    L.W, L.ln_g, L.ln_b, L.Wd, L.bd = W.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), Wd.data_ptr(), bd.data_ptr()
+    L.msg_act, L.ln_eps, L.drop = int(msg_act), 1e-5, drop.c()
+    return L
+
+
+class _MpLayerFused(torch.autograd.Function):
+    """One MlpMessagePassingLayer = one C call forward, one backward.  The layer input is `h_lo` alone or the
+    virtual concatenation [h_lo ; h_hi] of a ConcatResidual layer (never materialised).  What forward keeps for
+    backward is one opaque byte blob (packed input, routing bitmask, LayerNorm state; layout in csrc/bl_mp_layer.hip)."""
+
+    @staticmethod
+    def forward(ctx, h_lo, h_hi, W, ln_g, ln_b, Wd, bd, g: GraphIndex, msg_act: int, drop: Dropout):
+        _f32(h_lo, "node states")
+        lib = load_library()
+        N = h_lo.shape[0]
+        Din = h_lo.shape[1] + (h_hi.shape[1] if h_hi is not None else 0)
+        T, K2, Dm = W.shape
+        Dout = Wd.shape[1]
+        E = g.num_messages
+        assert K2 == 2 * Din and T == g.num_types and N == g.num_nodes
+        for t, nm in ((W, "W"), (ln_g, "ln_g"), (ln_b, "ln_b"), (Wd, "Wd"), (bd, "bd")):
+            _f32(t, nm)
+        need_bwd = torch.is_grad_enabled() and any(t.requires_grad for t in (h_lo, W, Wd) if t is not None)
+        wkn, wnk = _packed_layer_weights(W, need_bwd)
+        dev = h_lo.device
+        L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
+        saved = torch.empty((lib.bl_mp_layer_saved_bytes(N, E, Din, Dm, msg_act),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, 0),), dtype=torch.uint8, device=dev)
+        out = torch.empty((N, Dout), dtype=torch.float32, device=dev)
+        winner = torch.empty((N, Dm), dtype=torch.int32, device=dev) if WINNER_SINK is not None else None
+        _check(lib.bl_mp_layer_fwd(ctypes.byref(L), h_lo.data_ptr(), h_lo.stride(0), h_lo.shape[1], _p(h_hi),
+                                   h_hi.stride(0) if h_hi is not None else 0, wkn.data_ptr(), out.data_ptr(), _p(winner),
+                                   saved.data_ptr(), ws.data_ptr() if E > 0 else None, _stream()), "bl_mp_layer_fwd")
+        if winner is not None:
+            WINNER_SINK.append(winner)
+        ctx.saved = (h_lo.shape[1], h_hi.shape[1] if h_hi is not None else 0, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk = ctx.saved
+        ctx.saved = None
+        lib = load_library()
+        N, E = g.num_nodes, g.num_messages
+        T, K2, Dm = W.shape
+        Din, Dout = w_lo + w_hi, Wd.shape[1]
+        dev = out.device
+        g_out = g_out.contiguous()
+        if wnk is None:  # forward ran without grad mode knowing a backward would follow
+            wnk = _packed_layer_weights(W, True)[1]
+        direct = [_direct_small(bd), _direct_small(ln_g), _direct_small(ln_b), _direct_grad_target(Wd), _direct_grad_target(W)]
+        tgt = [d if d is not None else torch.zeros_like(p) for d, p in zip(direct, (bd, ln_g, ln_b, Wd, W))]
+        g_bd, g_lng, g_lnb, g_Wd, g_W = tgt
+        L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
+        ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, 1),), dtype=torch.uint8, device=dev)
+        g_lo = torch.empty((N, w_lo), dtype=torch.float32, device=dev)
+        g_hi = torch.empty((N, w_hi), dtype=torch.float32, device=dev) if w_hi else None
+        side = None
+        if USE_SIDE_STREAM:
+            key = torch.cuda.current_device()
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream()
+            side = _side_streams[key]
+        free_running = side is not None and direct[3] is not None and direct[4] is not None
+        _check(lib.bl_mp_layer_bwd(ctypes.byref(L), out.data_ptr(), g_out.data_ptr(), wnk.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+                                   g_lo.data_ptr(), g_lo.stride(0), w_lo, _p(g_hi), g_hi.stride(0) if g_hi is not None else 0,
+                                   g_W.data_ptr(), g_lng.data_ptr(), g_lnb.data_ptr(), g_Wd.data_ptr(), g_bd.data_ptr(), _stream(),
+                                   side.cuda_stream if side is not None else None, 0 if free_running else 1), "bl_mp_layer_bwd")
+        if free_running:
+            # the two weight-gradient GEMMs keep running behind the main chain (joined by join_side_stream()):
+            # what they read must not be recycled by the allocator before they are done
+            global _free_running
+            _free_running = True
+            for t in (saved, ws, g_W, g_Wd):
+                t.record_stream(side)
+        ret = [None if d is not None else t for d, t in zip(direct, tgt)]
+        return g_lo, g_hi, ret[4], ret[1], ret[2], ret[3], ret[0], None, None, None
+
+
+def fused_layer_ok(Din: int, Dm: int) -> bool:
+    return FUSED_LAYER and WGRAD_X6 and x6_ok(Din, Dm) and Dm <= 512
 
 
 class _GatedMpLayer(torch.autograd.Function):
@@ -759,6 +923,14 @@ def gated_mp_layer(h, W, Wi, bi, Wh, bh, graph: GraphIndex, drop: Dropout = NO_D
 
 
 def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu", drop: Dropout = NO_DROPOUT):
+    """h: the node states [N, Din], or a pair (stash, current) standing for their concatenation (ConcatResidual)."""
+    pair = isinstance(h, (tuple, list))
+    Din = sum(t.shape[1] for t in h) if pair else h.shape[1]
+    if fused_layer_ok(Din, W.shape[2]) and (not pair or h[0].shape[1] % 32 == 0):
+        lo, hi = (h[0].contiguous(), h[1].contiguous()) if pair else (h.contiguous(), None)
+        return _MpLayerFused.apply(lo, hi, W, ln_g, ln_b, Wd, bd, graph, _ACTS[msg_act], drop)
+    if pair:
+        h = torch.cat(list(h), dim=-1)
     return _MpLayer.apply(h.contiguous(), W, ln_g, ln_b, Wd, bd, graph, _ACTS[msg_act], drop)
 
 

@@ -161,10 +161,16 @@ class GraphNeuralNetwork(nn.Module):
             if isinstance(layer, _PassThrough):
                 stash[id(layer.owner)] = h
             elif isinstance(layer, ConcatResidualLayer):
-                h = torch.cat([stash.pop(id(layer)), h], dim=-1)
+                # [stash ; current] stays a PAIR: the MLP message-passing layer reads both halves in place
+                # (no concatenated copy, and backward writes the two gradients separately)
+                h = (stash.pop(id(layer)), h)
             else:
+                if isinstance(h, tuple) and not isinstance(layer, MlpMessagePassingLayer):
+                    h = torch.cat(h, dim=-1)
                 h = layer(h, graph, mk(layer.dropout_rate, 1 + li))
                 li += 1
                 all_states.append(h)
+        if isinstance(h, tuple):
+            h = torch.cat(h, dim=-1)
         out = torch.cat(all_states, dim=-1) if return_all_states else h
         return GnnOutput(h0, out, node_to_graph, reference_node_ids, reference_node_graph_idx, int(num_graphs))

@@ -32,6 +32,9 @@ class FlatAdam:
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_grad[off : off + p.numel()].view(p.shape)
+            # opt in to the kernels' direct accumulation into .grad (hip_ops._direct_*): this optimiser joins the
+            # side stream before it reads the gradients; parameters of any other optimiser keep plain autograd semantics
+            p._bl_direct_grad = True
             off += n
         self.m = torch.zeros_like(self.flat_param)
         self.v = torch.zeros_like(self.flat_param)
@@ -76,6 +79,7 @@ class FlatAdam:
             hip_ops.adam_clip_step(self.flat_param, self.flat_grad, self.m, self.v, self.sqnorm, prescale=prescale,
                                    clip=self.clip, lr=self.lr_at(self.step_count), beta1=self.beta1, beta2=self.beta2,
                                    eps=self.eps, step=self.step_count)
+            hip_ops.invalidate_weight_packs()  # the kernel wrote the parameters behind autograd's version counters
         else:
             raise hip_ops.HipOpsUnavailable("FlatAdam.step: parameters are not on a ROCm device (no CPU fallback)")
 
@@ -87,6 +91,7 @@ class FlatAdam:
         return {"m": self.m, "v": self.v, "step": self.step_count}
 
     def load_state_dict(self, sd):
+        hip_ops.invalidate_weight_packs()
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_count = int(sd["step"])

@@ -36,13 +36,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- packing ------------------------------------------------------------------------------------
 // rows: out[r][kg][plane][j] = plane(x[r, 8 kg + j])
+// (kg_total, kg_off): the packed row is kg_total k-groups wide per plane and this source fills the groups
+// kg_off .. kg_off + D/8 -- how [stash ; current] of a ConcatResidual layer is packed without a concatenated copy
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ x, int ld, long long R, int D,
-                                                        uint4* __restrict__ out) {
-  const int kgn = D >> 3;
+                                                        uint4* __restrict__ out, int kg_total, int kg_off) {
+  const int kgs = D >> 3;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= R * kgn) return;
-  const long long r = t / kgn;
-  const int kg = (int)(t % kgn);
+  if (t >= R * kgs) return;
+  const long long r = t / kgs;
+  const int kgn = kg_total;
+  const int kg = (int)(t % kgs) + kg_off;
+  x -= 8 * kg_off;  // column index below is relative to the packed row
   const float4 a = *reinterpret_cast<const float4*>(x + r * ld + 8 * kg);
   const float4 b = *reinterpret_cast<const float4*>(x + r * ld + 8 * kg + 4);
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -480,8 +484,21 @@ extern "C" int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, 
   BL_CHECK_ARG(D > 0 && D % 8 == 0 && ld % 4 == 0, "bl_pack_bf16x3: D must be a multiple of 8 (got %d)", D);
   const long long total = (long long)R * (D / 8);
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld,
-                     (long long)R, D, reinterpret_cast<uint4*>(out));
+                     (long long)R, D, reinterpret_cast<uint4*>(out), D / 8, 0);
   BL_LAUNCH_CHECK("bl_pack_bf16x3");
+  return BL_OK;
+}
+
+extern "C" int bl_pack_bf16x3_cols(const float* x, int32_t ld, int64_t R, int32_t D, int32_t D_total, int32_t col_off,
+                                   uint16_t* out, void* stream) {
+  if (R == 0) return BL_OK;
+  BL_CHECK_ARG(x && out && bl_aligned16(x) && bl_aligned16(out), "bl_pack_bf16x3_cols: null or misaligned pointer");
+  BL_CHECK_ARG(D > 0 && D % 8 == 0 && ld % 4 == 0 && D_total % 8 == 0 && col_off % 8 == 0 && col_off >= 0 && col_off + D <= D_total,
+               "bl_pack_bf16x3_cols: widths / offset must be multiples of 8 with col_off + D <= D_total");
+  const long long total = (long long)R * (D / 8);
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld,
+                     (long long)R, D, reinterpret_cast<uint4*>(out), D_total / 8, col_off / 8);
+  BL_LAUNCH_CHECK("bl_pack_bf16x3_cols");
   return BL_OK;
 }
 

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
     if (barg[j] < 0) best[j] = 0.f;  // empty segment (torch_scatter leaves 0) or padding lane
     if (d < D) {
       out[(size_t)seg * D + d] = best[j];
-      arg[(size_t)seg * D + d] = barg[j];
+      if (arg) arg[(size_t)seg * D + d] = barg[j];
       s += best[j];
       if (dact) {  // d act / d pre at the winner, so that backward never needs the [E, D] messages again
         float dv = 1.f;
@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
                                                               const int* __restrict__ tgt_ptr,
                                                               const int* __restrict__ tgt_msgs, int N, int Din,
                                                               int accumulate, float* __restrict__ g_h, int ld_gh,
-                                                              const int* __restrict__ node_order) {
+                                                              const int* __restrict__ node_order, int split,
+                                                              float* __restrict__ g_h2, int ld_gh2) {
   const int lane = threadIdx.x & 63;
   const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (slot >= N) return;
@@ -488,10 +489,14 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
       }
     }
   }
+  // columns >= split go to the second output (the two inputs of a folded ConcatResidual: [stash ; current])
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int d = lane + 64 * j;
-    if (d < Din) g_h[(size_t)n * ld_gh + d] = acc[j];
+    if (d < Din) {
+      if (d < split) g_h[(size_t)n * ld_gh + d] = acc[j];
+      else g_h2[(size_t)n * ld_gh2 + d - split] = acc[j];
+    }
   }
 }
 
@@ -604,7 +609,7 @@ extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* se
                                   const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, float* dact,
                                   uint32_t* winbits, const int32_t* seg_order, void* stream) {
   if (nseg == 0) return BL_OK;
-  BL_CHECK_ARG(seg_ptr && out && arg, "bl_segment_max_fwd: null pointer");
+  BL_CHECK_ARG(seg_ptr && out, "bl_segment_max_fwd: null pointer");  // arg (the winner table) is optional
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
   BL_CHECK_ARG(act == BL_ACT_NONE || act == BL_ACT_GELU, "bl_segment_max_fwd: act must be NONE or GELU");
   const bool has_ln = ln_g != nullptr;
@@ -678,8 +683,25 @@ extern "C" int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t
   BL_CHECK_ARG(Din > 0 && Din <= 512 && ld_ga >= (tgt_ptr ? 2 : 1) * Din, "bl_mp_scatter_grad: Din in 1..512, ld_ga >= (1 or 2)*Din");
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_a, ld_ga,
-                                       src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh, node_order))
+                                       src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh, node_order, Din,
+                                       (float*)nullptr, 0))
   BL_LAUNCH_CHECK("bl_mp_scatter_grad");
+  return BL_OK;
+}
+
+extern "C" int bl_mp_scatter_grad_split(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
+                                        const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din,
+                                        int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi, int32_t ld_hi,
+                                        const int32_t* node_order, void* stream) {
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(g_a && src_ptr && src_msgs && tgt_ptr && tgt_msgs && g_h_lo && g_h_hi, "bl_mp_scatter_grad_split: null pointer");
+  BL_CHECK_ARG(Din > 0 && Din <= 512 && ld_ga >= 2 * Din && split > 0 && split < Din && ld_lo >= split && ld_hi >= Din - split,
+               "bl_mp_scatter_grad_split: Din in 1..512, 0 < split < Din, ld_ga >= 2*Din");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_a, ld_ga,
+                                       src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, 0, g_h_lo, ld_lo, node_order, split,
+                                       g_h_hi, ld_hi))
+  BL_LAUNCH_CHECK("bl_mp_scatter_grad_split");
   return BL_OK;
 }
 

@@ -1,0 +1,313 @@
+// One MlpMessagePassingLayer per C call: bl_mp_layer_fwd / bl_mp_layer_bwd (SURVEY.md section 8b's minimum
+// set; kwargs of the reference call site buglab/models/gnnlayerdefs.py:6-23) + the optional per-kernel
+// HIP-event timing bench.py reads (bl_prof_*).
+//
+//   forward   pack h (one or two sources: a ConcatResidual input [stash ; current] is packed in place, no
+//             concatenated copy) -> bf16x6 message GEMM -> segmented max + GELU + LayerNorm (+ routing bitmask,
+//             activation derivative at the winners) -> dense + tanh + dropout
+//   backward  act/dropout backward (+ bias gradient) -> dense weight gradient (side stream) || dense input
+//             gradient -> LayerNorm backward (packed result) -> routed bf16x6 weight gradient (side stream) ||
+//             routed bf16x6 input gradient -> segmented sums over the src / tgt CSRs (two outputs for a
+//             folded concat)
+// The caller owns every buffer: `saved` lives from forward to backward, `ws` only during the call
+// (sizes from bl_mp_layer_saved_bytes / bl_mp_layer_workspace_bytes); nothing is allocated here except three
+// HIP events (once per process) used to fork / join the side stream.
+#include <vector>
+
+#include "bl_common.h"
+
+// ---- per-kernel timing ----------------------------------------------------------------------------
+namespace {
+struct ProfRec {
+  int kind;
+  double flop;
+  hipEvent_t e0, e1;
+  bool overlapped;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;
+const char* kProfNames[] = {"pack_rows",      "msg_gemm_x6",  "segment_max_ln", "dense_fwd",    "act_bwd",       "dense_wgrad",
+                            "dense_dgrad",    "layernorm_bwd", "msg_wgrad_x6",   "msg_dgrad_x6", "node_grad_sums"};
+constexpr int kProfKinds = sizeof(kProfNames) / sizeof(kProfNames[0]);
+
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {  // brackets the launches made while it is alive with two events on `st`
+  hipStream_t st;
+  bool on;
+  ProfScope(int kind, double flop, hipStream_t s, bool overlapped) : st(s), on(g_prof_on) {
+    if (!on) return;
+    ProfRec r{kind, flop, prof_event(), prof_event(), overlapped};
+    (void)hipEventRecord(r.e0, st);
+    g_prof.push_back(r);
+  }
+  ~ProfScope() {
+    if (on) (void)hipEventRecord(g_prof.back().e1, st);
+  }
+};
+}  // namespace
+
+extern "C" int bl_prof_enable(int32_t on) {
+  g_prof_on = on != 0;
+  return BL_OK;
+}
+extern "C" int bl_prof_reset(void) {
+  for (auto& r : g_prof) {
+    g_prof_pool.push_back(r.e0);
+    g_prof_pool.push_back(r.e1);
+  }
+  g_prof.clear();
+  return BL_OK;
+}
+extern "C" int bl_prof_num_kinds(void) { return kProfKinds; }
+extern "C" const char* bl_prof_kind_name(int32_t kind) { return kind >= 0 && kind < kProfKinds ? kProfNames[kind] : ""; }
+// totals of one kind since the last reset; the caller must have synchronised the device
+extern "C" int bl_prof_read(int32_t kind, double* ms, double* flop, int64_t* launches, int32_t* overlapped) {
+  double t = 0, f = 0;
+  int64_t n = 0;
+  int ov = 0;
+  for (auto& r : g_prof) {
+    if (r.kind != kind) continue;
+    float dt = 0.f;
+    hipError_t e = hipEventElapsedTime(&dt, r.e0, r.e1);
+    if (e != hipSuccess) {
+      bl_set_error("bl_prof_read: %s (synchronise the device first)", hipGetErrorString(e));
+      return (int)e;
+    }
+    t += dt;
+    f += r.flop;
+    ov |= r.overlapped ? 1 : 0;
+    ++n;
+  }
+  if (ms) *ms = t;
+  if (flop) *flop = f;
+  if (launches) *launches = n;
+  if (overlapped) *overlapped = ov;
+  return BL_OK;
+}
+
+// ---- buffer carving ---------------------------------------------------------------------------------
+namespace {
+inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+inline size_t packed_w_elems(int G, int K, int N) { return (size_t)G * ((N + 127) / 128) * (K / 32) * 12288; }
+
+struct Saved {  // forward -> backward
+  uint16_t* hp;      // [N, 3 Din]  packed layer input
+  float* dact;       // [N, Dm]     message activation derivative at each winner (GELU only)
+  uint32_t* bits;    // [E, Dm/32]  routing bitmask
+  float* agg;        // [N, Dm]
+  float* mean;       // [N]
+  float* rstd;       // [N]
+  float* ln_out;     // [N, Dm]
+  size_t bytes;
+};
+Saved carve_saved(void* base, int N, int E, int Din, int Dm, int msg_act) {
+  Saved s;
+  char* p = (char*)base;
+  size_t o = 0;
+  auto take = [&](size_t b) { char* q = p ? p + o : nullptr; o += al(b); return q; };
+  s.hp = (uint16_t*)take((size_t)N * 3 * Din * 2);
+  s.dact = (float*)(msg_act == BL_ACT_NONE ? nullptr : take((size_t)N * Dm * 4));
+  s.bits = (uint32_t*)take((size_t)E * (Dm / 32) * 4);
+  s.agg = (float*)take((size_t)N * Dm * 4);
+  s.mean = (float*)take((size_t)N * 4);
+  s.rstd = (float*)take((size_t)N * 4);
+  s.ln_out = (float*)take((size_t)N * Dm * 4);
+  s.bytes = o;
+  return s;
+}
+struct WsBwd {
+  float* g_z;      // [N, Dout]
+  float* g_ln;     // [N, Dm]
+  uint16_t* gqp;   // [N, 3 Dm]
+  float* g_a;      // [E, 2 Din]
+  size_t bytes;
+};
+WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout) {
+  WsBwd w;
+  char* p = (char*)base;
+  size_t o = 0;
+  auto take = [&](size_t b) { char* q = p ? p + o : nullptr; o += al(b); return q; };
+  w.g_z = (float*)take((size_t)N * Dout * 4);
+  w.g_ln = (float*)take((size_t)N * Dm * 4);
+  w.gqp = (uint16_t*)take((size_t)N * 3 * Dm * 2);
+  w.g_a = (float*)take((size_t)E * 2 * Din * 4);
+  w.bytes = o;
+  return w;
+}
+
+hipEvent_t g_fork1 = nullptr, g_fork2 = nullptr, g_join = nullptr;
+bool ensure_events() {
+  if (g_join) return true;
+  return hipEventCreateWithFlags(&g_fork1, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&g_fork2, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&g_join, hipEventDisableTiming) == hipSuccess;
+}
+
+int check_layer(const bl_mp_layer_t* L, const char* who) {
+  BL_CHECK_ARG(L && L->N > 0 && L->E >= 0 && L->T > 0, "%s: bad sizes", who);
+  BL_CHECK_ARG(L->Din % 32 == 0 && L->Dm % 32 == 0 && L->Dout % 4 == 0 && L->Din > 0 && L->Dm > 0 && L->Dm <= 512 && L->Dout > 0,
+               "%s: the fused layer needs Din, Dm multiples of 32 (bf16x6 GEMMs), Dm <= 512", who);
+  BL_CHECK_ARG(L->msg_src && L->msg_tgt && L->type_ptr && L->tgt_ptr && L->tgt_msgs && L->src_ptr && L->src_msgs,
+               "%s: null graph index array", who);
+  BL_CHECK_ARG(L->W && L->ln_g && L->ln_b && L->Wd && L->bd, "%s: null parameter", who);
+  BL_CHECK_ARG(L->msg_act == BL_ACT_NONE || L->msg_act == BL_ACT_GELU, "%s: message activation must be none or gelu", who);
+  return BL_OK;
+}
+}  // namespace
+
+extern "C" int64_t bl_mp_layer_saved_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t msg_act) {
+  return (int64_t)carve_saved(nullptr, N, E, Din, Dm, msg_act).bytes;
+}
+// forward scratch: the [E, Dm] pre-activations; backward scratch: g_z, g_ln, packed node gradient, [E, 2 Din] input gradients
+extern "C" int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t Dout, int32_t backward) {
+  if (backward) return (int64_t)carve_bwd(nullptr, N, E, Din, Dm, Dout).bytes;
+  return (int64_t)al((size_t)E * Dm * 4);
+}
+extern "C" int64_t bl_mp_layer_packed_weight_elems(int32_t T, int32_t Din, int32_t Dm, int32_t for_backward) {
+  return (int64_t)(for_backward ? packed_w_elems(T, Dm, 2 * Din) : packed_w_elems(T, 2 * Din, Dm));
+}
+
+#define BL_TRY(call_)        \
+  do {                       \
+    int rc_ = (call_);       \
+    if (rc_ != BL_OK) return rc_; \
+  } while (0)
+
+extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_t ld_lo, int32_t width_lo, const float* h_hi,
+                               int32_t ld_hi, const uint16_t* w_packed, float* h_out, int32_t* winner_out, void* saved,
+                               void* ws, void* stream) {
+  BL_TRY(check_layer(L, "bl_mp_layer_fwd"));
+  const int N = L->N, E = L->E, T = L->T, Din = L->Din, Dm = L->Dm, Dout = L->Dout;
+  BL_CHECK_ARG(h_lo && w_packed && h_out && saved && (ws || E == 0), "bl_mp_layer_fwd: null buffer");
+  BL_CHECK_ARG((h_hi == nullptr && width_lo == Din) || (h_hi != nullptr && width_lo > 0 && width_lo < Din && width_lo % 32 == 0),
+               "bl_mp_layer_fwd: width_lo must be Din (one source) or a multiple of 32 below Din (two sources)");
+  hipStream_t st = (hipStream_t)stream;
+  Saved S = carve_saved(saved, N, E, Din, Dm, L->msg_act);
+  float* pre = (float*)ws;
+  {
+    ProfScope ps(0, 0.0, st, false);
+    if (h_hi == nullptr) {
+      BL_TRY(bl_pack_bf16x3(h_lo, ld_lo, N, Din, S.hp, st));
+    } else {
+      BL_TRY(bl_pack_bf16x3_cols(h_lo, ld_lo, N, width_lo, Din, 0, S.hp, st));
+      BL_TRY(bl_pack_bf16x3_cols(h_hi, ld_hi, N, Din - width_lo, Din, width_lo, S.hp, st));
+    }
+  }
+  bl_rows_packed_t a;
+  a.xp[0] = S.hp; a.xp[1] = S.hp; a.xp[2] = nullptr;
+  a.idx[0] = L->msg_src; a.idx[1] = L->msg_tgt; a.idx[2] = nullptr;
+  a.width[0] = Din; a.width[1] = Din; a.width[2] = 0;
+  a.nsrc = 2;
+  const int64_t wstride = (int64_t)packed_w_elems(1, 2 * Din, Dm);
+  {
+    ProfScope ps(1, 2.0 * E * (2.0 * Din) * Dm, st, false);
+    BL_TRY(bl_gemm_rows_x6(&a, nullptr, 0, w_packed, wstride, L->type_ptr, nullptr, T, E, Dm, 2 * Din, pre, Dm, st));
+  }
+  {
+    ProfScope ps(2, 0.0, st, false);
+    // (E == 0: every segment is empty and the kernel never dereferences `pre`)
+    BL_TRY(bl_segment_max_fwd(pre, Dm, L->tgt_ptr, L->tgt_msgs, N, Dm, L->msg_act, S.agg, winner_out, L->ln_g,
+                              L->ln_b, L->ln_eps, S.ln_out, S.mean, S.rstd, S.dact, S.bits, L->node_order, st));
+  }
+  bl_rows_t d;
+  d.x[0] = S.ln_out; d.idx[0] = nullptr; d.ld[0] = Dm; d.width[0] = Dm; d.nsrc = 1;
+  d.x[1] = d.x[2] = nullptr; d.idx[1] = d.idx[2] = nullptr; d.ld[1] = d.ld[2] = 0; d.width[1] = d.width[2] = 0;
+  {
+    ProfScope ps(3, 2.0 * N * (double)Dm * Dout, st, false);
+    BL_TRY(bl_gemm_rows(&d, L->Wd, 0, Dout, 0, L->bd, nullptr, nullptr, 1, N, Dout, Dm, BL_ACT_TANH, L->drop, h_out, Dout, st));
+  }
+  return BL_OK;
+}
+
+extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const float* g_out, const uint16_t* w_packed_bwd,
+                               const void* saved, void* ws, float* g_h_lo, int32_t ld_lo, int32_t width_lo, float* g_h_hi,
+                               int32_t ld_hi, float* g_W, float* g_ln_g, float* g_ln_b, float* g_Wd, float* g_bd,
+                               void* stream, void* side_stream, int32_t join_side) {
+  BL_TRY(check_layer(L, "bl_mp_layer_bwd"));
+  const int N = L->N, E = L->E, T = L->T, Din = L->Din, Dm = L->Dm, Dout = L->Dout;
+  BL_CHECK_ARG(h_out && g_out && w_packed_bwd && saved && ws && g_h_lo && g_W && g_ln_g && g_ln_b && g_Wd && g_bd,
+               "bl_mp_layer_bwd: null buffer");
+  BL_CHECK_ARG((g_h_hi == nullptr && width_lo == Din) || (g_h_hi != nullptr && width_lo > 0 && width_lo < Din),
+               "bl_mp_layer_bwd: width_lo must be Din (one output) or below Din (two outputs)");
+  hipStream_t st = (hipStream_t)stream, side = side_stream ? (hipStream_t)side_stream : st;
+  const bool two = side != st;
+  if (two) BL_CHECK_ARG(ensure_events(), "bl_mp_layer_bwd: cannot create HIP events");
+  Saved S = carve_saved(const_cast<void*>(saved), N, E, Din, Dm, L->msg_act);
+  WsBwd B = carve_bwd(ws, N, E, Din, Dm, Dout);
+
+  {  // y = drop(tanh(z)): g_z, bias gradient
+    ProfScope ps(4, 0.0, st, false);
+    BL_TRY(bl_act_bwd(g_out, h_out, N, Dout, Dout, BL_ACT_TANH, L->drop, B.g_z, g_bd, st));
+  }
+  bl_rows_t r1;
+  r1.x[1] = r1.x[2] = nullptr; r1.idx[0] = r1.idx[1] = r1.idx[2] = nullptr; r1.ld[1] = r1.ld[2] = 0; r1.width[1] = r1.width[2] = 0; r1.nsrc = 1;
+  if (two) {
+    (void)hipEventRecord(g_fork1, st);
+    (void)hipStreamWaitEvent(side, g_fork1, 0);
+  }
+  {  // dense weight gradient, next to the input-gradient chain
+    ProfScope ps(5, 2.0 * N * (double)Dm * Dout, side, two);
+    r1.x[0] = S.ln_out; r1.ld[0] = Dm; r1.width[0] = Dm;
+    BL_TRY(bl_gemm_wgrad(&r1, B.g_z, Dout, nullptr, nullptr, 1, N, Dout, Dm, g_Wd, 0, Dout, side));
+  }
+  {
+    ProfScope ps(6, 2.0 * N * (double)Dm * Dout, st, two);
+    r1.x[0] = B.g_z; r1.ld[0] = Dout; r1.width[0] = Dout;
+    bl_dropout_t nodrop = {0.f, 0u, 0u};
+    BL_TRY(bl_gemm_rows(&r1, L->Wd, 0, Dout, 1, nullptr, nullptr, nullptr, 1, N, Dm, Dout, BL_ACT_NONE, nodrop, B.g_ln, Dm, st));
+  }
+  {  // LayerNorm backward x activation derivative at the winners -> packed d loss / d (winning pre-activation)
+    ProfScope ps(7, 0.0, st, two);
+    BL_TRY(bl_layernorm_bwd(B.g_ln, S.agg, S.mean, S.rstd, L->ln_g, N, Dm, nullptr, g_ln_g, g_ln_b, S.dact, B.gqp, st));
+  }
+  if (E > 0) {
+    bl_rows_packed_t a;
+    a.xp[0] = S.hp; a.xp[1] = S.hp; a.xp[2] = nullptr;
+    a.idx[0] = L->msg_src; a.idx[1] = L->msg_tgt; a.idx[2] = nullptr;
+    a.width[0] = Din; a.width[1] = Din; a.width[2] = 0;
+    a.nsrc = 2;
+    if (two) {
+      (void)hipEventRecord(g_fork2, st);
+      (void)hipStreamWaitEvent(side, g_fork2, 0);
+    }
+    {
+      ProfScope ps(8, 2.0 * E * (2.0 * Din) * Dm, side, two);
+      BL_TRY(bl_gemm_wgrad_routed_x6(&a, B.gqp, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, nullptr, T, E, Dm, 2 * Din, g_W,
+                                     (int64_t)2 * Din * Dm, Dm, side));
+    }
+    bl_rows_packed_t g;
+    g.xp[0] = B.gqp; g.xp[1] = g.xp[2] = nullptr; g.idx[0] = L->msg_tgt; g.idx[1] = g.idx[2] = nullptr;
+    g.width[0] = Dm; g.width[1] = g.width[2] = 0; g.nsrc = 1;
+    {
+      ProfScope ps(9, 2.0 * E * (2.0 * Din) * Dm, st, two);
+      BL_TRY(bl_gemm_rows_x6(&g, S.bits, Dm / 32, w_packed_bwd, (int64_t)packed_w_elems(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E,
+                             2 * Din, Dm, B.g_a, 2 * Din, st));
+    }
+  }
+  {
+    ProfScope ps(10, 0.0, st, two);
+    // E == 0: both CSRs are empty and g_a is never read
+    if (g_h_hi == nullptr)
+      BL_TRY(bl_mp_scatter_grad(B.g_a, 2 * Din, L->src_ptr, L->src_msgs, L->tgt_ptr, L->tgt_msgs, N, Din, 0, g_h_lo, ld_lo,
+                                L->node_order, st));
+    else
+      BL_TRY(bl_mp_scatter_grad_split(B.g_a, 2 * Din, L->src_ptr, L->src_msgs, L->tgt_ptr, L->tgt_msgs, N, Din, width_lo, g_h_lo,
+                                      ld_lo, g_h_hi, ld_hi, L->node_order, st));
+  }
+  if (two && join_side) {
+    (void)hipEventRecord(g_join, side);
+    (void)hipStreamWaitEvent(st, g_join, 0);
+  }
+  return BL_OK;
+}

@@ -37,6 +37,7 @@ def _run_hip(module, mb_np, seed=None):
     for i, p in enumerate(module.parameters()):
         if i % 2 == 0:
             p.grad = torch.zeros_like(p)
+            p._bl_direct_grad = True  # what FlatAdam sets on the parameters it owns
     loss = module(**mb, dropout_seed=seed)
     loss.backward()
     from buglab.models import hip_ops
