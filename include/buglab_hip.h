@@ -289,6 +289,34 @@ int bl_gather_rows(const float* x, int32_t ld_x, const int32_t* idx, int32_t R, 
                    int32_t ld_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Whole scoring heads per call (the kernels are the ones above; these entry points sequence them).
+ * H3/H4/H5  score[r] = w2 . relu(concat_j(x_j[idx_j[r]]) . W1 + b1) + b2 -- the MLP(k H -> H -> 1) of
+ * buglab/models/layers/mlp.py:6-20 behind TextRepairModule / SingleCandidateNodeSelectorModule /
+ * CandidatePairSelectorModule (fixermodules.py:36-39, 71-73, 116-124).  `hidden` [R, H] is kept for backward.
+ * bwd ACCUMULATES into g_W1 [K, H], g_b1, g_w2, g_b2 and into every non-NULL g_x[j] (the gradient matrix of source j,
+ * rows addressed through a->idx[j]; several sources may name the same matrix). */
+int bl_gather_concat_mlp_score_fwd(const bl_rows_t* a, const float* W1, const float* b1, const float* w2, const float* b2,
+                                   int32_t R, int32_t H, float* hidden, float* score, void* stream);
+int64_t bl_gather_concat_mlp_score_workspace_bytes(int32_t R, int32_t H, int32_t K);
+int bl_gather_concat_mlp_score_bwd(const bl_rows_t* a, const float* W1, const float* w2, const float* hidden,
+                                   const float* g_score, int32_t R, int32_t H, void* ws, float* g_W1, float* g_b1,
+                                   float* g_w2, float* g_b2, float* const* g_x, const int32_t* ld_gx, void* stream);
+/* H1  candidate localization scores (localizationmodule.py:54-60), before the NO_BUG logit and the log-softmax:
+ *   s = x[cand] . Ws + bs;  pool[g] = max over graph g's candidates (contiguous rows cand_ptr[g]..cand_ptr[g+1]);
+ *   score[c] = w . sigmoid([x[cand[c]] ; pool[cand_graph[c]]] . W1 + b1)
+ * bwd ACCUMULATES into g_x (rows addressed through cand) and the parameter gradients. */
+int64_t bl_localization_scores_saved_bytes(int32_t C, int32_t B, int32_t H);
+int64_t bl_localization_scores_workspace_bytes(int32_t C, int32_t B, int32_t H, int32_t backward);
+int bl_localization_scores_fwd(const float* x, int32_t ld_x, const int32_t* cand, const int32_t* cand_graph,
+                               const int32_t* cand_ptr, int32_t C, int32_t B, int32_t H, const float* Ws, const float* bs,
+                               const float* W1, const float* b1, const float* w, void* saved, void* ws, float* score,
+                               void* stream);
+int bl_localization_scores_bwd(const float* x, int32_t ld_x, const int32_t* cand, const int32_t* cand_graph,
+                               const int32_t* cand_ptr, int32_t C, int32_t B, int32_t H, const float* Ws, const float* W1,
+                               const float* w, const void* saved, void* ws, const float* g_score, float* g_x,
+                               int32_t ld_gx, float* g_Ws, float* g_bs, float* g_W1, float* g_b1, float* g_w, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * T1  optimiser on flat fp32 buffers: global-norm clip (buglab/models/train.py:104, clip 0.5) fused
  * with Adam (buglab/models/utils.py:51-52).  bl_sqnorm writes sum(g^2) to *out (device scalar,
  * zeroed inside); bl_adam_clip_step reads it on the device -- no host sync. */

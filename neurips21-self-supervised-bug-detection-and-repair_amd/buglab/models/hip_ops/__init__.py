@@ -68,6 +68,16 @@ _SIGNATURES = {
     "bl_mp_layer_fwd": ([POINTER(bl_mp_layer_t), c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_mp_layer_bwd": ([POINTER(bl_mp_layer_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32], ctypes.c_int),
+    "bl_gather_concat_mlp_score_fwd": ([POINTER(bl_rows_t), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gather_concat_mlp_score_workspace_bytes": ([c_int32, c_int32, c_int32], c_int64),
+    "bl_gather_concat_mlp_score_bwd": ([POINTER(bl_rows_t), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_int32), c_void_p], ctypes.c_int),
+    "bl_localization_scores_saved_bytes": ([c_int32, c_int32, c_int32], c_int64),
+    "bl_localization_scores_workspace_bytes": ([c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_localization_scores_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_localization_scores_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_prof_enable": ([c_int32], ctypes.c_int),
     "bl_prof_reset": ([], ctypes.c_int),
     "bl_prof_num_kinds": ([], ctypes.c_int),
@@ -115,7 +125,12 @@ def load_library(path: Optional[str] = None):
     return lib
 
 
+CALL_COUNT = 0  # calls into the library so far (bench.py reports calls per training step)
+
+
 def _check(rc: int, what: str):
+    global CALL_COUNT
+    CALL_COUNT += 1
     if rc != 0:
         msg = load_library().bl_last_error()
         raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
@@ -1081,6 +1096,113 @@ def segment_max_pool(x, seg_ptr, seg_of, nseg: int):
     Returns (values [nseg, D], argmax row int32 [nseg, D]; -1 for an empty segment)."""
     return _SegmentMaxPool.apply(x.contiguous(), seg_ptr, seg_of, nseg)
 
+
+
+# ------------------------------------------------------------------------------------------------
+# whole scoring heads per C call (csrc/bl_heads_fused.hip)
+def _grad_target(param):
+    """(buffer the kernels accumulate into, what backward returns for it)."""
+    d = _direct_small(param)
+    if d is not None:
+        return d, None
+    z = torch.zeros_like(param)
+    return z, z
+
+
+class _MlpScore(torch.autograd.Function):
+    """score[r] = w2 . relu(concat_j(x_j[idx_j[r]]) @ W1 + b1) + b2: forward and backward are one C call each."""
+
+    @staticmethod
+    def forward(ctx, W1, b1, w2, b2, nsrc, *flat):
+        xs, idxs = flat[:nsrc], flat[nsrc:]
+        rows, K = _rows(list(zip(xs, idxs)))
+        R = idxs[0].shape[0] if idxs[0] is not None else xs[0].shape[0]
+        H = W1.shape[1]
+        dev = W1.device
+        hidden = torch.empty((R, H), dtype=torch.float32, device=dev)
+        score = torch.empty((R,), dtype=torch.float32, device=dev)
+        _check(load_library().bl_gather_concat_mlp_score_fwd(ctypes.byref(rows), _f32(W1, "W1").data_ptr(), _f32(b1).data_ptr(),
+                                                             _f32(w2).data_ptr(), _p(b2), R, H, hidden.data_ptr(), score.data_ptr(),
+                                                             _stream()), "bl_gather_concat_mlp_score_fwd")
+        ctx.saved = (W1, b1, w2, b2, xs, idxs, hidden, K)
+        return score
+
+    @staticmethod
+    def backward(ctx, g_score):
+        W1, b1, w2, b2, xs, idxs, hidden, K = ctx.saved
+        lib = load_library()
+        R, H = hidden.shape
+        dev = W1.device
+        rows, _ = _rows(list(zip(xs, idxs)))
+        (gW1, rW1), (gb1, rb1), (gw2, rw2) = _grad_target(W1), _grad_target(b1), _grad_target(w2)
+        gb2, rb2 = _grad_target(b2) if b2 is not None else (None, None)
+        # one gradient matrix per DISTINCT source tensor (the scorers read the same node-state matrix two or three times)
+        bufs, ret = {}, []
+        gx = (c_void_p * 3)()
+        ld = (c_int32 * 3)()
+        for j, x in enumerate(xs):
+            if not ctx.needs_input_grad[5 + j]:
+                ret.append(None)
+                continue
+            key = x.data_ptr()
+            if key not in bufs:
+                bufs[key] = torch.zeros_like(x)
+                ret.append(bufs[key])
+            else:
+                ret.append(None)
+            gx[j], ld[j] = bufs[key].data_ptr(), bufs[key].stride(0)
+        ws = torch.empty((lib.bl_gather_concat_mlp_score_workspace_bytes(R, H, K),), dtype=torch.uint8, device=dev)
+        _check(lib.bl_gather_concat_mlp_score_bwd(ctypes.byref(rows), W1.data_ptr(), w2.data_ptr(), hidden.data_ptr(),
+                                                  _f32(g_score.contiguous()).data_ptr(), R, H, ws.data_ptr(), gW1.data_ptr(), gb1.data_ptr(),
+                                                  gw2.data_ptr(), _p(gb2), gx, ld, _stream()), "bl_gather_concat_mlp_score_bwd")
+        return (rW1, rb1, rw2, rb2, None) + tuple(ret) + (None,) * len(xs)
+
+
+def mlp_score(sources: Sequence[RowSource], W1, b1, w2, b2):
+    xs = [x for x, _ in sources]
+    idxs = [i for _, i in sources]
+    return _MlpScore.apply(W1, b1, w2, b2, len(sources), *xs, *idxs)
+
+
+class _LocalizationScores(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cand, cand_graph, cand_ptr, B, Ws, bs, W1, b1, w):
+        lib = load_library()
+        _f32(x, "node states")
+        C, H = cand.shape[0], x.shape[1]
+        dev = x.device
+        saved = torch.empty((lib.bl_localization_scores_saved_bytes(C, B, H),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((lib.bl_localization_scores_workspace_bytes(C, B, H, 0),), dtype=torch.uint8, device=dev)
+        score = torch.empty((C,), dtype=torch.float32, device=dev)
+        _check(lib.bl_localization_scores_fwd(x.data_ptr(), x.stride(0), _i32(cand).data_ptr(), _i32(cand_graph).data_ptr(),
+                                              _i32(cand_ptr).data_ptr(), C, B, H, _f32(Ws).data_ptr(), _f32(bs).data_ptr(),
+                                              _f32(W1).data_ptr(), _f32(b1).data_ptr(), _f32(w).data_ptr(), saved.data_ptr(),
+                                              ws.data_ptr(), score.data_ptr(), _stream()), "bl_localization_scores_fwd")
+        ctx.saved = (x, cand, cand_graph, cand_ptr, B, Ws, bs, W1, b1, w, saved)
+        return score
+
+    @staticmethod
+    def backward(ctx, g_score):
+        x, cand, cand_graph, cand_ptr, B, Ws, bs, W1, b1, w, saved = ctx.saved
+        lib = load_library()
+        C, H = cand.shape[0], x.shape[1]
+        dev = x.device
+        g_x = torch.zeros_like(x)
+        (gWs, rWs), (gbs, rbs), (gW1, rW1), (gb1, rb1), (gw, rw) = (_grad_target(t) for t in (Ws, bs, W1, b1, w))
+        ws = torch.empty((lib.bl_localization_scores_workspace_bytes(C, B, H, 1),), dtype=torch.uint8, device=dev)
+        _check(lib.bl_localization_scores_bwd(x.data_ptr(), x.stride(0), cand.data_ptr(), cand_graph.data_ptr(), cand_ptr.data_ptr(), C, B, H,
+                                              Ws.data_ptr(), W1.data_ptr(), w.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+                                              _f32(g_score.contiguous()).data_ptr(), g_x.data_ptr(), g_x.stride(0), gWs.data_ptr(),
+                                              gbs.data_ptr(), gW1.data_ptr(), gb1.data_ptr(), gw.data_ptr(), _stream()),
+               "bl_localization_scores_bwd")
+        return g_x, None, None, None, None, rWs, rbs, rW1, rb1, rw
+
+
+def localization_scores(x, cand, cand_graph, cand_ptr, num_graphs: int, Ws, bs, W1, b1, w):
+    """Candidate scores of the localization head before the NO_BUG logit (reference localizationmodule.py:54-60)."""
+    if cand.shape[0] == 0:
+        return torch.zeros((0,), dtype=torch.float32, device=x.device)
+    return _LocalizationScores.apply(x.contiguous(), cand, cand_graph, cand_ptr, int(num_graphs), Ws, bs, W1, b1, w)
 
 # ------------------------------------------------------------------------------------------------
 # optimiser on flat buffers

@@ -58,10 +58,9 @@ class LocalizationModule(ModuleWithMetrics):
         -> (ids [C+B] int32, logprobs [C+B], arange [B])"""
         dev = node_reprs.device
         C = candidate_nodes.shape[0]
-        summary = hip_ops.gather_linear([(node_reprs, candidate_nodes)], self.Ws, self.bs, "none")  # [C, H]
-        pooled, _ = hip_ops.segment_max_pool(summary, candidate_ptr, candidate_to_sample_idx, num_samples)  # :56-58
-        l1 = hip_ops.gather_linear([(node_reprs, candidate_nodes), (pooled, candidate_to_sample_idx)], self.W1, self.b1, "sigmoid")
-        scores = hip_ops.rowdot(l1, self.w)  # :60
+        # :56-60 in one call: summary GEMM -> per-graph max pool -> [candidate ; pooled] GEMM + sigmoid -> score
+        scores = hip_ops.localization_scores(node_reprs, candidate_nodes, candidate_to_sample_idx, candidate_ptr, num_samples,
+                                             self.Ws, self.bs, self.W1, self.b1, self.w)
         arange = torch.arange(num_samples, dtype=torch.int32, device=dev)
         scores_with_no_bug = torch.cat((scores, torch.ones(num_samples, dtype=torch.float32, device=dev)))  # :63-68
         ids = torch.cat((candidate_to_sample_idx, arange))
