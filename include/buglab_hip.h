@@ -317,6 +317,38 @@ int bl_localization_scores_bwd(const float* x, int32_t ld_x, const int32_t* cand
                                int32_t ld_gx, float* g_Ws, float* g_bs, float* g_W1, float* g_b1, float* g_w, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * `seq-great` / `seq-rat` relational-transformer block (reference buglab/models/layers/relational_transformer.py,
+ * relational_multihead_attention.py, multihead_attention.py): the row-wise kernels around the MFMA GEMMs.
+ * q (pre-scaled by dk^-0.5), k, v, the attention context and their gradients are [B, H, L, dk] (one [L, dk] matrix per
+ * (sample, head) = one GEMM group); scores / probabilities are [B * H * L, L].  The minibatch's edges come as a CSR over
+ * query rows (b * L + i): ekey = key position, ecode = 2 * edge_type + direction (0: the query is the edge's source). */
+/* y = LayerNorm(x + r) (r may be NULL); z_out (optional) receives x + r; the backward is bl_layernorm_bwd.
+ * nn.LayerNorm of relational_transformer.py:84-85 + the residual adds of :113,122 */
+int bl_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta, float eps, int32_t nrows,
+                         int32_t D, float* z_out, float* y, float* mean, float* rstd, void* stream);
+/* S[(b, h, i), key] += edge term, relational_multihead_attention.py:90-152 (index_put_ with accumulate=True):
+ * mode 0: <bias[code][h, :], q[b, h, i, :]> (what seq-great runs, :135-152); mode 1: bias[code][h] * sum_d k[b, h, key, d] */
+int bl_rel_attn_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
+                         int32_t dk, int32_t mode, const float* qk, const float* bias_f, const float* bias_r, float* S,
+                         void* stream);
+/* gradients of the edge terms from dS: g_q += (mode 0, row-owned), g_k += (mode 1, atomics), g_bias_* += (atomics) */
+int bl_rel_attn_bias_bwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
+                         int32_t dk, int32_t mode, int32_t T, const float* qk, const float* bias_f, const float* bias_r,
+                         const float* dS, float* g_q, float* g_k, float* g_bias_f, float* g_bias_r, void* stream);
+/* softmax over keys with the padding keys (key >= lens[row / rows_per_sample]) masked, in place (multihead_attention.py:65-71) */
+int bl_masked_softmax_fwd(float* S, int32_t R, int32_t L, int32_t rows_per_sample, const int32_t* lens, void* stream);
+/* dP <- P * (dP - sum_k P dP) */
+int bl_softmax_bwd(const float* P, float* dP, int32_t R, int32_t L, void* stream);
+/* `rat` edge value biases (relational_multihead_attention.py:155-178): ctx[b, h, i, :] += P[(b, h, i), key] * vb[code][h, :] */
+int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
+                          int32_t dk, const float* P, const float* vb_f, const float* vb_r, float* ctx, void* stream);
+int bl_rel_value_bias_bwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
+                          int32_t dk, int32_t T, const float* P, const float* g_ctx, const float* vb_f, const float* vb_r,
+                          float* dP, float* g_vb_f, float* g_vb_r, void* stream);
+/* in-place counter-hash dropout (forward and backward are the same call) */
+int bl_dropout_inplace(float* x, int64_t n, bl_dropout_t drop, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * T1  optimiser on flat fp32 buffers: global-norm clip (buglab/models/train.py:104, clip 0.5) fused
  * with Adam (buglab/models/utils.py:51-52).  bl_sqnorm writes sum(g^2) to *out (device scalar,
  * zeroed inside); bl_adam_clip_step reads it on the device -- no host sync. */

@@ -78,6 +78,16 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_localization_scores_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_add_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_rel_attn_bias_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_rel_attn_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_masked_softmax_fwd": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_void_p], ctypes.c_int),
+    "bl_rel_value_bias_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_rel_value_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_dropout_inplace": ([c_void_p, c_int64, bl_dropout_t, c_void_p], ctypes.c_int),
     "bl_prof_enable": ([c_int32], ctypes.c_int),
     "bl_prof_reset": ([], ctypes.c_int),
     "bl_prof_num_kinds": ([], ctypes.c_int),
@@ -979,21 +989,24 @@ class _GatherLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, W, bias, act, nsrc, *flat):
+        drop = NO_DROPOUT
+        if len(flat) == 2 * nsrc + 1:  # optional trailing Dropout: y = drop(act(x W + b))
+            drop, flat = flat[-1], flat[:-1]
         xs, idxs = flat[:nsrc], flat[nsrc:]
         sources = list(zip(xs, idxs))
         R = idxs[0].shape[0] if idxs[0] is not None else xs[0].shape[0]
-        out = gemm_rows(sources, _f32(W, "W"), R, W.shape[1], bias=bias, act=act)
-        ctx.saved = (W, bias is not None, act, sources, out)
+        out = gemm_rows(sources, _f32(W, "W"), R, W.shape[1], bias=bias, act=act, drop=drop)
+        ctx.saved = (W, bias is not None, act, sources, out, drop)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        W, has_bias, act, sources, out = ctx.saved
+        W, has_bias, act, sources, out, drop = ctx.saved
         R, N = out.shape
         K = W.shape[0]
         dev = W.device
         g_bias = torch.zeros((N,), dtype=torch.float32, device=dev) if has_bias else None
-        g_z = act_bwd(g_out.contiguous(), out, act, NO_DROPOUT, g_bias)
+        g_z = act_bwd(g_out.contiguous(), out, act, drop, g_bias)
         g_W = torch.zeros_like(W)
         gemm_wgrad(sources, g_z, R, N, g_W)
         g_a = gemm_rows([(g_z, None)], W, R, K, b_is_nk=True, ldb=N)
@@ -1009,13 +1022,14 @@ class _GatherLinear(torch.autograd.Function):
                 scatter_add_rows(g_a, off, w, idx, g_x)
                 g_xs.append(g_x)
             off += w
-        return (g_W, g_bias, None, None) + tuple(g_xs) + (None,) * len(sources)
+        return (g_W, g_bias, None, None) + tuple(g_xs) + (None,) * (len(sources) + (1 if drop is not NO_DROPOUT else 0))
 
 
-def gather_linear(sources: Sequence[RowSource], W, bias, act: str = "none"):
+def gather_linear(sources: Sequence[RowSource], W, bias, act: str = "none", drop: Dropout = NO_DROPOUT):
     xs = [x for x, _ in sources]
     idxs = [i for _, i in sources]
-    return _GatherLinear.apply(W, bias, _ACTS[act], len(sources), *xs, *idxs)
+    extra = (drop,) if drop is not NO_DROPOUT else ()
+    return _GatherLinear.apply(W, bias, _ACTS[act], len(sources), *xs, *idxs, *extra)
 
 
 class _RowDot(torch.autograd.Function):
@@ -1203,6 +1217,164 @@ def localization_scores(x, cand, cand_graph, cand_ptr, num_graphs: int, Ws, bs, 
     if cand.shape[0] == 0:
         return torch.zeros((0,), dtype=torch.float32, device=x.device)
     return _LocalizationScores.apply(x.contiguous(), cand, cand_graph, cand_ptr, int(num_graphs), Ws, bs, W1, b1, w)
+
+
+# ------------------------------------------------------------------------------------------------
+# `seq-great` relational transformer block (csrc/bl_seq_ops.hip + the MFMA GEMMs)
+class _AddLayerNorm(torch.autograd.Function):
+    """y = LayerNorm(x + r) (r optional); backward hands the same gradient to x and r."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps):
+        _f32(x, "x")
+        n, D = x.shape
+        dev = x.device
+        z = torch.empty_like(x) if r is not None else x
+        y = torch.empty_like(x)
+        mean = torch.empty((n,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((n,), dtype=torch.float32, device=dev)
+        _check(load_library().bl_add_layernorm_fwd(x.data_ptr(), _p(r), _f32(gamma).data_ptr(), _f32(beta).data_ptr(), float(eps), n, D,
+                                                   z.data_ptr() if r is not None else None, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   _stream()), "bl_add_layernorm_fwd")
+        ctx.saved = (z, mean, rstd, gamma, beta, r is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        z, mean, rstd, gamma, beta, has_r = ctx.saved
+        (gg, rg), (gb, rb) = _grad_target(gamma), _grad_target(beta)
+        g_z = layernorm_bwd(g_y.contiguous(), z, mean, rstd, gamma, gg, gb)
+        return g_z, (g_z if has_r else None), rg, rb, None
+
+
+def add_layernorm(x, r, gamma, beta, eps: float = 1e-5):
+    return _AddLayerNorm.apply(x.contiguous(), r.contiguous() if r is not None else None, gamma, beta, eps)
+
+
+class RelEdges(NamedTuple):
+    """Edges of a padded [B, L] minibatch as a CSR over query rows b * L + i (buglab.data.seqcollate.edge_csr)."""
+
+    row_ptr: torch.Tensor   # int32 [B * L + 1]
+    key: torch.Tensor       # int32 [n]  key position of the entry
+    code: torch.Tensor      # int32 [n]  2 * edge_type + direction (0: the query is the edge's source, 1: its target)
+    num_entries: int
+
+
+_group_ptr_cache = {}
+
+
+def _uniform_group_ptr(G: int, L: int, device):
+    key = (G, L, str(device))
+    t = _group_ptr_cache.get(key)
+    if t is None:
+        if len(_group_ptr_cache) > 64:
+            _group_ptr_cache.clear()
+        t = (torch.arange(G + 1, dtype=torch.int64) * L).to(torch.int32).to(device)
+        _group_ptr_cache[key] = t
+    return t
+
+
+class _RelAttention(torch.autograd.Function):
+    """Relational multi-head self-attention between the QKV projection and the output projection
+    (reference multihead_attention.py:46-80, relational_multihead_attention.py:72-178).  Q.K^T, P.V and their four
+    gradient products are MFMA GEMMs grouped by (sample, head); edge terms, masked softmax and value biases are the
+    row-wise kernels of csrc/bl_seq_ops.hip."""
+
+    @staticmethod
+    def forward(ctx, qkv, lens, edges: RelEdges, bias_f, bias_r, vb_f, vb_r, B, L, H, dk, T, scalar_bias, drop: Dropout):
+        lib = load_library()
+        _f32(qkv, "qkv")
+        G, D = B * H, H * dk
+        st = _stream()
+        scale = float(dk) ** -0.5
+        t3 = qkv.view(B, L, H, 3, dk).permute(3, 0, 2, 1, 4).contiguous()  # [3, B, H, L, dk]
+        qs, kt, vt = t3[0], t3[1], t3[2]
+        qs.mul_(scale)  # multihead_attention.py:54: queries pre-scaled
+        gptr = _uniform_group_ptr(G, L, qkv.device)
+        S = gemm_rows([(qs.view(G * L, dk), None)], kt, G * L, L, b_is_nk=True, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
+        mode = 1 if scalar_bias else 0
+        if edges.num_entries > 0:
+            _check(lib.bl_rel_attn_bias_fwd(edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr(), B, L, H, dk, mode,
+                                            (kt if scalar_bias else qs).data_ptr(), _f32(bias_f).data_ptr(), _f32(bias_r).data_ptr(),
+                                            S.data_ptr(), st), "bl_rel_attn_bias_fwd")
+        _check(lib.bl_masked_softmax_fwd(S.data_ptr(), G * L, L, H * L, _i32(lens).data_ptr(), st), "bl_masked_softmax_fwd")
+        P = S
+        Pd = P
+        if drop.p > 0:  # nn.Dropout on the probabilities (multihead_attention.py:72)
+            Pd = P.clone()
+            _check(lib.bl_dropout_inplace(Pd.data_ptr(), Pd.numel(), drop.c(), st), "bl_dropout_inplace")
+        ctx_t = gemm_rows([(Pd, None)], vt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
+        if vb_f is not None and edges.num_entries > 0:
+            _check(lib.bl_rel_value_bias_fwd(edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr(), B, L, H, dk,
+                                             Pd.data_ptr(), _f32(vb_f).data_ptr(), _f32(vb_r).data_ptr(), ctx_t.data_ptr(), st),
+                   "bl_rel_value_bias_fwd")
+        out = ctx_t.view(B, H, L, dk).permute(0, 2, 1, 3).contiguous().view(B * L, D)
+        ctx.saved = (qs, kt, vt, P, Pd, lens, edges, bias_f, bias_r, vb_f, vb_r, B, L, H, dk, T, mode, drop, gptr, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        qs, kt, vt, P, Pd, lens, edges, bias_f, bias_r, vb_f, vb_r, B, L, H, dk, T, mode, drop, gptr, scale = ctx.saved
+        ctx.saved = None
+        lib = load_library()
+        G, D = B * H, H * dk
+        dev = g_out.device
+        st = _stream()
+        g_ct = g_out.view(B, L, H, dk).permute(0, 2, 1, 3).contiguous().view(G * L, dk)
+        dP = gemm_rows([(g_ct, None)], vt, G * L, L, b_is_nk=True, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
+        g3 = torch.zeros((3, B, H, L, dk), dtype=torch.float32, device=dev)
+        g_qs, g_k, g_v = g3[0], g3[1], g3[2]
+        gemm_wgrad([(Pd, None)], g_ct, G * L, dk, g_v.view(G, L, dk), gw_group_stride=L * dk, group_ptr=gptr, G=G)
+        has_e = edges.num_entries > 0
+        ep = (edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr()) if has_e else None
+        r_vbf = r_vbr = None
+        if vb_f is not None:
+            (g_vbf, r_vbf), (g_vbr, r_vbr) = _grad_target(vb_f), _grad_target(vb_r)
+            if has_e:
+                _check(lib.bl_rel_value_bias_bwd(*ep, B, L, H, dk, T, Pd.data_ptr(), g_ct.data_ptr(), vb_f.data_ptr(), vb_r.data_ptr(),
+                                                 dP.data_ptr(), g_vbf.data_ptr(), g_vbr.data_ptr(), st), "bl_rel_value_bias_bwd")
+        if drop.p > 0:
+            _check(lib.bl_dropout_inplace(dP.data_ptr(), dP.numel(), drop.c(), st), "bl_dropout_inplace")
+        _check(lib.bl_softmax_bwd(P.data_ptr(), dP.data_ptr(), G * L, L, st), "bl_softmax_bwd")
+        dS = dP
+        gemm_rows([(dS, None)], kt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G, out=g_qs.view(G * L, dk))
+        gemm_wgrad([(dS, None)], qs.view(G * L, dk), G * L, dk, g_k.view(G, L, dk), gw_group_stride=L * dk, group_ptr=gptr, G=G)
+        (g_bf, r_bf), (g_br, r_br) = _grad_target(bias_f), _grad_target(bias_r)
+        if has_e:
+            _check(lib.bl_rel_attn_bias_bwd(*ep, B, L, H, dk, mode, T, (kt if mode == 1 else qs).data_ptr(), bias_f.data_ptr(),
+                                            bias_r.data_ptr(), dS.data_ptr(), g_qs.data_ptr(), g_k.data_ptr(), g_bf.data_ptr(),
+                                            g_br.data_ptr(), st), "bl_rel_attn_bias_bwd")
+        g_qs.mul_(scale)
+        g_qkv = g3.permute(1, 3, 2, 0, 4).contiguous().view(B * L, 3 * D)
+        return g_qkv, None, None, r_bf, r_br, r_vbf, r_vbr, None, None, None, None, None, None, None
+
+
+def rel_attention(qkv, lens, edges: RelEdges, bias_f, bias_r, vb_f, vb_r, B, L, H, dk, T, scalar_bias=False, drop: Dropout = NO_DROPOUT):
+    """qkv [B*L, H*3*dk] (per head [q | k | v]) -> attention context [B*L, H*dk]."""
+    return _RelAttention.apply(qkv.contiguous(), lens, edges, bias_f, bias_r, vb_f, vb_r, int(B), int(L), int(H), int(dk), int(T),
+                               bool(scalar_bias), drop)
+
+
+def dropout_rows(x, drop: Dropout):
+    """Elementwise counter-hash dropout with autograd (embedding dropout of the sequence models)."""
+    if drop.p <= 0:
+        return x
+    return _DropoutFn.apply(x, drop)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop):
+        y = x.contiguous().clone()
+        _check(load_library().bl_dropout_inplace(_f32(y).data_ptr(), y.numel(), drop.c(), _stream()), "bl_dropout_inplace")
+        ctx.drop = drop
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        _check(load_library().bl_dropout_inplace(g.data_ptr(), g.numel(), ctx.drop.c(), _stream()), "bl_dropout_inplace")
+        return g, None
 
 # ------------------------------------------------------------------------------------------------
 # optimiser on flat buffers
