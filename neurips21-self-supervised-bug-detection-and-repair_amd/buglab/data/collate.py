@@ -361,13 +361,17 @@ _INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "
                 "head_gather_idx", "head_local_idx", "node_order", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
 
 
+# present only in minibatches of the sequence models (buglab.models.seqmodel.collate_sequences)
+_INT_KEYS_GD_SEQ = ("seq_lens", "erow_ptr", "ekey", "ecode")
+
+
 def pack_minibatch(mb: Dict[str, Any], out: Optional[np.ndarray] = None):
     """Host half of `to_device`: every int32 array of a collated minibatch laid out in ONE int32 blob (16-byte aligned
     pieces) + the small metadata needed to take it apart again.  -> (blob int32 [total], meta dict).  `out`: write into
     this buffer (e.g. a shared-memory segment of a loader process) instead of allocating; it must hold `packed_size(mb)`."""
     gd = mb["graph_data"]
     arrays = []
-    for k in _INT_KEYS_GD:
+    for k in _INT_KEYS_GD + tuple(k for k in _INT_KEYS_GD_SEQ if k in gd):
         arrays.append(("gd", k, np.ascontiguousarray(gd[k], dtype=I32)))
     for k, v in gd["reference_node_ids"].items():
         arrays.append(("ref", k, np.ascontiguousarray(v, dtype=I32)))
@@ -394,13 +398,16 @@ def pack_minibatch(mb: Dict[str, Any], out: Optional[np.ndarray] = None):
     if "rewrite_logprobs" in mb:
         meta["rewrite_logprobs"] = np.asarray(mb["rewrite_logprobs"], dtype=np.float32)
         meta["gen_num_groups"] = int(mb["gen_num_groups"])
+    if "seq_len" in gd:
+        meta["seq"] = {"seq_batch": int(gd["seq_batch"]), "seq_len": int(gd["seq_len"])}
+        meta["node_mappings"] = mb.get("node_mappings")
     return blob, meta
 
 
 def packed_size(mb: Dict[str, Any]) -> int:
     """Upper bound (int32 elements) of the blob `pack_minibatch` writes."""
     gd = mb["graph_data"]
-    n = sum(int(np.size(gd[k])) + 3 for k in _INT_KEYS_GD)
+    n = sum(int(np.size(gd[k])) + 3 for k in _INT_KEYS_GD + tuple(k for k in _INT_KEYS_GD_SEQ if k in gd))
     n += sum(int(np.size(v)) + 3 for v in gd["reference_node_ids"].values()) + sum(int(np.size(v)) + 3 for v in gd["reference_node_graph_idx"].values())
     n += sum(int(np.size(mb[k])) + 3 for k in _INT_KEYS_MB + (("gen_group_ptr", "gen_group_items") if "gen_group_ptr" in mb else ()))
     return n + int(np.size(mb["has_bug"])) + 8
@@ -442,6 +449,9 @@ def upload_packed(blob: np.ndarray, meta: Dict[str, Any], device) -> Dict[str, A
     if "rewrite_logprobs" in meta:
         out["rewrite_logprobs"] = torch.from_numpy(meta["rewrite_logprobs"]).to(dev)
         out["gen_num_groups"] = meta["gen_num_groups"]
+    if "seq" in meta:
+        out_gd.update(meta["seq"])
+        out["node_mappings"] = meta["node_mappings"]
     return out
 
 

@@ -232,3 +232,136 @@ def make_buglab_dataset(n: int, seed: int = 0):
     rng = np.random.default_rng(seed)
     return [make_buglab_datapoint(rng, num_syntax_nodes=int(rng.integers(20, 60)), num_tokens=int(rng.integers(15, 40)),
                                   buggy=(i % 2 == 0)) for i in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------
+# Synthetic raw datapoints with an AST-shaped Child tree over a NextToken chain: what the sequence models'
+# graph -> token projection (buglab.representations.tokenseq, reference seqmodel.py:441-589) walks --
+# Assign / BinaryOperation / ComparisonTarget (incl. the two-token IsNot) / Call nodes, symbols with
+# OccurrenceOf edges, data-flow style edges between tokens and syntax nodes, rewrites of all scout families.
+def make_buglab_seq_datapoint(rng: np.random.Generator, num_statements: int = 6, buggy: bool = True, package: str = "synthetic"):
+    nodes: List[str] = ["Module"]
+    child: List[list] = []
+    tokens: List[int] = []
+    names: List[int] = []            # Name tokens
+    symbols = [_identifier(rng) for _ in range(4)]
+
+    def add(label, parent=None, edge_label=None):
+        nodes.append(label)
+        i = len(nodes) - 1
+        if parent is not None:
+            child.append([parent, i] if edge_label is None else [parent, i, edge_label])
+        return i
+
+    def tok(label, parent, edge_label=None):
+        i = add(label, parent, edge_label)
+        tokens.append(i)
+        return i
+
+    def name(parent, edge_label=None):
+        i = tok(symbols[int(rng.integers(0, len(symbols)))], parent, edge_label)
+        names.append(i)
+        return i
+
+    binops, comparisons, calls, literals = [], [], [], []
+    for _ in range(num_statements):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:  # x = a + b
+            st = add("Assign", 0)
+            name(st)
+            tok("=", st)
+            bo = add("BinaryOperation", st)
+            name(bo)
+            tok(["+", "-", "*"][int(rng.integers(0, 3))], bo)
+            name(bo)
+            binops.append(bo)
+        elif kind == 1:  # if a < b :   /   if a is not b :
+            st = add("If", 0)
+            tok("if", st)
+            ct = add("ComparisonTarget", st)
+            name(ct)
+            if rng.integers(0, 3) == 0:
+                two = add("IsNot", ct)
+                tok("is", two)
+                tok("not", two)
+            else:
+                tok(["<", "<=", "==", "!="][int(rng.integers(0, 4))], ct)
+            name(ct)
+            tok(":", st)
+            comparisons.append(ct)
+        elif kind == 2:  # f ( a , b , c )
+            st = add("Expr", 0)
+            call = add("Call", st)
+            name(call)
+            tok("(", call)
+            args = []
+            for a in range(3):
+                args.append(name(call, "args"))
+                if a < 2:
+                    tok(",", call)
+            tok(")", call)
+            calls.append(call)
+        else:  # x += 1
+            st = add("AugAssign", 0)
+            name(st)
+            tok("+=", st)
+            literals.append(tok(str(int(rng.integers(0, 3))), st))
+    if not names:
+        st = add("Expr", 0)
+        name(st)
+    next_token = [[tokens[i], tokens[i + 1]] for i in range(len(tokens) - 1)]
+    sym_nodes, occ = {}, []
+    for t in names:
+        s = nodes[t]
+        if s not in sym_nodes:
+            nodes.append(s)
+            sym_nodes[s] = len(nodes) - 1
+        occ.append([t, sym_nodes[s]])
+    pick = lambda pool: pool[int(rng.integers(0, len(pool)))]
+    syntax = [i for i in range(len(nodes)) if i not in tokens and i not in sym_nodes.values()]
+    edges = {
+        "Child": child, "NextToken": next_token, "OccurrenceOf": occ,
+        "Sibling": [[child[i][1], child[i + 1][1]] for i in range(0, len(child) - 1, 3)],
+        "LastMayWrite": [[pick(names), pick(names)] for _ in range(max(1, len(names) // 2))],
+        "NextMayUse": [[pick(names), pick(names)] for _ in range(max(1, len(names) // 2))],
+        "ComputedFrom": [[pick(syntax), pick(names)] for _ in range(3)] + [[pick(names), pick(syntax)] for _ in range(2)],
+    }
+    reference_nodes, rewrites, metadata, ranges = [], [], [], []
+
+    def rw(node, rewrite, meta):
+        reference_nodes.append(int(node))
+        rewrites.append(rewrite)
+        metadata.append(meta)
+        ranges.append(((0, 0), (0, 1)))
+
+    for bo in binops[:2]:
+        for op in ("+", "-", "*", "/"):
+            rw(bo, ("ReplaceText", op), ("BinaryOperatorRewriteScout", None))
+    for ct in comparisons[:2]:
+        for op in ("<", "<=", "=="):
+            rw(ct, ("ReplaceText", op), ("ComparisonOperatorRewriteScout", None))
+    for t in names[:3]:
+        for s in sym_nodes.values():
+            rw(t, ("ReplaceText", nodes[s]), ("VariableMisuseRewriteScout", int(s)))
+    for call in calls[:2]:
+        rw(call, ("ArgSwap", (0, 1)), ("ArgSwapRewriteScout", None))
+        rw(call, ("ArgSwap", (1, 2)), ("ArgSwapRewriteScout", None))
+    for lit in literals[:1]:
+        rw(lit, ("ReplaceText", "1"), ("LiteralRewriteScout", None))
+    target = int(rng.integers(0, len(rewrites))) if (buggy and rewrites) else None
+    return {
+        "graph": {"nodes": nodes, "edges": edges, "path": f"{package}/seq.py", "text": "", "reference_nodes": reference_nodes,
+                  "code_range": ((0, 0), (1, 0))},
+        "candidate_rewrites": rewrites, "candidate_rewrite_metadata": metadata, "candidate_rewrite_ranges": ranges,
+        "target_fix_action_idx": target, "package_name": package,
+    }
+
+
+def make_buglab_seq_dataset(n: int, seed: int = 0, min_statements: int = 4, max_statements: int = 9):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        d = make_buglab_seq_datapoint(rng, num_statements=int(rng.integers(min_statements, max_statements + 1)), buggy=(len(out) % 2 == 0))
+        if d["candidate_rewrites"]:
+            out.append(d)
+    return out

@@ -1,7 +1,7 @@
 """Model registry -- the plugin API of the path (reference buglab/models/modelregistry.py):
 `load_model`, `construct_model_dict`, `gnn`, buggy-sample weight schedules.  Same names, kwargs,
-defaults and error behaviour; `gnn-mlp` is built on the HIP path, the other registry names raise
-NotImplementedError until their SURVEY section 8f rows are built."""
+defaults and error behaviour; `gnn-mlp`, `ggnn`, `seq-great` and `seq-rat` are built on the HIP path;
+`seq-transformer` / `seq-gru` (torch.nn wrappers in the reference) raise NotImplementedError."""
 import logging
 import re
 from functools import partial
@@ -80,9 +80,22 @@ def gnn(*, mp_layer, add_self_edge: bool, use_all_gnn_layer_outputs: bool = Fals
     )
 
 
-def seq_transformer(*, layer_type, **__):
-    raise NotImplementedError(f"sequence models (`seq-{layer_type}`, reference modelregistry.py:97-126) are a SURVEY "
-                              "section 8f 'next' row; only `gnn-mlp` runs on the HIP path so far")
+def seq_transformer(*, layer_type, hidden_state_size: int = 256, dropout_rate: float = 0.1, vocab_size: int = 15000,
+                    selector_loss_type: str = "classify-max-loss", num_layers: int = 5, num_heads: int = 8, max_seq_size: int = 400,
+                    intermediate_dimension_size: int = 1024, buggy_samples_weight_spec: Union[str, int, float] = 1.0,
+                    rezero_mode: str = "off", normalisation_mode: str = "postnorm", **__):
+    """reference :97-126 (same kwargs and defaults).  `great` / `rat` run on the HIP path; `transformer` / `gru` wrap
+    torch.nn modules in the reference and are not built here."""
+    if layer_type not in ("great", "rat"):
+        raise NotImplementedError(f"`seq-{layer_type}` wraps torch.nn.{'TransformerEncoderLayer' if layer_type == 'transformer' else 'GRU'} "
+                                  "in the reference (seqmodel.py:108-130); the HIP path implements `seq-great` and `seq-rat`")
+    from buglab.models.seqmodel import SeqBugLabModel
+
+    return SeqBugLabModel(hidden_state_size, max_subtoken_vocab_size=vocab_size, dropout_rate=dropout_rate, layer_type=layer_type,
+                          generator_loss_type=selector_loss_type, intermediate_dimension_size=intermediate_dimension_size,
+                          buggy_samples_weight_schedule=buggy_sample_weight_schedule(buggy_samples_weight_spec),
+                          max_seq_size=max_seq_size, num_heads=num_heads, num_layers=num_layers, rezero_mode=rezero_mode,
+                          normalisation_mode=normalisation_mode)
 
 
 def construct_model_dict(gnn_constructor: Callable, seq_constructor: Callable) -> Dict[str, Callable]:

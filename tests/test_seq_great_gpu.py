@@ -124,3 +124,103 @@ def test_attention_dropout_and_padding():
     num = (f(x + eps * d) - f(x - eps * d)) / (2 * eps)
     ana = float((xg.grad.double() * d.double()).sum())
     assert abs(num - ana) <= 5e-2 * abs(ana), (num, ana)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole model through the registry: host pipeline -> padded minibatch -> HIP encoder + heads, vs the CPU oracle
+_ENC = {"qkv_W": ("self_attn._selfatt_head_transforms.weight", True), "out_W": ("self_attn._out_proj.weight", True),
+        "edge_bias_f": ("self_attn._edge_attention_biases.weight", False), "edge_bias_r": ("self_attn._reverse_edge_attention_biases.weight", False),
+        "edge_vbias_f": ("self_attn._edge_value_biases.weight", False), "edge_vbias_r": ("self_attn._reverse_edge_value_biases.weight", False),
+        "lin1_W": ("linear1.weight", True), "lin1_b": ("linear1.bias", False), "lin2_W": ("linear2.weight", True), "lin2_b": ("linear2.bias", False),
+        "norm1_g": ("norm1.weight", False), "norm1_b": ("norm1.bias", False), "norm2_g": ("norm2.weight", False), "norm2_b": ("norm2.bias", False)}
+_HEADS = {"_localization_module.": "loc.", "_text_repair_module.": "text.", "_varmisuse_module.": "var.", "_argswap_module.": "swap."}
+
+
+def _oracle_params(module):
+    """module.state_dict() -> {oracle name: (tensor for the oracle (fp64 leaf), module parameter name, transposed?)}"""
+    out = {}
+    for k, v in module.state_dict().items():
+        v = v.detach().cpu().double()
+        if k.startswith("_gnn.layers."):
+            _, _, i, name = k.split(".", 3)
+            ref, tr = _ENC[name]
+            out[f"layers.{i}.{ref}"] = (v.T.contiguous() if tr else v, k, tr)
+        elif k == "_gnn.embed.table":
+            out["embed.table"] = (v, k, False)
+        elif k == "_gnn.positional_encoding":
+            out["positional_encoding"] = (v, k, False)
+        elif k in ("_gnn.input_norm_g", "_gnn.input_norm_b"):
+            out["input_norm." + ("weight" if k.endswith("_g") else "bias")] = (v, k, False)
+        else:
+            for a, b in _HEADS.items():
+                if k.startswith(a):
+                    out[b + k[len(a):]] = (v, k, False)
+    return out
+
+
+@pytest.mark.parametrize("model_name", ["seq-great", "seq-rat"])
+def test_seq_model_end_to_end_matches_oracle(model_name):
+    import copy
+    from pathlib import Path
+
+    from buglab.data.collate import to_device
+    from buglab.data.synthetic import make_buglab_seq_dataset
+    from buglab.models.modelregistry import load_model
+    from oracle import great_oracle as G
+    from oracle import seq_oracle as SO
+
+    data = make_buglab_seq_dataset(6, seed=5)
+    model = load_model({"modelName": model_name, "hidden_state_size": 64, "num_layers": 2, "num_heads": 4, "intermediate_dimension_size": 96,
+                        "dropout_rate": 0.0}, Path("/tmp/_bl_seq_e2e.pkl.gz"))[0]
+    model.compute_metadata(copy.deepcopy(data))
+    torch.manual_seed(0)
+    nn_ = model.build_neural_module().cuda().train()
+    samples = [model.tensorize(copy.deepcopy(d)) for d in data]
+    assert all(s is not None for s in samples)
+    mb_np = model.collate_minibatch({"samples": samples})
+    mb = to_device(mb_np, "cuda")
+    nn_.reset_metrics()
+    loss = nn_(**mb)
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(nn_.named_parameters())
+    table = _oracle_params(nn_)
+    p = {k: v[0].clone().requires_grad_(True) for k, v in table.items()}
+    cfg = G.GreatConfig(d_model=64, num_heads=4, num_layers=2, dim_feedforward=96, num_edge_types=max(1, len(model.edge_types)),
+                        use_edge_value_biases=model_name == "seq-rat")
+    out = SO.forward_loss(p, mb_np, cfg)
+    assert abs(float(loss.detach()) - float(out["loss"])) < 1e-4, (float(loss.detach()), float(out["loss"]))
+    out["loss"].backward()
+    with torch.no_grad():
+        nn_.eval()
+        _, loc_lp, enc_out, _ = nn_.compute_localization_logprobs(mb["graph_data"])
+    assert float((loc_lp.cpu().double() - out["loc_logprobs"].detach()).abs().max()) < 1e-4
+    valid = (np.arange(mb_np["graph_data"]["seq_len"])[None, :] < mb_np["graph_data"]["seq_lens"][:, None]).reshape(-1)
+    d = (enc_out.output_node_representations.cpu().double() - out["node_reprs"].detach())[torch.from_numpy(valid)]
+    assert float(d.abs().max()) < 1e-4
+    for name, (_, mod_name, tr) in table.items():
+        if mod_name not in named:
+            continue
+        want = p[name].grad if p[name].grad is not None else torch.zeros_like(p[name])
+        want = want.T if tr else want
+        got = named[mod_name].grad
+        got = got.cpu().double() if got is not None else torch.zeros_like(want)
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-6, name
+    # a few optimiser steps lower the loss; predict() returns normalised distributions over (mapped) graph nodes
+    from buglab.runtime.optim import FlatAdam
+
+    opt = FlatAdam(nn_.parameters(), lr=1e-3, num_warmup_steps=0)
+    nn_.train()
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        l = nn_(**mb)
+        l.backward()
+        opt.step()
+        losses.append(float(l.detach()))
+    assert losses[-1] < losses[0]
+    res = list(model.predict(iter(copy.deepcopy(data)), nn_, "cuda", parallelize=False))
+    assert len(res) == len(data)
+    for point, loc, rewrites in res:
+        assert len(rewrites) == len(point["candidate_rewrites"]) and -1 in loc
+        assert set(k for k in loc if k >= 0) == set(point["graph"]["reference_nodes"])
