@@ -107,15 +107,63 @@ def cpu_baseline(args, seconds_budget=25.0):
     }
 
 
+def cpu_baseline_seq(args, seconds_budget=25.0):
+    """seq-great on the CPU oracle (oracle/seq_oracle.py: the reference's own transformer layers restated and pinned,
+    heads as in the graph model): forward + backward of a 2-sequence minibatch, fp32, all host cores."""
+    import torch
+
+    from buglab.data.synthetic import make_samples
+    from buglab.models.seqmodel import SeqTensorizedSample, collate_sequences
+    from oracle import buglab_oracle as O
+    from oracle import great_oracle as G
+    from oracle import seq_oracle as SO
+
+    nb, D, T = 2, args.hidden, args.types
+    mb = collate_sequences([SeqTensorizedSample(s, {}, ()) for s in make_samples(nb, seed=123, num_nodes=args.seq_len,
+                                                                                    num_messages=2 * args.seq_len, num_edge_types=T)], T)
+    cfg = G.GreatConfig(d_model=D, num_heads=8, num_layers=args.layers, dim_feedforward=4 * D, num_edge_types=T)
+    g = torch.Generator().manual_seed(0)
+    r = lambda *shape: (torch.randn(*shape, generator=g) * 0.05)
+    p = {k: v for k, v in O.init_params(O.OracleConfig(hidden=D, num_layers=4, num_edge_types=T), seed=0).items() if not k.startswith("mp.")}
+    p.update({"positional_encoding": r(1, 5000, D), "input_norm.weight": torch.ones(D), "input_norm.bias": torch.zeros(D)})
+    for i in range(args.layers):
+        pre = f"layers.{i}."
+        p.update({pre + "self_attn._selfatt_head_transforms.weight": r(3 * D, D), pre + "self_attn._out_proj.weight": r(D, D),
+                  pre + "self_attn._edge_attention_biases.weight": r(T, D), pre + "self_attn._reverse_edge_attention_biases.weight": r(T, D),
+                  pre + "linear1.weight": r(4 * D, D), pre + "linear1.bias": r(4 * D), pre + "linear2.weight": r(D, 4 * D),
+                  pre + "linear2.bias": r(D), pre + "norm1.weight": torch.ones(D), pre + "norm1.bias": torch.zeros(D),
+                  pre + "norm2.weight": torch.ones(D), pre + "norm2.bias": torch.zeros(D)})
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    t_spent, n_steps, step = 0.0, 0, 0
+    while True:
+        t0 = time.perf_counter()
+        for v in leaves.values():
+            v.grad = None
+        SO.forward_loss(leaves, mb, cfg)["loss"].backward()
+        dt = time.perf_counter() - t0
+        step += 1
+        if step > 1:
+            t_spent += dt
+            n_steps += 1
+        if step >= 2 and (t_spent + dt > seconds_budget or n_steps >= 3):
+            break
+    return {"value": round(nb * n_steps / t_spent, 3), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_steps} forward+backward passes of {nb} sequences ({args.seq_len} tokens, H{D}, {args.layers} layers) on the CPU oracle, dropout 0"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--model", default="gnn-mlp", choices=["gnn-mlp", "seq-great"],
+                    help="gnn-mlp: BASELINE configs[1] (default).  seq-great: BASELINE configs[4], relational transformer, "
+                         "hidden 256, 5 layers, 8 heads, FF 1024, sequences of --seq-len tokens")
+    ap.add_argument("--seq-len", type=int, default=512)
+    ap.add_argument("--hidden", type=int, default=None, help="default 128 (gnn-mlp) / 256 (seq-great)")
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--types", type=int, default=16)
-    ap.add_argument("--graphs", type=int, default=64, help="graphs per GPU (weak scaling)")
+    ap.add_argument("--graphs", type=int, default=None, help="graphs (sequences) per GPU (weak scaling); default 64 / 32")
     ap.add_argument("--nodes", type=int, default=2000)
     ap.add_argument("--messages", type=int, default=10000)
     ap.add_argument("--dropout", type=float, default=0.2)
@@ -123,6 +171,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true", help="skip the forward-only passes after the timed training steps (profiling)")
     args = ap.parse_args()
+    seq = args.model == "seq-great"
+    if args.hidden is None:
+        args.hidden = 256 if seq else 128
+    if args.graphs is None:
+        args.graphs = 32 if seq else 64
+    if seq:
+        args.layers, args.types, args.dropout = (5 if args.layers == 8 else args.layers), (8 if args.types == 16 else args.types), 0.1
 
     import torch
     import torch.distributed as dist
@@ -138,11 +193,24 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     hip_ops.load_library()  # fail loudly if the HIP extension is missing
 
-    samples = make_samples(args.graphs, seed=1000 + rank, num_nodes=args.nodes, num_messages=args.messages, num_edge_types=args.types,
-                           degree=args.degree, max_degree=512)
-    mb = to_device(collate_samples(samples, args.types), device)
     torch.manual_seed(0)  # identical initial weights on every rank
-    module = build_gnn_mlp_module(args.hidden, args.layers, args.types, dropout_rate=args.dropout, dropout_base_seed=rank).to(device).train()
+    if seq:
+        # BASELINE configs[4]: every sequence has --seq-len tokens (1-6 subtokens each), 2 relations per token over 8 edge
+        # kinds, 40 candidate locations and the usual rewrite candidates; laid out by the product's own padded collator
+        from buglab.models.layers.messagepassing import SubtokenEmbedder
+        from buglab.models.seqmodel import SeqBugLabModule, SeqTensorizedSample, SequenceEncoder, collate_sequences
+
+        samples = make_samples(args.graphs, seed=1000 + rank, num_nodes=args.seq_len, num_messages=2 * args.seq_len, num_edge_types=args.types)
+        mb = to_device(collate_sequences([SeqTensorizedSample(s, {}, ()) for s in samples], args.types), device)
+        enc = SequenceEncoder(SubtokenEmbedder(15000, args.hidden, 6, args.dropout), args.hidden, args.types, args.layers, 8,
+                              4 * args.hidden, args.dropout, layer_type="great")
+        module = SeqBugLabModule(enc, 48).to(device).train()
+        module._dropout_base_seed = rank
+    else:
+        samples = make_samples(args.graphs, seed=1000 + rank, num_nodes=args.nodes, num_messages=args.messages, num_edge_types=args.types,
+                               degree=args.degree, max_degree=512)
+        mb = to_device(collate_samples(samples, args.types), device)
+        module = build_gnn_mlp_module(args.hidden, args.layers, args.types, dropout_rate=args.dropout, dropout_base_seed=rank).to(device).train()
     opt = FlatAdam(module.parameters())
     weight = D.global_batch_weight(args.graphs, device)
 
@@ -221,7 +289,14 @@ def main():
 
     if rank == 0:
         total_graphs = args.graphs * world * args.steps
-        fwd_flop, fwd_bytes = algorithmic_work_per_graph(args.hidden, args.layers, args.nodes, args.messages, args.types, args.graphs)
+        if seq:
+            # per sequence and layer: QKV + output projections 8 L D^2, feed-forward 4 L D FF, Q.K^T + P.V 4 L^2 D (~5.4 GFLOP)
+            Ls, Dh, FFd = args.seq_len, args.hidden, 4 * args.hidden
+            fwd_flop = args.layers * (8.0 * Ls * Dh * Dh + 4.0 * Ls * Dh * FFd + 4.0 * Ls * Ls * Dh)
+            n_par = args.layers * (4 * Dh * Dh + 2 * Dh * FFd)
+            fwd_bytes = args.layers * (3 * 4.0 * Ls * Dh) + 4.0 * n_par / args.graphs
+        else:
+            fwd_flop, fwd_bytes = algorithmic_work_per_graph(args.hidden, args.layers, args.nodes, args.messages, args.types, args.graphs)
         value = total_graphs / elapsed
         # dominant kernel = largest EXCLUSIVE time per step among the MFMA GEMM kinds (serial pass)
         gemm = {k: v for k, v in kern.items() if v["flop"] > 0 and v["ms"] > 0}
@@ -275,9 +350,11 @@ def main():
             "dtype": "f32",  # fp32 storage/accumulation; MP-layer products as bf16x6 split terms (fp32-equivalent)
             "data": "synthetic",
             "config": {
-                "workload": f"gnn-mlp hidden={args.hidden} layers={args.layers} edge_types={args.types} "
-                            f"batch={args.graphs} graphs/GPU x ({args.nodes} nodes, {args.messages} msgs) dropout={args.dropout}"
-                            + (" power-law in-degree (max 512)" if args.degree == "powerlaw" else ""),
+                "workload": (f"seq-great relational transformer hidden={args.hidden} layers={args.layers} heads=8 ff={4 * args.hidden} "
+                             f"edge_kinds={args.types} batch={args.graphs} sequences/GPU x {args.seq_len} tokens dropout={args.dropout}") if seq else
+                            (f"gnn-mlp hidden={args.hidden} layers={args.layers} edge_types={args.types} "
+                             f"batch={args.graphs} graphs/GPU x ({args.nodes} nodes, {args.messages} msgs) dropout={args.dropout}"
+                             + (" power-law in-degree (max 512)" if args.degree == "powerlaw" else "")),
                 "global_batch": args.graphs * world,
                 "parallelism": f"dp{world}",
                 "loss_last_step": round(last_loss, 5),
@@ -285,7 +362,7 @@ def main():
             },
             "predict_graphs_per_s": None if predict_elapsed is None else round(args.graphs * world * args.steps / predict_elapsed, 1),  # forward-only, eval mode
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else (cpu_baseline_seq(args) if seq else cpu_baseline(args)),
         }
         print(json.dumps(line), flush=True)
     if world > 1:
