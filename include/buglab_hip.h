@@ -350,12 +350,20 @@ int bl_dropout_inplace(float* x, int64_t n, bl_dropout_t drop, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * T1  optimiser on flat fp32 buffers: global-norm clip (buglab/models/train.py:104, clip 0.5) fused
- * with Adam (buglab/models/utils.py:51-52).  bl_sqnorm writes sum(g^2) to *out (device scalar,
- * zeroed inside); bl_adam_clip_step reads it on the device -- no host sync. */
-int bl_sqnorm(const float* g, int64_t n, float* out, void* stream);
+ * with Adam (buglab/models/utils.py:51-52).  bl_sqnorm writes sum(g^2) to *out (device scalar);
+ * bl_adam_clip_step reads it on the device -- no host sync.  The sum is taken in one fixed order (per-block partials in
+ * `scratch`, bl_sqnorm_scratch_bytes() bytes, then one block): equal gradients give a bit-equal norm on every replica. */
+int64_t bl_sqnorm_scratch_bytes(void);
+int bl_sqnorm(const float* g, int64_t n, float* out, float* scratch, void* stream);
 int bl_adam_clip_step(float* param, const float* grad, float* m, float* v, int64_t n, const float* grad_sqnorm,
                       float grad_prescale, float clip_norm, float lr, float beta1, float beta2, float eps,
                       int32_t step, void* stream);
+/* data-parallel form: `grad` is the all-reduced SUM over ranks of (graphs on the rank) x (the rank's gradient) and
+ * *batch_total (device) the all-reduced number of graphs: the update uses grad / *batch_total; *batch_total <= 0 (no
+ * rank had a minibatch) leaves parameters and moments untouched.  No value returns to the host. */
+int bl_adam_clip_step_dp(float* param, const float* grad, float* m, float* v, int64_t n, const float* grad_sqnorm,
+                         const float* batch_total, float clip_norm, float lr, float beta1, float beta2, float eps,
+                         int32_t step, void* stream);
 
 #ifdef __cplusplus
 }

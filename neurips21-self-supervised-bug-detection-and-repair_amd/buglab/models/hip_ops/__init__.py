@@ -106,7 +106,9 @@ _SIGNATURES = {
     "bl_rowdot_bwd": ([c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_scatter_add_rows": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gather_rows": ([c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_sqnorm": ([c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "bl_sqnorm_scratch_bytes": ([], ctypes.c_int64),
+    "bl_sqnorm": ([c_void_p, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_adam_clip_step_dp": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p], ctypes.c_int),
     "bl_adam_clip_step": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p], ctypes.c_int),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -1378,8 +1380,19 @@ class _DropoutFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------
 # optimiser on flat buffers
-def sqnorm(flat_grad: torch.Tensor, out: torch.Tensor):
-    _check(load_library().bl_sqnorm(_f32(flat_grad).data_ptr(), flat_grad.numel(), out.data_ptr(), _stream()), "bl_sqnorm")
+_SQNORM_SCRATCH: dict = {}
+
+
+def sqnorm(flat_grad: torch.Tensor, out: torch.Tensor, scratch: Optional[torch.Tensor] = None):
+    """sum(g^2) -> out[0], added in one fixed order (replicas with equal gradients clip by the same number).  `scratch`
+    (bl_sqnorm_scratch_bytes()) defaults to one buffer per (device, stream)."""
+    lib = load_library()
+    if scratch is None:
+        key = (flat_grad.device, _stream())
+        scratch = _SQNORM_SCRATCH.get(key)
+        if scratch is None:
+            scratch = _SQNORM_SCRATCH[key] = torch.empty(lib.bl_sqnorm_scratch_bytes() // 4, dtype=torch.float32, device=flat_grad.device)
+    _check(lib.bl_sqnorm(_f32(flat_grad).data_ptr(), flat_grad.numel(), out.data_ptr(), scratch.data_ptr(), _stream()), "bl_sqnorm")
     return out
 
 
@@ -1389,3 +1402,12 @@ def adam_clip_step(param, grad, m, v, sqn, *, prescale=1.0, clip=0.5, lr=1e-4, b
                                          param.numel(), _p(sqn), float(prescale), float(clip), float(lr), float(beta1), float(beta2),
                                          float(eps), int(step), _stream()),
         "bl_adam_clip_step")
+
+
+def adam_clip_step_dp(param, grad, m, v, sqn, batch_total, *, clip=0.5, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
+    """Data-parallel form: grad = sum over ranks of B_rank * grad_rank, batch_total = device scalar sum of B_rank."""
+    _check(
+        load_library().bl_adam_clip_step_dp(_f32(param).data_ptr(), _f32(grad).data_ptr(), _f32(m).data_ptr(), _f32(v).data_ptr(),
+                                            param.numel(), _p(sqn), _f32(batch_total).data_ptr(), float(clip), float(lr), float(beta1),
+                                            float(beta2), float(eps), int(step), _stream()),
+        "bl_adam_clip_step_dp")

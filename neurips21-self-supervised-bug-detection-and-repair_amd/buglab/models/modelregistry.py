@@ -120,9 +120,9 @@ def load_model(model_spec: Dict[str, Any], model_path: Path, restore_path: Optio
 
         LOGGER.info("Resuming training from %s." % model_path)
         initialize_metadata = False
-        model, nn = AbstractNeuralModel.restore_model(
-            Path(restore_path) if restore_path is not None else model_path,
-            torch.device("cuda:0" if torch.cuda.is_available() else "cpu"))
+        # each rank restores onto ITS device (the reference is single-GPU and hard-wires cuda:0, modelregistry.py:155)
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        model, nn = AbstractNeuralModel.restore_model(Path(restore_path) if restore_path is not None else model_path, device)
     else:
         nn = None
         models = construct_model_dict(gnn, seq_transformer)

@@ -77,9 +77,21 @@ def run(arguments):
     trainer.register_train_epoch_end_hook(lambda model, nn, epoch, metrics: LOGGER.info("train epoch %s: %s", epoch, metrics))
     trainer.register_validation_epoch_end_hook(lambda model, nn, epoch, metrics: LOGGER.info("valid epoch %s: %s", epoch, metrics))
     if initialize_metadata:
-        data_for_metadata = LazyDataIterable(construct_data_loading_callable(training_data_path, shuffle=True,
-                                                                              limit_num_yielded_elements=250_000))
-        trainer.load_metadata_and_create_network(data_for_metadata, not arguments["--sequential"], not arguments["--quiet"])
+        import torch
+        import torch.distributed as dist
+
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:
+            data_for_metadata = LazyDataIterable(construct_data_loading_callable(training_data_path, shuffle=True,
+                                                                                  limit_num_yielded_elements=250_000))
+            trainer.load_metadata_and_create_network(data_for_metadata, not arguments["--sequential"], not arguments["--quiet"])
+        if multi:
+            # ONE metadata pass (rank 0) and one set of initial weights for every replica: vocabularies built from
+            # differently shuffled samples would map tokens to different embedding rows on different ranks
+            box = [(trainer.model, trainer.neural_module) if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if dist.get_rank() != 0:
+                trainer.model, trainer.neural_module = box[0]
     trainer.train(training_data, validation_data, show_progress_bar=not arguments["--quiet"], initialize_metadata=False,
                   parallelize=not arguments["--sequential"], use_multiprocessing=not arguments["--sequential"], patience=10)
 

@@ -47,6 +47,41 @@ def partition_by_messages(num_messages: Sequence[int], world_size: int) -> List[
     return [sorted(p) for p in parts]
 
 
+def datapoint_messages(datapoint) -> int:
+    """Message count of a raw (un-tensorised) BugLab datapoint: the edges it lists, which is what a step's time follows."""
+    try:
+        edges = datapoint["graph"]["edges"]
+        return int(sum(len(v) for v in edges.values())) if hasattr(edges, "values") else 1
+    except Exception:
+        return 1
+
+
+def balanced_rank_share(data, rank: int, world: int, window_per_rank: int = 16, size_fn=datapoint_messages):
+    """This rank's share of a stream that every rank iterates in the same order: the stream is cut in windows of
+    `world * window_per_rank` datapoints and each window is split with `partition_by_messages` (greedy bin-packing by
+    message count), so that ranks get about the same number of MESSAGES per step, not just the same number of graphs.
+    Deterministic given the stream: every datapoint is taken by exactly one rank."""
+    if world <= 1:
+        yield from data
+        return
+    window: list = []
+
+    def flush():
+        parts = partition_by_messages([size_fn(d) for d in window], world)
+        for i in parts[rank]:
+            yield window[i]
+
+    for d in data:
+        if d is None:
+            continue
+        window.append(d)
+        if len(window) == world * window_per_rank:
+            yield from flush()
+            window = []
+    if window:
+        yield from flush()
+
+
 def global_batch_weight(local_graphs: int, device) -> float:
     """B_rank / B_total, the factor that makes the sum over ranks of per-rank losses
     (`loc.mean() + repair / B_rank`, reference gnn.py:251) equal the full-minibatch loss."""

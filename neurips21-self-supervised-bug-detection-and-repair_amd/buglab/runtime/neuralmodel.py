@@ -144,8 +144,14 @@ class AbstractNeuralModel(ABC, Generic[TRawDatapoint, TTensorizedDatapoint, TNeu
 
     # ---- persistence --------------------------------------------------------------------------
     def save(self, path: Path, neural_module) -> None:
-        with gzip.open(path, "wb") as f:
+        """Written to a temporary file and moved into place: a crash mid-write cannot corrupt the previous best checkpoint."""
+        import os
+
+        path = Path(path)
+        tmp = path.with_name(path.name + ".tmp")
+        with gzip.open(tmp, "wb") as f:
             torch.save((self, neural_module), f)
+        os.replace(tmp, path)
 
     @classmethod
     def restore_model(cls, path: Path, device=None) -> Tuple["AbstractNeuralModel", Any]:

@@ -17,15 +17,25 @@ from buglab.models import hip_ops
 
 
 class FlatAdam:
+    TAIL = 4  # floats appended to the gradient buffer and all-reduced with it: [graphs on this rank, rank had a minibatch, -, -]
+
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, clip_gradient_norm: float = 0.5,
-                 num_warmup_steps: int = 800, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None):
+                 num_warmup_steps: int = 800, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, distributed: bool = True):
+        self.distributed = distributed  # False: never all-reduce (a single-replica reference run inside a multi-rank job)
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
         sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]  # keep every view 16-byte aligned
         self.numel = sum(sizes)
         self.flat_param = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._grad_and_tail = torch.zeros(self.numel + self.TAIL, dtype=torch.float32, device=dev)
+        self.flat_grad = self._grad_and_tail[: self.numel]
+        self.tail = self._grad_and_tail[self.numel :]
+        self._tail_host = [torch.zeros(self.TAIL, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(self.TAIL)
+                           for _ in range(2)]
+        self._tail_event = [None, None]
+        self._tail_slot = 0
+        self._last_dp_step_counted = False
         off = 0
         for p, n in zip(self.params, sizes):
             view = self.flat_param[off : off + p.numel()].view(p.shape)
@@ -47,7 +57,7 @@ class FlatAdam:
 
     def zero_grad(self):
         hip_ops.join_side_stream()
-        self.flat_grad.zero_()
+        self._grad_and_tail.zero_()
 
     def lr_at(self, step: int) -> float:
         """LambdaLR semantics of the reference's LinearWarmupScheduler (utils.py:55-66): the k-th
@@ -63,7 +73,7 @@ class FlatAdam:
         still to be applied to the buffer (folded into the fused Adam kernel)."""
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+        if self.distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             if grad_weight != 1.0:
                 self.flat_grad.mul_(grad_weight)  # weights may differ per rank: scale locally, then sum
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
@@ -82,6 +92,71 @@ class FlatAdam:
             hip_ops.invalidate_weight_packs()  # the kernel wrote the parameters behind autograd's version counters
         else:
             raise hip_ops.HipOpsUnavailable("FlatAdam.step: parameters are not on a ROCm device (no CPU fallback)")
+
+    # ---- data parallel: everything a step needs from the other ranks rides on the ONE gradient all-reduce ------------
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """Make every replica start from rank `src`'s parameters (and optimiser moments)."""
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            for t in (self.flat_param, self.m, self.v):
+                dist.broadcast(t, src=src, group=self.process_group)
+            hip_ops.invalidate_weight_packs()
+
+    def step_data_parallel(self, local_graphs: int) -> None:
+        """One optimiser step of a data-parallel run.  Each rank calls it EVERY step, with the number of graphs of the
+        minibatch it just back-propagated (0, with an untouched zero gradient buffer, when its loader is exhausted).
+        The gradient buffer is scaled by that count and all-reduced together with a 4-float tail carrying the count
+        and a "had a minibatch" flag: one collective per step, no host synchronisation.  The fused clip+Adam kernel
+        divides by the global count it finds in the tail (on the device) and does nothing when that count is zero."""
+        import torch.distributed as dist
+
+        hip_ops.join_side_stream()
+        B = int(local_graphs)
+        self.tail.zero_()
+        if B > 0:
+            self.tail[:2] = torch.tensor([float(B), 1.0]).to(self.tail.device, non_blocking=True)
+            self.flat_grad.mul_(float(B))
+        if self.distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            dist.all_reduce(self._grad_and_tail, op=dist.ReduceOp.SUM, group=self.process_group)
+        self.step_count += 1
+        self._last_dp_step_counted = True
+        self._apply_update_data_parallel()
+        hip_ops.invalidate_weight_packs()
+        # the tail of THIS step goes to pinned memory asynchronously; `previous_step_was_idle` reads it one step later
+        slot = self._tail_slot
+        self._tail_host[slot].copy_(self.tail, non_blocking=True)
+        ev = None
+        if self.tail.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._tail_event[slot] = ev
+        self._tail_slot = slot ^ 1
+        self._dp_steps = getattr(self, "_dp_steps", 0) + 1
+
+    def _apply_update_data_parallel(self) -> None:
+        """Squared norm + fused clip / Adam on the device (the CPU tests of the protocol override this)."""
+        if not self.flat_param.is_cuda:
+            raise hip_ops.HipOpsUnavailable("FlatAdam.step_data_parallel: parameters are not on a ROCm device (no CPU fallback)")
+        hip_ops.sqnorm(self.flat_grad, self.sqnorm)
+        hip_ops.adam_clip_step_dp(self.flat_param, self.flat_grad, self.m, self.v, self.sqnorm, self.tail, clip=self.clip,
+                                  lr=self.lr_at(self.step_count), beta1=self.beta1, beta2=self.beta2, eps=self.eps, step=self.step_count)
+
+    def previous_step_was_idle(self) -> bool:
+        """True when NO rank had a minibatch in the most recent `step_data_parallel` (the epoch is over for everyone).
+        Reads the pinned copy made by that step: by the time the next minibatch has been fetched the copy is long
+        complete, so this does not stall the device queue.  The idle step is taken back from the step counter."""
+        if getattr(self, "_dp_steps", 0) == 0:
+            return False
+        slot = self._tail_slot ^ 1
+        ev = self._tail_event[slot]
+        if ev is not None:
+            ev.synchronize()
+        idle = float(self._tail_host[slot][1]) == 0.0
+        if idle and self._last_dp_step_counted:
+            self.step_count -= 1  # nothing was updated (the kernel saw a zero global count)
+            self._last_dp_step_counted = False
+        return idle
 
     def grad_norm(self) -> float:
         """Global L2 norm of the last reduced gradient (host sync; diagnostics only)."""

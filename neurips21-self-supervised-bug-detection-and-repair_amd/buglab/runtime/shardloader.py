@@ -24,10 +24,16 @@ class ShardDataset:
     (train.py:76-91), and additionally aware of its files so that loading can be spread over processes."""
 
     def __init__(self, path, shuffle: bool = False, take_only_first_n_files: Optional[int] = None,
-                 limit_num_yielded_elements: Optional[int] = None):
+                 limit_num_yielded_elements: Optional[int] = None, seed: int = 0):
         self.path = path if isinstance(path, RichPath) else RichPath.create(str(path))
         self.shuffle, self.take_only_first_n_files = shuffle, take_only_first_n_files
         self.limit_num_yielded_elements = limit_num_yielded_elements
+        self.seed, self.epoch = seed, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        """The file order of an epoch is a function of (seed, epoch) only: every rank of a data-parallel run sees the
+        SAME order, so that the per-rank shares of the stream are disjoint and cover it."""
+        self.epoch = int(epoch)
 
     def shard_files(self) -> List[str]:
         files = sorted(self.path.iterate_filtered_files_in_dir("*.msgpack.l.gz"))
@@ -35,12 +41,19 @@ class ShardDataset:
             files = files[: self.take_only_first_n_files]
         files = [f.to_local_path().path for f in files]
         if self.shuffle:
-            random.shuffle(files)
+            random.Random(self.seed * 1_000_003 + self.epoch).shuffle(files)
         return files
 
     def __iter__(self):
-        return iter(load_all_msgpack_l_gz(self.path, shuffle=self.shuffle, take_only_first_n_files=self.take_only_first_n_files,
-                                          limit_num_yielded_elements=self.limit_num_yielded_elements))
+        n = 0
+        for f in self.shard_files():  # same (seeded) order as the loader processes use
+            for d in load_msgpack_l_gz(f):
+                if d is None:
+                    continue
+                yield d
+                n += 1
+                if self.limit_num_yielded_elements is not None and n > self.limit_num_yielded_elements:
+                    return  # same cut-off as load_all_msgpack_l_gz (reference msgpackutils.py:40-41)
 
 
 def default_num_workers() -> int:
@@ -53,20 +66,49 @@ def default_num_workers() -> int:
     return max(0, min(8, cores // max(1, world) - 1))
 
 
+def _read_shard(f: str) -> Iterator:
+    """Datapoints of one shard; a shard that cannot be read is reported and skipped like the reference does
+    (msgpackutils.py:45-46).  ONLY reading is guarded: tensorize / collate errors are bugs or bad samples and travel to
+    the consumer (`_WorkerError`) instead of silently dropping the rest of the shard."""
+    it = iter(load_msgpack_l_gz(f))
+    while True:
+        try:
+            d = next(it)
+        except StopIteration:
+            return
+        except Exception as e:
+            print(f"Error loading {f}: {e}.")
+            return
+        yield d
+
+
+class _WorkerError:
+    def __init__(self, where: str, exc: BaseException):
+        import traceback
+
+        self.text = f"loader process failed in {where}: {exc!r}\n{traceback.format_exc()}"
+
+
+def _rank_stream(files: Sequence[str], rank: int, world: int, stop) -> Iterator:
+    """This rank's datapoints of the worker's files: per file, windows split by message count (see
+    buglab.runtime.distributed.balanced_rank_share) -- every rank's worker w reads the same files in the same order."""
+    from buglab.runtime.distributed import balanced_rank_share
+
+    for f in files:
+        for d in balanced_rank_share(_read_shard(f), rank, world):
+            if stop.is_set():
+                return
+            yield d
+
+
 def _worker(model, files: Sequence[str], rank: int, world: int, out_q, stop) -> None:
     try:
-        for f in files:
-            try:
-                for i, d in enumerate(load_msgpack_l_gz(f)):
-                    if stop.is_set():
-                        return
-                    if d is None or i % world != rank:
-                        continue
-                    t = model.tensorize(d)
-                    if t is not None:  # dropped sample (reference gnn.py:404-405)
-                        out_q.put(t)
-            except Exception as e:  # reference msgpackutils.py:45-46: bad files are reported and skipped
-                print(f"Error loading {f}: {e}.")
+        for d in _rank_stream(files, rank, world, stop):
+            t = model.tensorize(d)
+            if t is not None:  # dropped sample (reference gnn.py:404-405)
+                out_q.put(t)
+    except BaseException as e:
+        out_q.put(_WorkerError("tensorize", e))
     finally:
         out_q.put(_DONE)
 
@@ -74,25 +116,19 @@ def _worker(model, files: Sequence[str], rank: int, world: int, out_q, stop) -> 
 def _minibatch_worker(model, files: Sequence[str], rank: int, world: int, max_minibatch_size: int, packed: bool, out_q, stop) -> None:
     try:
         mb, n = model.initialize_minibatch(), 0
-        for f in files:
-            try:
-                for i, d in enumerate(load_msgpack_l_gz(f)):
-                    if stop.is_set():
-                        return
-                    if d is None or i % world != rank:
-                        continue
-                    t = model.tensorize(d)
-                    if t is None:
-                        continue
-                    keep = model.extend_minibatch_with(t, mb)
-                    n += 1
-                    if not keep or n >= max_minibatch_size:
-                        out_q.put(_ship(model.collate_minibatch(mb), packed))
-                        mb, n = model.initialize_minibatch(), 0
-            except Exception as e:
-                print(f"Error loading {f}: {e}.")
-        if n > 0:
+        for d in _rank_stream(files, rank, world, stop):
+            t = model.tensorize(d)
+            if t is None:
+                continue
+            keep = model.extend_minibatch_with(t, mb)
+            n += 1
+            if not keep or n >= max_minibatch_size:
+                out_q.put(_ship(model.collate_minibatch(mb), packed))
+                mb, n = model.initialize_minibatch(), 0
+        if n > 0 and not stop.is_set():
             out_q.put(_ship(model.collate_minibatch(mb), packed))
+    except BaseException as e:
+        out_q.put(_WorkerError("tensorize / collate", e))
     finally:
         out_q.put(_DONE)
 
@@ -188,11 +224,14 @@ def _run_workers(target, model, files: Sequence[str], num_workers: int, extra_ar
                 item = out_q.get(timeout=1.0)
             except queue_mod.Empty:
                 if not any(p.is_alive() for p in procs) and out_q.empty():
-                    break  # a worker died without its sentinel
+                    raise RuntimeError(f"{num_workers - done} loader process(es) exited without finishing their shards "
+                                       "(killed? out of memory?): the epoch would silently be incomplete")
                 continue
             if isinstance(item, str) and item == _DONE:
                 done += 1
                 continue
+            if isinstance(item, _WorkerError):
+                raise RuntimeError(item.text)
             yield item
             n += 1
             if limit is not None and n >= limit:

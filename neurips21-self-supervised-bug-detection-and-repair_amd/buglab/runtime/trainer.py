@@ -145,13 +145,11 @@ class ModelTrainer:
         return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
     def _rank_share(self, data: Iterable):
+        """This rank's datapoints of a stream every rank reads in the SAME order: windows of the stream are split by
+        message count (greedy bin-packing, buglab.runtime.distributed.balanced_rank_share) -- a step's time follows the
+        number of messages, not the number of graphs."""
         rank, world = self._world()
-        if world == 1:
-            yield from data
-            return
-        for i, d in enumerate(data):
-            if i % world == rank:
-                yield d
+        yield from D.balanced_rank_share(data, rank, world)
 
     def _iter_minibatches(self, data, device, parallelize, shuffle_key=None):
         from buglab.runtime.shardloader import collated_minibatches_parallel, default_num_workers
@@ -192,18 +190,36 @@ class ModelTrainer:
         nn = self.neural_module
         nn.train()
         nn.reset_metrics()
+        if hasattr(training_data, "set_epoch"):
+            training_data.set_epoch(epoch)  # every rank shuffles the shard files with the same per-epoch seed
         it = iter(self._iter_minibatches(training_data, device, parallelize))
         step, num_graphs, t0 = 0, 0, time.time()
+        _, world = self._world()
+        fused_dp = world > 1 and hasattr(optimizer, "step_data_parallel")
         try:
             while True:
                 mb = next(it, None)
-                if not self._all_ranks_have(mb is not None, device):
-                    break
-                optimizer.zero_grad()
-                loss = nn(**mb)
-                loss.backward()
-                B = int(mb["has_bug"].shape[0])
-                optimizer.step(D.global_batch_weight(B, device))
+                if fused_dp:
+                    # Ranks stay in lock step through the gradient all-reduce alone: a rank whose loader is exhausted
+                    # keeps stepping with an empty contribution until the tail of the all-reduce says that nobody had
+                    # a minibatch (read one step late from pinned memory: no device synchronisation, no extra collective)
+                    if step > 0 and optimizer.previous_step_was_idle():
+                        break
+                    optimizer.zero_grad()
+                    B = 0
+                    if mb is not None:
+                        loss = nn(**mb)
+                        loss.backward()
+                        B = int(mb["has_bug"].shape[0])
+                    optimizer.step_data_parallel(B)
+                else:
+                    if not self._all_ranks_have(mb is not None, device):
+                        break
+                    optimizer.zero_grad()
+                    loss = nn(**mb)
+                    loss.backward()
+                    B = int(mb["has_bug"].shape[0])
+                    optimizer.step(D.global_batch_weight(B, device))
                 if scheduler is not None:
                     scheduler.step(epoch_idx=epoch, epoch_step=step)
                 step += 1
@@ -223,21 +239,16 @@ class ModelTrainer:
         nn.reset_metrics()
         total, n = torch.zeros((), device=device), 0
         with torch.no_grad():
-            it = iter(self._iter_minibatches(validation_tensors, device, parallelize))
-            try:
-                while True:
-                    mb = next(it, None)
-                    if not self._all_ranks_have(mb is not None, device):
-                        break
-                    total += nn(**mb).detach()
-                    n += 1
-            finally:
-                it.close()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # validation needs no lock step between ranks: each rank runs through its own share, ONE all-reduce at the end
+            for mb in self._iter_minibatches(validation_tensors, device, parallelize):
+                total += nn(**mb).detach()
+                n += 1
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if distributed:
             t = torch.stack([total, torch.tensor(float(n), device=device)])
             dist.all_reduce(t)
             total, n = t[0], int(t[1].item())
-        metrics = nn.report_metrics()
+        metrics = nn.report_metrics()  # per-rank counters (the loss above is global)
         val_loss = float(total) / max(n, 1)
         for hook in self._validation_epoch_end_hooks:
             hook(self.model, nn, epoch, metrics)
@@ -246,6 +257,12 @@ class ModelTrainer:
             improved = target > best_target_metric if self._target_higher_better else target < best_target_metric
         else:
             target, improved = val_loss, val_loss < best_target_metric
+        if distributed:
+            # every rank must take the same early-stopping / checkpoint branch: rank 0's decision is the decision
+            # (a target metric, or an overridden _run_validation, is computed from rank-local counters)
+            decision = [float(target), bool(improved)]
+            dist.broadcast_object_list(decision, src=0)
+            target, improved = decision
         LOGGER.info("Epoch %s: validation loss %.5f. Metrics: %s", epoch, val_loss, metrics)
         return target, improved
 
@@ -261,8 +278,20 @@ class ModelTrainer:
             device = torch.device("cuda", torch.cuda.current_device())
         self._nn = self.neural_module.to(device)
         optimizer = self._optimizer_creator(self._nn.parameters())
-        if self._clip is not None and hasattr(optimizer, "clip"):
-            optimizer.clip = self._clip
+        if self._clip is not None:
+            if hasattr(optimizer, "clip"):
+                optimizer.clip = self._clip
+            else:
+                LOGGER.warning("clip_gradient_norm=%s was requested but %s cannot apply it (only FlatAdam fuses the clip); "
+                               "gradients are NOT clipped", self._clip, type(optimizer).__name__)
+        _, world = self._world()
+        if world > 1:
+            # replicas must be identical before the first step: rank 0's parameters (and moments) win
+            if hasattr(optimizer, "broadcast_parameters"):
+                optimizer.broadcast_parameters(0)
+            else:
+                for p in self._nn.parameters():
+                    dist.broadcast(p.data, src=0)
         scheduler = self._scheduler_creator(optimizer) if self._scheduler_creator is not None else None
         for hook in self._training_start_hooks:
             hook(self.model, self._nn, optimizer)

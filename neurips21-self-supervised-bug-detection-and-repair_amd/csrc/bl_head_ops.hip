@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------
 // T1  flat-buffer optimiser
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+// Two passes so that the sum has ONE order of additions whatever the block scheduling: data-parallel replicas clip by
+// this number and must get it bit-identical from bit-identical gradients (atomics would let them drift by an ulp a step).
+constexpr int SQNORM_MAX_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long n, float* __restrict__ partials) {
   __shared__ float red[4];
   float s = 0.f;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -121,17 +124,32 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   s = bl_wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ partials, int count, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
+  s = bl_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
 }
 
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* __restrict__ sqnorm, float prescale, float clip,
                                                         float lr_over_bc1, float beta1, float beta2, float eps,
-                                                        float inv_sqrt_bc2) {
+                                                        float inv_sqrt_bc2, const float* __restrict__ batch_total) {
   float scale = prescale;
+  if (batch_total) {  // data parallel: the summed gradient is weighted by graphs per rank; divide by the global count
+    const float bt = batch_total[0];
+    if (!(bt > 0.f)) return;  // no rank had a minibatch (the step after the last one of an epoch): leave everything untouched
+    scale /= bt;
+  }
   if (clip > 0.f) {
-    const float total = sqrtf(sqnorm[0]) * prescale;
+    const float total = sqrtf(sqnorm[0]) * scale;  // norm of the gradient the update uses (after the 1/count of data parallel)
     scale *= fminf(1.0f, clip / (total + 1e-6f));  // torch.nn.utils.clip_grad_norm_
   }
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -209,13 +227,16 @@ extern "C" int bl_gather_rows(const float* x, int32_t ld_x, const int32_t* idx, 
   return BL_OK;
 }
 
-extern "C" int bl_sqnorm(const float* g, int64_t n, float* out, void* stream) {
-  BL_CHECK_ARG(g && out && bl_aligned16(g), "bl_sqnorm: null or misaligned pointer");
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) { bl_set_error("bl_sqnorm: memset failed: %s", hipGetErrorString(e)); return (int)e; }
-  if (n == 0) return BL_OK;
-  const int blocks = (int)fmin(2048.0, (double)((n / 4 + 255) / 256 + 1));
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (long long)n, out);
+extern "C" int64_t bl_sqnorm_scratch_bytes(void) { return (int64_t)SQNORM_MAX_BLOCKS * sizeof(float); }
+
+extern "C" int bl_sqnorm(const float* g, int64_t n, float* out, float* scratch, void* stream) {
+  BL_CHECK_ARG(g && out && scratch && bl_aligned16(g), "bl_sqnorm: null or misaligned pointer");
+  const int blocks = n == 0 ? 0 : (int)fmin((double)SQNORM_MAX_BLOCKS, (double)((n / 4 + 255) / 256 + 1));
+  if (blocks) {
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (long long)n, scratch);
+    BL_LAUNCH_CHECK("bl_sqnorm");
+  }
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, blocks, out);
   BL_LAUNCH_CHECK("bl_sqnorm");
   return BL_OK;
 }
@@ -232,7 +253,22 @@ extern "C" int bl_adam_clip_step(float* param, const float* grad, float* m, floa
   const int blocks = (int)fmin(2048.0, (double)((n + 255) / 256));
   hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n,
                      grad_sqnorm, grad_prescale, clip_norm, (float)((double)lr / bc1), beta1, beta2, eps,
-                     (float)(1.0 / sqrt(bc2)));
+                     (float)(1.0 / sqrt(bc2)), (const float*)nullptr);
   BL_LAUNCH_CHECK("bl_adam_clip_step");
+  return BL_OK;
+}
+
+extern "C" int bl_adam_clip_step_dp(float* param, const float* grad, float* m, float* v, int64_t n, const float* grad_sqnorm,
+                                    const float* batch_total, float clip_norm, float lr, float beta1, float beta2, float eps,
+                                    int32_t step, void* stream) {
+  if (n == 0) return BL_OK;
+  BL_CHECK_ARG(param && grad && m && v && batch_total && (clip_norm <= 0.f || grad_sqnorm) && step >= 1, "bl_adam_clip_step_dp: null pointer or step < 1");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int blocks = (int)fmin(2048.0, (double)((n + 255) / 256));
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (long long)n,
+                     grad_sqnorm, 1.0f, clip_norm, (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)),
+                     batch_total);
+  BL_LAUNCH_CHECK("bl_adam_clip_step_dp");
   return BL_OK;
 }

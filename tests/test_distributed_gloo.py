@@ -78,3 +78,128 @@ def test_partition_by_messages_balances_load():
     assert sorted(i for p in parts for i in p) == list(range(8))
     loads = [sum(msgs[i] for i in p) for p in parts]
     assert max(loads) - min(loads) <= 40
+
+
+def test_balanced_rank_share_is_a_partition_by_messages():
+    from buglab.runtime.distributed import balanced_rank_share
+
+    rng = np.random.default_rng(0)
+    data = [{"id": i, "graph": {"edges": {"a": [0] * int(rng.integers(1, 400)), "b": [0] * int(rng.integers(1, 50))}}} for i in range(203)]
+    shares = [list(balanced_rank_share(iter(data), r, 4)) for r in range(4)]
+    assert sorted(d["id"] for s in shares for d in s) == list(range(203))  # every datapoint exactly once
+    load = [sum(len(d["graph"]["edges"]["a"]) + len(d["graph"]["edges"]["b"]) for d in s) for s in shares]
+    assert max(load) - min(load) < 0.06 * max(load)  # i % world would leave this at ~15 %
+    assert list(balanced_rank_share(iter(data), 0, 1)) == data
+
+
+# ---- the training loop itself under data parallelism (ranks with UNEQUAL numbers of minibatches) ------------------------------
+class _TinyModel:
+    """Host-side stand-in with the AbstractNeuralModel surface ModelTrainer uses; a minibatch = a [B, 3] feature block."""
+
+    def __init__(self, per_rank_batches):
+        self.per_rank_batches = per_rank_batches
+
+    def tensorize_dataset(self, data, parallelize=False):
+        return iter(data)
+
+    def minibatch_iterator(self, tensors, device, size, parallelize=False):
+        for x in tensors:
+            yield {"x": torch.tensor(x, dtype=torch.float32), "has_bug": torch.zeros(len(x), dtype=torch.bool)}, None
+
+    def save(self, path, nn):
+        torch.save({k: v.clone() for k, v in nn.state_dict().items()}, path)
+
+
+class _TinyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(3))
+        self.b = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, *, x, has_bug):
+        return ((x @ self.w + self.b - x.sum(1)) ** 2).mean()
+
+    def reset_metrics(self):
+        pass
+
+    def report_metrics(self):
+        return {}
+
+
+def _cpu_flat_adam():
+    from buglab.runtime.optim import FlatAdam
+
+    class CpuFlatAdam(FlatAdam):
+        """The product's data-parallel protocol with the two device kernels replaced by the same arithmetic in torch."""
+
+        def _apply_update_data_parallel(self):
+            bt = float(self.tail[0])
+            if not bt > 0:
+                return
+            g = self.flat_grad / bt
+            g = g * min(1.0, self.clip / (float(g.norm()) + 1e-6))
+            self.m.mul_(self.beta1).add_(g, alpha=1 - self.beta1)
+            self.v.mul_(self.beta2).addcmul_(g, g, value=1 - self.beta2)
+            bc1, bc2 = 1 - self.beta1 ** self.step_count, 1 - self.beta2 ** self.step_count
+            self.flat_param.addcdiv_(self.m, (self.v.sqrt() / bc2 ** 0.5).add_(self.eps), value=-self.lr_at(self.step_count) / bc1)
+
+    return CpuFlatAdam
+
+
+def _trainer_worker(rank, world, port, batches, out_dir):
+    from tests.conftest import PKG, ROOT  # noqa: F401
+    from buglab.runtime import distributed as D
+    from buglab.runtime.trainer import ModelTrainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D.init_from_env("cpu")
+    torch.manual_seed(100 + rank)  # deliberately different: the trainer must broadcast rank 0's parameters
+    net = _TinyNet()
+    with torch.no_grad():
+        net.w.normal_()
+    model = _TinyModel(batches)
+    Opt = _cpu_flat_adam()
+    opts = []
+
+    def make_opt(params):
+        opts.append(Opt(params, lr=0.05, num_warmup_steps=0))
+        return opts[-1]
+
+    tr = ModelTrainer(model, os.path.join(out_dir, f"m{rank}.pt"), max_num_epochs=2, optimizer_creator=make_opt)
+    tr.neural_module = net
+    tr._rank_share = lambda data: iter(data)  # each rank is handed its own (unequal) share below
+    tr.train(batches[rank], batches[rank][:1], initialize_metadata=False, parallelize=False, device=torch.device("cpu"))
+    torch.save({"w": net.w.detach().clone(), "b": net.b.detach().clone(), "steps": opts[0].step_count}, os.path.join(out_dir, f"p{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_unequal_shards_stay_identical(tmp_path):
+    """ModelTrainer.train over gloo, 2 ranks, rank 0 with 2 minibatches per epoch and rank 1 with 4: both ranks finish every
+    epoch together (no hang), take the same number of optimiser steps, end with IDENTICAL parameters, and those equal a
+    single-process run over the per-step unions of the two ranks' minibatches."""
+    rng = np.random.default_rng(3)
+    mk = lambda n: rng.normal(size=(n, 3)).tolist()
+    batches = [[mk(4), mk(2)], [mk(3), mk(5), mk(2), mk(6)]]
+    mp.spawn(_trainer_worker, args=(2, _free_port(), batches, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
+    assert torch.equal(p0["w"], p1["w"]) and torch.equal(p0["b"], p1["b"])
+    assert p0["steps"] == p1["steps"] == 2 * 4  # 4 real steps per epoch; the idle step that ends an epoch is not counted
+    # single process: step k of an epoch uses the concatenation of what the ranks had at step k
+    torch.manual_seed(100)
+    net = _TinyNet()
+    with torch.no_grad():
+        net.w.normal_()
+    opt = _cpu_flat_adam()(net.parameters(), lr=0.05, num_warmup_steps=0)
+    for _ in range(2):
+        for k in range(4):
+            xs = [torch.tensor(b[k], dtype=torch.float32) for b in batches if k < len(b)]
+            opt.zero_grad()
+            # per-rank mean losses weighted by B_rank / B_total == what the all-reduce of B_rank-scaled gradients computes
+            tot = sum(len(x) for x in xs)
+            loss = sum(net(x=x, has_bug=None) * (len(x) / tot) for x in xs)
+            loss.backward()
+            opt.tail[0] = 1.0
+            opt.step_count += 1
+            opt._apply_update_data_parallel()
+    assert float((net.w.detach() - p0["w"]).abs().max()) < 1e-6 and float((net.b.detach() - p0["b"]).abs().max()) < 1e-6

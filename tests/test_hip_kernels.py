@@ -311,6 +311,35 @@ def test_flat_adam_matches_oracle(ops):
             assert (p.detach().cpu() - ref_p[i]).abs().max() < 2e-6, (step, i)
 
 
+def test_data_parallel_adam_clips_the_mean_gradient_and_norm_is_reproducible(ops):
+    """bl_adam_clip_step_dp gets the SUM over ranks of (graphs x gradient) and the global graph count on the device: it
+    must clip and step exactly like one process with the mean gradient -- in both the clipped (big gradient) and the
+    unclipped (tiny gradient) regime -- and leave everything alone when the count is 0.  The norm it clips by is
+    summed in a fixed order: repeated calls give the same bits (replicas must not drift apart)."""
+    torch.manual_seed(1)
+    n = 100_003
+    p0 = torch.randn(n)
+    for count, gscale in ((8.0, 3.0), (8.0, 1e-4)):
+        mean_grad = torch.randn(n) * gscale
+        ref_p, m, v = {0: p0.clone()}, {0: torch.zeros(n)}, {0: torch.zeros(n)}
+        O.adam_clip_step(ref_p, {0: mean_grad}, m, v, 1, lr=1e-2, clip=0.5, warmup=0)
+        p, summed = _dev(p0.clone()), _dev(mean_grad * count)
+        dm, dv, sq = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+        tail = torch.tensor([count, 1.0, 0.0, 0.0], device="cuda")
+        ops.sqnorm(summed, sq)
+        first = sq.clone()
+        for _ in range(5):
+            ops.sqnorm(summed, sq)
+            assert torch.equal(sq, first)
+        assert abs(float(sq) - float((summed.double() ** 2).sum())) <= 1e-5 * float(sq)
+        ops.adam_clip_step_dp(p, summed, dm, dv, sq, tail, clip=0.5, lr=1e-2, step=1)
+        assert (p.cpu() - ref_p[0]).abs().max() < 2e-6
+        assert (dm.cpu() - m[0]).abs().max() < 1e-6 * max(1.0, gscale)
+        before = p.clone()
+        ops.adam_clip_step_dp(p, summed, dm, dv, sq, torch.zeros(4, device="cuda"), clip=0.5, lr=1e-2, step=2)
+        assert torch.equal(p, before)
+
+
 @pytest.mark.parametrize("Din,Dm,sizes", [(64, 96, [130, 0, 1, 257, 64]), (32, 128, [5, 300]), (128, 256, [129, 128, 127])])
 def test_gemm_rows_bf16x6_is_fp32_accurate(ops, Din, Dm, sizes):
     """fp32-accurate GEMM on the bf16 matrix cores: split hi/mid/lo + six MFMA terms.  The error vs an

@@ -1,0 +1,118 @@
+#!/usr/bin/env python
+"""Data-parallel path on a device: 2 ranks (torchrun) train gnn-mlp on unequal shards of one minibatch and must end
+up exactly where ONE process training on the union minibatch ends up.
+
+    BL_FORCE_DEVICE=0 BL_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+        --master-addr 127.0.0.1 --master-port 29533 tools/dp_check.py
+
+On a single-GPU box both ranks share GPU 0 and the collective runs over gloo (RCCL refuses two ranks on one device);
+the code path is the product's: FlatAdam.step_data_parallel = ONE all-reduce of [B_rank x gradient | B_rank, flag] per
+step, fused clip + Adam reading the global count on the device.
+
+Rank 0 also trains a single process in lockstep (union minibatch while both ranks have data, its own shard once rank
+1 has run dry) and compares, every step: the graph-weighted loss, the reduced gradient / global graph count, and the
+parameters after the update.  Before each step the single process is given the replicas' parameters and moments: the
+routed max of the message-passing layers is discontinuous, so 1e-7 of summation-order difference in the parameters
+flips a near-tie now and then and moves a gradient entry by 1e-3 -- a property of the model (tests/test_hip_parity.py
+handles it the same way), not of the reduction that is being checked here.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "neurips21-self-supervised-bug-detection-and-repair_amd")]
+import torch
+import torch.distributed as dist
+
+from buglab.data.collate import collate_samples, to_device
+from buglab.data.synthetic import make_samples
+from buglab.models import hip_ops
+from buglab.models.gnn import build_gnn_mlp_module
+from buglab.runtime import distributed as D
+from buglab.runtime.optim import FlatAdam
+
+
+def main():
+    rank, world, device = D.init_from_env("cuda")
+    assert world == 2
+    hip_ops.load_library()
+    sizes = (5, 3)
+    samples = make_samples(sum(sizes), seed=7, num_nodes=300, num_messages=1500, num_edge_types=8, vocab_size=2000)
+    lo = sum(sizes[:rank])
+    mine = to_device(collate_samples(samples[lo:lo + sizes[rank]], 8), device)
+    build = lambda: build_gnn_mlp_module(64, 8, 8, vocabulary_size=2000, dropout_rate=0.0).to(device).train()
+    torch.manual_seed(1234 + rank)  # replicas start DIFFERENT; broadcast_parameters must fix that
+    module = build()
+    opt = FlatAdam(module.parameters(), lr=1e-3, num_warmup_steps=0)
+    opt.broadcast_parameters(0)
+
+    def replica_gap(t):
+        both = [torch.zeros_like(t) for _ in range(2)]
+        dist.all_gather(both, t.detach().clone())
+        return float((both[0] - both[1]).abs().max())
+
+    assert replica_gap(opt.flat_param) == 0.0, "broadcast_parameters left the replicas different"
+    # rank 0 also trains ONE process' worth in lockstep: the union minibatch (steps 0-2), then its own shard alone (step 3)
+    if rank == 0:
+        torch.manual_seed(1234)
+        ref = build()
+        ropt = FlatAdam(ref.parameters(), lr=1e-3, num_warmup_steps=0, distributed=False)
+        union = to_device(collate_samples(samples, 8), device)
+        names = [n for n, _ in ref.named_parameters()]
+    report = []
+    for step in range(4):
+        if rank == 0:  # the single process starts every step from the replicas' state (see the docstring)
+            for mine_t, theirs_t in ((ropt.flat_param, opt.flat_param), (ropt.m, opt.m), (ropt.v, opt.v)):
+                mine_t.copy_(theirs_t)
+            ropt.step_count = opt.step_count
+            hip_ops.invalidate_weight_packs()
+        opt.zero_grad()
+        B, my_loss = 0, 0.0
+        if not (rank == 1 and step == 3):  # rank 1 runs out of data one step early
+            loss = module(**mine)
+            loss.backward()
+            B = sizes[rank]
+            my_loss = float(loss.detach())
+        opt.step_data_parallel(B)
+        gaps = (replica_gap(opt.flat_grad), replica_gap(opt.sqnorm), replica_gap(opt.flat_param))
+        assert gaps == (0.0, 0.0, 0.0), f"step {step}: replicas differ in (reduced gradient, its norm, parameters) by {gaps}"
+        assert not (step > 0 and opt.previous_step_was_idle())
+        weighted = torch.tensor([my_loss * B, float(B)], dtype=torch.float64)
+        parts = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(2)]
+        dist.all_gather(parts, weighted.to(device))
+        if rank == 0:
+            dp_loss = float(sum(p[0] for p in parts) / sum(p[1] for p in parts))
+            ropt.zero_grad()
+            l = ref(**(union if step < 3 else mine))
+            l.backward()
+            hip_ops.join_side_stream()
+            total = float(sum(p[1] for p in parts))
+            g_gap = float((ropt.flat_grad - opt.flat_grad / total).abs().max())
+            g_scale = float(ropt.flat_grad.abs().max())
+            ropt.step()
+            torch.cuda.synchronize()
+            gap_per_param = [float((a.detach() - b.detach()).abs().max()) for a, b in zip(ref.parameters(), module.parameters())]
+            worst = max(range(len(names)), key=lambda i: gap_per_param[i])
+            report.append((step, dp_loss, float(l.detach()), g_gap, g_scale, gap_per_param[worst], names[worst]))
+    opt.zero_grad()
+    opt.step_data_parallel(0)  # nobody has data: the idle step that ends an epoch
+    assert opt.previous_step_was_idle() and opt.step_count == 4
+    torch.cuda.synchronize()
+    assert replica_gap(opt.flat_param) == 0.0
+    if rank == 0:
+        print(f"dp_check: 2 ranks x {sizes} graphs on {torch.cuda.get_device_name(0)} over {dist.get_backend()}; replicas bit-identical after "
+              f"every step; against one process on the union minibatch:", flush=True)
+        for step, dp_loss, ref_loss, g_gap, g_scale, p_gap, p_name in report:
+            print(f"  step {step}: loss {dp_loss:.6f} (graph-weighted over ranks) vs {ref_loss:.6f}; max |gradient gap| {g_gap:.2e} "
+                  f"(largest entry {g_scale:.2e}); max |parameter gap| after the step {p_gap:.2e} ({p_name})", flush=True)
+        assert all(abs(r[1] - r[2]) < 2e-5 for r in report), "losses differ"
+        assert all(r[3] < 2e-6 * max(1.0, r[4]) for r in report), "gradients differ"
+        # Adam's first steps move a coordinate by lr * g / (|g| + 1e-8): where |g| ~ 1e-7 the 1e-7 of summation-order noise in g is
+        # visible as a few percent of lr = 1e-3; a wrong count or a lost shard would move every coordinate by ~lr
+        assert all(r[5] < 5e-5 for r in report), "parameters differ"
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
