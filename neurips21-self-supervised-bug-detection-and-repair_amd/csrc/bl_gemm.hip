@@ -30,9 +30,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// clock probe (tuning only): min start / max end of the shader-clock and the 100 MHz wall counters
-__device__ unsigned long long bl_clk_probe[4];
-
 #define BM 128
 #define BN 128
 
@@ -122,7 +119,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
                                                               const int* __restrict__ group_ptr,
                                                               const int* __restrict__ group_w, int G, int M, int N,
                                                               int K, uint32_t drop_key, uint32_t drop_thresh,
-                                                              float drop_scale, float* __restrict__ c, int ldc, int probe) {
+                                                              float drop_scale, float* __restrict__ c, int ldc) {
   constexpr int LDS_MN = BK + 4;        // row stride of an MN-major image
   constexpr int LDS_K = 128;            // row stride of a K-major image
   constexpr int TI = TBM / 64;          // 32-row MFMA tiles per wave (waves are 2 x 2 over TBM x 128)
@@ -137,10 +134,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
   __shared__ int rowidx[3][TBM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (probe == 1 && tid == 0 && blockIdx.x == 7 && blockIdx.y == 0) {
-    bl_clk_probe[0] = (unsigned long long)clock64();
-    bl_clk_probe[1] = (unsigned long long)wall_clock64();
-  }
   int g, row0, nrows;
   if (!find_piece(group_ptr, G, M, TBM, blockIdx.x, g, row0, nrows)) return;
   const int n0 = blockIdx.y * BN;
@@ -260,14 +253,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
 #pragma unroll
     for (int q = 0; q < BK / 8; ++q) {
       if (q + 1 < BK / 8) ROWS_READ_FRAGS(q + 1, (q + 1) & 1)
-      if (probe != 2) {
-        mfma_group<true, TI>(fa[q & 1], fb[q & 1], acc);
-      } else {
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti) asm volatile("" ::"v"(fa[q & 1][ti][0]), "v"(fa[q & 1][ti][3]));
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) asm volatile("" ::"v"(fb[q & 1][tj][0]), "v"(fb[q & 1][tj][3]));
-      }
+      mfma_group<true, TI>(fa[q & 1], fb[q & 1], acc);
     }
     if (NBUF == 1) {
       __syncthreads();
@@ -309,10 +295,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_rows_kernel(ROWS_PARAMS, const
         }
         *reinterpret_cast<float4*>(crow + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
-  }
-  if (probe == 1 && tid == 0 && blockIdx.x == 7 && blockIdx.y == 0) {
-    bl_clk_probe[2] = (unsigned long long)clock64();
-    bl_clk_probe[3] = (unsigned long long)wall_clock64();
   }
 }
 
@@ -469,16 +451,6 @@ static int fill_rows(const bl_rows_t* a, RowsDev& d, int& K, const char* who) {
   return BL_OK;
 }
 
-// Tuning hook (tools/gemm_bench.py only): BL_GEMM_VARIANT selects an alternative tile pipeline.
-static int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* s = getenv("BL_GEMM_VARIANT");
-    v = s ? atoi(s) : 0;
-  }
-  return v;
-}
-
 #define ROWS_CFG_DEFAULT 32, 1, 2
 
 static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t mask_ld, const float* b, int64_t b_group_stride, int32_t ldb, int32_t b_is_nk,
@@ -495,66 +467,28 @@ static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t m
   BL_CHECK_ARG(group_ptr == nullptr || G >= 1, "bl_gemm_rows: G must be >= 1 with group_ptr");
   BL_CHECK_ARG((uint64_t)M * (uint64_t)N < (1ull << 32) || drop.p <= 0.f, "bl_gemm_rows: dropout index space is 32 bit");
   const bl_drop_dev dd = bl_make_drop(drop);
-  static const int tbm = getenv("BL_GEMM_TBM") ? atoi(getenv("BL_GEMM_TBM")) : 128;
-  dim3 grid((M + tbm - 1) / tbm + (group_ptr ? G : 0), (N + BN - 1) / BN);
+  dim3 grid((M + BM - 1) / BM + (group_ptr ? G : 0), (N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
-  static const int probe = getenv("BL_CLK_PROBE") ? atoi(getenv("BL_CLK_PROBE")) : 0;
-  if (probe == 1) {
-    unsigned long long init[4] = {~0ull, ~0ull, 0ull, 0ull};
-    hipMemcpyToSymbol(HIP_SYMBOL(bl_clk_probe), init, sizeof(init));
-  }
-#define ROWS_LAUNCH ROWS_ARGS(d), mask_arg, mask_ld, b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc, probe
-#define ROWS_GO(NK_, ACT_, ...)                                                                                     \
-  {                                                                                                                 \
-    if (tbm == 64)                                                                                                  \
-      hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, 32, 1, 4, false, 64>), grid, dim3(256), 0, st, ROWS_LAUNCH);   \
-    else                                                                                                            \
-      hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, __VA_ARGS__, false, 128>), grid, dim3(256), 0, st, ROWS_LAUNCH); \
-  }
+#define ROWS_LAUNCH ROWS_ARGS(d), mask_arg, mask_ld, b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc
+#define ROWS_GO(NK_, ACT_) hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, ROWS_CFG_DEFAULT, false, BM>), grid, dim3(256), 0, st, ROWS_LAUNCH)
   if (b_is_nk) {
     BL_CHECK_ARG(act == BL_ACT_NONE, "bl_gemm_rows: the transposed-B (input gradient) form takes no activation");
-    if (mask_arg) {
-      if (tbm == 64)
-        hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, 32, 1, 4, true, 64>), grid, dim3(256), 0, st, ROWS_LAUNCH);
-      else
-        hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, 32, 1, 2, true, 128>), grid, dim3(256), 0, st, ROWS_LAUNCH);
-    } else
-    switch (gemm_variant()) {
-      case 1: ROWS_GO(true, BL_ACT_NONE, 32, 1, 4); break;
-      case 2: ROWS_GO(true, BL_ACT_NONE, 32, 2, 2); break;
-      case 3: ROWS_GO(true, BL_ACT_NONE, 64, 1, 2); break;
-      case 4: ROWS_GO(true, BL_ACT_NONE, 16, 2, 4); break;
-      case 5: ROWS_GO(true, BL_ACT_NONE, 16, 2, 2); break;
-      default: ROWS_GO(true, BL_ACT_NONE, ROWS_CFG_DEFAULT); break;
-    }
+    if (mask_arg)
+      hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, ROWS_CFG_DEFAULT, true, BM>), grid, dim3(256), 0, st, ROWS_LAUNCH);
+    else
+      ROWS_GO(true, BL_ACT_NONE);
   } else {
     BL_CHECK_ARG(mask_arg == nullptr, "bl_gemm_rows_masked: only the transposed-B (input gradient) form takes a routing mask");
     switch (act) {
-      case BL_ACT_NONE:
-        switch (gemm_variant()) {
-          case 1: ROWS_GO(false, BL_ACT_NONE, 32, 1, 4); break;
-          case 2: ROWS_GO(false, BL_ACT_NONE, 32, 2, 2); break;
-          case 3: ROWS_GO(false, BL_ACT_NONE, 64, 1, 2); break;
-          case 4: ROWS_GO(false, BL_ACT_NONE, 16, 2, 4); break;
-          case 5: ROWS_GO(false, BL_ACT_NONE, 16, 2, 2); break;
-          default: ROWS_GO(false, BL_ACT_NONE, ROWS_CFG_DEFAULT); break;
-        }
-        break;
-      case BL_ACT_RELU: ROWS_GO(false, BL_ACT_RELU, ROWS_CFG_DEFAULT); break;
-      case BL_ACT_SIGMOID: ROWS_GO(false, BL_ACT_SIGMOID, ROWS_CFG_DEFAULT); break;
-      case BL_ACT_TANH: ROWS_GO(false, BL_ACT_TANH, ROWS_CFG_DEFAULT); break;
-      case BL_ACT_GELU: ROWS_GO(false, BL_ACT_GELU, ROWS_CFG_DEFAULT); break;
+      case BL_ACT_NONE: ROWS_GO(false, BL_ACT_NONE); break;
+      case BL_ACT_RELU: ROWS_GO(false, BL_ACT_RELU); break;
+      case BL_ACT_SIGMOID: ROWS_GO(false, BL_ACT_SIGMOID); break;
+      case BL_ACT_TANH: ROWS_GO(false, BL_ACT_TANH); break;
+      case BL_ACT_GELU: ROWS_GO(false, BL_ACT_GELU); break;
       default: BL_CHECK_ARG(false, "bl_gemm_rows: unknown activation %d", act);
     }
   }
   BL_LAUNCH_CHECK("bl_gemm_rows");
-  if (probe == 1) {
-    hipStreamSynchronize(st);
-    unsigned long long v[4];
-    hipMemcpyFromSymbol(v, HIP_SYMBOL(bl_clk_probe), sizeof(v));
-    const double wall_s = (double)(v[3] - v[1]) / 1e8;
-    fprintf(stderr, "[buglab_hip] clock probe: %.1f us, shader clock %.3f GHz\n", wall_s * 1e6, (double)(v[2] - v[0]) / wall_s / 1e9);
-  }
   return BL_OK;
 }
 
@@ -604,7 +538,6 @@ static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, c
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       ncu = prop.multiProcessorCount;
     resident = per_cu * ncu;
-    if (getenv("BL_DEBUG")) fprintf(stderr, "[buglab_hip] wgrad(masked=%d): %d workgroups/CU x %d CUs\n", g_mask ? 1 : 0, per_cu, ncu);
   }
   const int ntiles_all = ((K + BM - 1) / BM) * ((N + BN - 1) / BN);
   const int extra = (group_ptr ? G : 0) * ntiles_all;  // partial last pieces of the groups
@@ -618,8 +551,7 @@ static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, c
       break;
     }
   }
-  static const int min_chunk = getenv("BL_WGRAD_MIN_CHUNK") ? atoi(getenv("BL_WGRAD_MIN_CHUNK")) : 256;
-  if (kchunk < min_chunk) kchunk = min_chunk;
+  if (kchunk < 256) kchunk = 256;
   const int ntiles_n = (N + BN - 1) / BN;
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ((K + BM - 1) / BM) * ntiles_n);
 #define WGRAD_GO(...)                                                                                                      \
@@ -633,14 +565,7 @@ static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, c
                          g_c, ld_g, g_idx, g_mask, ld_mask, group_ptr, group_w, G, M, N, K, kchunk, gw,                      \
                          (long long)gw_group_stride, ld_gw, ntiles_n);                                                       \
   }
-  switch (gemm_variant()) {
-    case 1: WGRAD_GO(32, 1, 4); break;
-    case 2: WGRAD_GO(32, 2, 2); break;
-    case 3: WGRAD_GO(64, 1, 2); break;
-    case 4: WGRAD_GO(16, 2, 4); break;
-    case 5: WGRAD_GO(16, 2, 2); break;
-    default: WGRAD_GO(32, 1, 2); break;
-  }
+  WGRAD_GO(32, 1, 2)
   BL_LAUNCH_CHECK("bl_gemm_wgrad");
   return BL_OK;
 }

@@ -534,8 +534,7 @@ extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bi
   BL_CHECK_ARG(win_bits == nullptr || (a->nsrc == 1 && a->idx[0] && ld_bits * 32 >= K),
                "bl_gemm_rows_x6: the routed form needs exactly one gathered source and ld_bits >= K / 32");
   dim3 grid((M + XBM - 1) / XBM + (group_ptr ? G : 0), (N + XBN - 1) / XBN);
-  static const int xcd = getenv("BL_XCD_REMAP") ? atoi(getenv("BL_XCD_REMAP")) : 1;
-  static const int pad_lds = getenv("BL_X6_PAD_LDS") ? atoi(getenv("BL_X6_PAD_LDS")) : 0;  // tuning: caps workgroups/CU
+  const int xcd = 1;  // XCD-contiguous tile order (x6_locate)
   const uint4* x0 = reinterpret_cast<const uint4*>(a->xp[0]);
   const uint4* x1 = a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr;
   const uint4* x2 = a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr;
@@ -546,7 +545,7 @@ extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bi
   if (win_bits)
     hipLaunchKernelGGL((gemm_rows_x6_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
   else
-    hipLaunchKernelGGL((gemm_rows_x6_kernel<false>), grid, dim3(256), pad_lds, (hipStream_t)stream, X6_ARGS);
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
   BL_LAUNCH_CHECK("bl_gemm_rows_x6");
   return BL_OK;
 }
@@ -579,7 +578,6 @@ extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       ncu = prop.multiProcessorCount;
     resident = per_cu * ncu;
-    if (getenv("BL_DEBUG")) fprintf(stderr, "[buglab_hip] wgrad_x6: %d workgroups/CU x %d CUs\n", per_cu, ncu);
   }
   const int ntiles_n = (N + XBN - 1) / XBN;
   const int ntiles_all = ((K + XBM - 1) / XBM) * ntiles_n;
@@ -595,7 +593,7 @@ extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t
     }
   }
   if (kchunk < 256) kchunk = 256;
-  static const int xcd = getenv("BL_XCD_REMAP") ? atoi(getenv("BL_XCD_REMAP")) : 1;
+  const int xcd = 1;
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ntiles_all);
   hipLaunchKernelGGL(gemm_wgrad_x6_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const uint4*>(a->xp[0]), a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr,

@@ -21,6 +21,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(fn, args, nprocs=2, timeout=150.0):
+    """mp.spawn with a deadline: a rank stuck in a collective fails the test instead of hanging the suite."""
+    import time
+
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.monotonic() + timeout
+    try:
+        while not ctx.join(timeout=1.0):
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"{fn.__name__}: ranks still running after {timeout:.0f} s")
+    finally:
+        for p in ctx.processes:
+            if p.is_alive():
+                p.kill()
+
+
 def _worker(rank, world, port, sizes, out_path):
     import sys
 
@@ -61,7 +77,7 @@ def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path, sizes):
     from buglab.data.synthetic import make_samples
 
     out = str(tmp_path / "g.pt")
-    mp.spawn(_worker, args=(2, _free_port(), sizes, out), nprocs=2, join=True)
+    _spawn(_worker, (2, _free_port(), sizes, out))
     reduced = torch.load(out)
     cfg = O.OracleConfig(hidden=32, num_layers=4, num_edge_types=4, vocab_size=120)
     samples = make_samples(sum(sizes), seed=11, num_nodes=40, num_messages=160, num_edge_types=4, vocab_size=120, num_candidates=6)
@@ -181,7 +197,7 @@ def test_trainer_two_ranks_unequal_shards_stay_identical(tmp_path):
     rng = np.random.default_rng(3)
     mk = lambda n: rng.normal(size=(n, 3)).tolist()
     batches = [[mk(4), mk(2)], [mk(3), mk(5), mk(2), mk(6)]]
-    mp.spawn(_trainer_worker, args=(2, _free_port(), batches, str(tmp_path)), nprocs=2, join=True)
+    _spawn(_trainer_worker, (2, _free_port(), batches, str(tmp_path)))
     p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
     assert torch.equal(p0["w"], p1["w"]) and torch.equal(p0["b"], p1["b"])
     assert p0["steps"] == p1["steps"] == 2 * 4  # 4 real steps per epoch; the idle step that ends an epoch is not counted
