@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--messages", type=int, default=10000)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--degree", default="uniform", choices=["uniform", "powerlaw"], help="in-degree law (powerlaw = BASELINE config c4, max 512)")
+    ap.add_argument("--serial", action="store_true", help="weight-gradient GEMMs on the main stream everywhere (no side-stream overlap): the run "
+                    "whose rocprofv3 --kernel-trace --stats averages are the exclusive kernel times the roofline quotes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true", help="skip the forward-only passes after the timed training steps (profiling)")
     args = ap.parse_args()
@@ -192,6 +194,8 @@ def main():
     rank, world, device = D.init_from_env("cuda")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     hip_ops.load_library()  # fail loudly if the HIP extension is missing
+    if args.serial:
+        hip_ops.USE_SIDE_STREAM = False
 
     torch.manual_seed(0)  # identical initial weights on every rank
     if seq:
@@ -248,7 +252,7 @@ def main():
 
     def profile_pass(side_stream: bool):
         prev = hip_ops.USE_SIDE_STREAM
-        hip_ops.USE_SIDE_STREAM = side_stream
+        hip_ops.USE_SIDE_STREAM = side_stream and not args.serial
         try:
             step()
             torch.cuda.synchronize()

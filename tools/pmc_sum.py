@@ -1,16 +1,17 @@
 #!/usr/bin/env python
-"""Sum rocprofv3 counter_collection.csv per kernel (tuning helper)."""
+"""Per-kernel average of one rocprofv3 counter:  pmc_sum.py <counter_collection.csv> <COUNTER>  -> JSON on stdout
+{kernel name (up to the argument list): {"per_launch": mean counter value, "launches": n}}."""
 import collections
 import csv
+import json
 import sys
 
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-calls = collections.Counter()
+counter = sys.argv[2]
+acc, n = collections.defaultdict(float), collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"][:48]
-    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-    calls[(k, r["Counter_Name"])] += 1
-pat = sys.argv[2] if len(sys.argv) > 2 else ""
-for k, v in acc.items():
-    if pat in k:
-        print(k, {a: (round(b / calls[(k, a)] / 1e6, 3)) for a, b in v.items()}, "(M per launch)")
+    if r["Counter_Name"] != counter:
+        continue
+    k = r["Kernel_Name"].split("(")[0][:60]
+    acc[k] += float(r["Counter_Value"])
+    n[k] += 1
+json.dump({k: {"per_launch": round(acc[k] / n[k], 1), "launches": n[k]} for k in acc}, sys.stdout, indent=1)
