@@ -119,8 +119,13 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// M2 (+ LayerNorm of M3): segmented max with argmax, one wave per segment
-template <int NV, bool HAS_LN>
+// M2 (+ LayerNorm of M3): segmented max with argmax, one wave per segment.
+// GELU (the message activation in front of the max) is not monotonic -- it falls from 0- at -inf to its minimum at
+// x* = -0.7518 and rises from there -- but it is monotonic on either side of x*: the largest gelu(x) of a segment is
+// gelu(largest x) or gelu(smallest x).  The GELU form therefore tracks both extremes of the RAW messages and evaluates
+// two erf per (segment, channel) instead of one per (message, channel), and it has the winner's raw message at hand for
+// the derivative.  (A -inf message still gives gelu(-inf) = NaN, like the eager op.)
+template <int NV, bool HAS_LN, bool GELU2>
 __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ x, int ldx,
                                                           const int* __restrict__ seg_ptr,
                                                           const int* __restrict__ seg_items, int nseg, int D, int act,
@@ -137,10 +142,10 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
   // long as the whole launch, so it must start at t = 0 instead of wherever its node id falls
   const int seg = seg_order ? seg_order[slot] : slot;
   const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
-  float best[NV];
-  int barg[NV];
+  float best[NV], low[NV];
+  int barg[NV], larg[NV];
 #pragma unroll
-  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; }
+  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; }
 
   for (int base = beg; base < end; base += 64) {
     const int cnt = min(64, end - base);
@@ -165,7 +170,11 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           float t = v[u][j];
-          if (act == BL_ACT_GELU) t = bl_gelu(t);
+          if (GELU2) {
+            if (t < low[j]) { low[j] = t; larg[j] = e[u]; }
+          } else if (act == BL_ACT_GELU) {
+            t = bl_gelu(t);
+          }
           if (BL_MAX_WINS(t, best[j])) { best[j] = t; barg[j] = e[u]; }
         }
     }
@@ -177,10 +186,25 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
         const int d = lane + 64 * j;
         if (d < D) {
           float t = row[d];
-          if (act == BL_ACT_GELU) t = bl_gelu(t);
+          if (GELU2) {
+            if (t < low[j]) { low[j] = t; larg[j] = e; }
+          } else if (act == BL_ACT_GELU) {
+            t = bl_gelu(t);
+          }
           if (BL_MAX_WINS(t, best[j])) { best[j] = t; barg[j] = e; }
         }
       }
+    }
+  }
+  float raw[NV];  // GELU form: the winner's message before the activation (its derivative is needed below)
+  if (GELU2) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      raw[j] = best[j];
+      if (barg[j] < 0) continue;  // empty segment / padding lane
+      const float gh = bl_gelu(best[j]), gl = bl_gelu(low[j]);  // a NaN message sits in best[j] and stays NaN
+      best[j] = gh;
+      if (gl > gh || gl != gl) { best[j] = gl; barg[j] = larg[j]; raw[j] = low[j]; }
     }
   }
   if (winbits) {
@@ -214,7 +238,9 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
       s += best[j];
       if (dact) {  // d act / d pre at the winner, so that backward never needs the [E, D] messages again
         float dv = 1.f;
-        if (act == BL_ACT_GELU) dv = barg[j] >= 0 ? bl_gelu_grad(x[(size_t)barg[j] * ldx + d]) : 0.f;
+        // (the winner's raw message is in a register: re-reading it would be 64 scattered 4-byte loads per wave,
+        // several times the address-coalescing work of the whole message sweep above)
+        if (act == BL_ACT_GELU) dv = barg[j] >= 0 ? bl_gelu_grad(GELU2 ? raw[j] : x[(size_t)barg[j] * ldx + d]) : 0.f;
         dact[(size_t)seg * D + d] = dv;
       }
     }
@@ -616,12 +642,13 @@ extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* se
   BL_CHECK_ARG(!has_ln || (ln_b && ln_out && mean && rstd), "bl_segment_max_fwd: LayerNorm outputs missing");
   dim3 grid((nseg + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+#define SEGMAX_GO(LN_, G2_)                                                                                                  \
+  DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, LN_, G2_>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, \
+                                     act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order))
   if (has_ln) {
-    DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, true>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
-                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order))
+    if (act == BL_ACT_GELU) SEGMAX_GO(true, true) else SEGMAX_GO(true, false)
   } else {
-    DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, false>), grid, block, 0, st, x, ldx, seg_ptr, seg_items,
-                                       nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order))
+    if (act == BL_ACT_GELU) SEGMAX_GO(false, true) else SEGMAX_GO(false, false)
   }
   BL_LAUNCH_CHECK("bl_segment_max_fwd");
   return BL_OK;
