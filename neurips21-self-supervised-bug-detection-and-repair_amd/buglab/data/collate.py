@@ -422,10 +422,10 @@ def upload_packed(blob: np.ndarray, meta: Dict[str, Any], device) -> Dict[str, A
 
     dev = torch.device(device)
     total = int(meta["total"])
-    staging = torch.empty(total, dtype=torch.int32)
-    if dev.type == "cuda":
-        staging = staging.pin_memory()
-    staging.numpy()[:] = blob[:total]
+    # straight into a pinned buffer from the caching host allocator: a pageable temporary first would be a fresh 16 MB
+    # mmap + 4 000 page faults + munmap per minibatch, in a process whose other threads then take the TLB shootdowns
+    staging = torch.empty(total, dtype=torch.int32, pin_memory=dev.type == "cuda")
+    np.copyto(staging.numpy(), blob[:total])
     dblob = staging.to(dev, non_blocking=True)
     out_gd: Dict[str, Any] = {"reference_node_ids": {}, "reference_node_graph_idx": {}}
     out: Dict[str, Any] = {"graph_data": out_gd}

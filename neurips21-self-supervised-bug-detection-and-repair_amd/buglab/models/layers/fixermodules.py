@@ -49,7 +49,8 @@ class _ScorerBase(ModuleWithMetrics):
         targets = targets.long()
         if selected_fixes is not None:
             with torch.no_grad():
-                c = torch.stack([selected_fixes[targets].sum(), torch.tensor(targets.shape[0], device=targets.device)]).long()
+                c = torch.stack([selected_fixes[targets].sum().long(),  # (full: a fill kernel; torch.tensor would be a blocking copy)
+                                 torch.full((), int(targets.shape[0]), dtype=torch.long, device=targets.device)])
                 self._counts = c if self._counts is None else self._counts + c
         return -logprobs[targets]
 

@@ -84,7 +84,8 @@ class LocalizationModule(ModuleWithMetrics):
             pred = torch.where((seg_arg[:, 0] >= 0) & (seg_max[:, 0] >= no_bug_lp), seg_arg[:, 0].long(), arange.long() + C)
             ok = pred == correct
             nb = has_bug.logical_not()
-            stats = torch.stack([torch.tensor(float(B), device=lp.device), ok.sum().float(), nb.sum().float(),
+            # (torch.full is a fill kernel; torch.tensor(B, device=...) would be a blocking copy from pageable memory)
+            stats = torch.stack([torch.full((), float(B), device=lp.device), ok.sum().float(), nb.sum().float(),
                                  (nb & ok).sum().float(), -lp.sum()])
             self._stats = stats if self._stats is None else self._stats + stats
         w_buggy = self._buggy_samples_weight_schedule(self._epoch_idx)

@@ -115,7 +115,8 @@ class FlatAdam:
         B = int(local_graphs)
         self.tail.zero_()
         if B > 0:
-            self.tail[:2] = torch.tensor([float(B), 1.0]).to(self.tail.device, non_blocking=True)
+            self.tail[0].fill_(float(B))  # fill kernels: a host tensor would have to be copied from pageable memory (blocking)
+            self.tail[1].fill_(1.0)
             self.flat_grad.mul_(float(B))
         if self.distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.all_reduce(self._grad_and_tail, op=dist.ReduceOp.SUM, group=self.process_group)

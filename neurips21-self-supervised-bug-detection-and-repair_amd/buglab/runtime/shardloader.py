@@ -215,8 +215,19 @@ def _run_workers(target, model, files: Sequence[str], num_workers: int, extra_ar
     stop = ctx.Event()
     procs = [ctx.Process(target=target, args=(model, files[w::num_workers], *extra_args, out_q, stop), daemon=True)
              for w in range(num_workers)]
-    for p in procs:
-        p.start()
+    # The children inherit the interpreter's heap, including any unreachable-but-not-yet-collected objects of the
+    # trainer (device tensors, HIP events / streams in reference cycles).  A collection inside a child would run their
+    # destructors there, and HIP does not survive a fork: collect here, then freeze what exists so that no child's
+    # collector ever looks at it; the parent thaws its own heap again once the children are running.
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        gc.unfreeze()
     done, n = 0, 0
     try:
         while done < num_workers:
@@ -237,18 +248,29 @@ def _run_workers(target, model, files: Sequence[str], num_workers: int, extra_ar
             if limit is not None and n >= limit:
                 break
     finally:
+        # Shutdown.  Workers see `stop`, finish the item they are putting and exit; the queue is drained meanwhile so that
+        # nobody stays blocked on a full pipe (shared-memory segments of dropped items are unlinked).  A worker that is
+        # still alive after the grace period is killed -- and from then on the pipe may end in a truncated message, on
+        # which a read would block for ever: no reads after a kill.
+        import time as _time
+
         stop.set()
-        try:  # unblock workers stuck on a full queue (dropping their shared-memory segments), then reap them
-            while True:
-                _discard(out_q.get_nowait())
-        except queue_mod.Empty:
-            pass
+        deadline = _time.monotonic() + 5.0
+        while any(p.is_alive() for p in procs) and _time.monotonic() < deadline:
+            try:
+                _discard(out_q.get(timeout=0.05))
+            except queue_mod.Empty:
+                pass
+        stuck = [p for p in procs if p.is_alive()]
+        for p in stuck:
+            p.terminate()
         for p in procs:
             p.join(timeout=2.0)
-            if p.is_alive():
-                p.terminate()
-        try:  # whatever the workers still managed to enqueue while shutting down
-            while True:
-                _discard(out_q.get(timeout=0.05))
-        except queue_mod.Empty:
-            pass
+        if not stuck:
+            try:  # every writer exited on its own: what is left in the pipe are whole messages
+                while True:
+                    _discard(out_q.get(timeout=0.05))
+            except queue_mod.Empty:
+                pass
+        out_q.close()
+        out_q.cancel_join_thread()

@@ -23,6 +23,19 @@ from buglab.runtime.optim import FlatAdam
 LOGGER = logging.getLogger(__name__)
 
 
+def _record_stream(obj, stream) -> None:
+    """Every device tensor reachable from a (nested) minibatch is marked as in use on `stream`."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
 def _prefetch(iterator, depth: int = 2):
     """Runs `iterator` in a background thread, `depth` items ahead; exceptions are re-raised in the consumer.
     Closing the returned generator (or dropping it) stops the thread and closes `iterator`, so that a consumer
@@ -163,16 +176,53 @@ class ModelTrainer:
             rank, world = self._world()
             limit = getattr(data, "limit_num_yielded_elements", None)
 
+            self.last_input_timing = timing = {"loader_wait_s": 0.0, "upload_s": 0.0, "minibatches": 0}
+            upload_stream = None
+            if torch.device(device).type == "cuda":
+                # one stream for the trainer's lifetime: a stream object that dies would have its destructor run in
+                # the loader processes forked later (they inherit the interpreter's garbage), and HIP does not survive a fork
+                if getattr(self, "_upload_stream", None) is None:
+                    self._upload_stream = torch.cuda.Stream(device)
+                upload_stream = self._upload_stream
+
             def received():  # runs in a prefetch thread: the staging copy + pinned H2D copy overlap the trainer
                 seen = 0     # thread's kernel launches; the int32 blob comes through shared memory, not the pipe
-                for item in collated_minibatches_parallel(self.model, data.shard_files(), workers, self._minibatch_size, rank, world,
-                                                          packed=True):
-                    yield receive_packed(item, device)
-                    seen += int(item[2]["num_graphs"]) * world
-                    if limit is not None and seen >= limit:
-                        break
+                source = collated_minibatches_parallel(self.model, data.shard_files(), workers, self._minibatch_size, rank, world, packed=True)
+                try:
+                    while True:
+                        t0 = time.perf_counter()
+                        item = next(source, None)
+                        t1 = time.perf_counter()
+                        if item is None:
+                            break
+                        if upload_stream is not None:
+                            # the copy runs on its own stream (its own allocator pool): it overlaps the step that is running instead
+                            # of queueing behind it; the trainer's stream waits for `ready` before the first kernel of the step
+                            with torch.cuda.stream(upload_stream):
+                                mb = receive_packed(item, device)
+                                ready = torch.cuda.Event()
+                                ready.record(upload_stream)
+                            mb["_upload_ready"] = ready
+                        else:
+                            mb = receive_packed(item, device)
+                        timing["loader_wait_s"] += t1 - t0
+                        timing["upload_s"] += time.perf_counter() - t1
+                        timing["minibatches"] += 1
+                        yield mb
+                        seen += int(item[2]["num_graphs"]) * world
+                        if limit is not None and seen >= limit:
+                            break
+                finally:
+                    source.close()
 
-            yield from _prefetch(received(), depth=3)
+            for mb in _prefetch(received(), depth=3):
+                ready = mb.pop("_upload_ready", None)
+                if ready is not None:
+                    torch.cuda.current_stream().wait_event(ready)
+                    # the blob was allocated on the upload stream and is used on this one: its memory may only be recycled
+                    # once this stream is done with it
+                    _record_stream(mb, torch.cuda.current_stream())
+                yield mb
             return
         tensors = self.model.tensorize_dataset(self._rank_share(data), parallelize=parallelize)
         for mb, _ in self.model.minibatch_iterator(tensors, device, self._minibatch_size, parallelize=parallelize):
@@ -196,9 +246,16 @@ class ModelTrainer:
         step, num_graphs, t0 = 0, 0, time.time()
         _, world = self._world()
         fused_dp = world > 1 and hasattr(optimizer, "step_data_parallel")
+        waited, first_wait = 0.0, None  # time this thread spent blocked on the input pipeline (first minibatch apart)
         try:
             while True:
+                tw = time.perf_counter()
                 mb = next(it, None)
+                tw = time.perf_counter() - tw
+                if first_wait is None:
+                    first_wait = tw
+                else:
+                    waited += tw
                 if fused_dp:
                     # Ranks stay in lock step through the gradient all-reduce alone: a rank whose loader is exhausted
                     # keeps stepping with an empty contribution until the tail of the all-reduce says that nobody had
@@ -229,6 +286,9 @@ class ModelTrainer:
         metrics = nn.report_metrics()
         elapsed = time.time() - t0
         LOGGER.info("Epoch %s: %s steps, %.1f graphs/s (this rank). Train metrics: %s", epoch, step, num_graphs / max(elapsed, 1e-9), metrics)
+        # where the epoch went on the host side: a large share of `input wait` means the loaders, not the device, set the pace
+        self.last_epoch_timing = {"elapsed_s": elapsed, "steps": step, "first_minibatch_s": first_wait or 0.0, "input_wait_s": waited}
+        LOGGER.info("Epoch %s timing: first minibatch after %.2f s, %.2f s of %.2f s blocked on input", epoch, first_wait or 0.0, waited, elapsed)
         return metrics
 
     def _run_validation(self, validation_tensors, epoch, best_target_metric, device, parallelize, show_progress_bar):

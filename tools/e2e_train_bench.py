@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--minibatch-size", type=int, default=64)
     ap.add_argument("--dry-run", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the trainer thread during the reported epoch")
     a = ap.parse_args()
     os.environ["BUGLAB_LOADER_WORKERS"] = str(a.workers)
 
@@ -63,19 +64,96 @@ def main():
     from buglab.runtime.trainer import ModelTrainer
 
     hip_ops.load_library()
+    if os.environ.get("SWITCH_INTERVAL"):
+        sys.setswitchinterval(float(os.environ["SWITCH_INTERVAL"]))
     device = torch.device("cuda", 0)
     trainer = ModelTrainer(model, Path(d) / "m.pkl.gz", minibatch_size=a.minibatch_size, clip_gradient_norm=0.5)
     trainer.neural_module = model.build_neural_module().to(device)
     trainer._use_multiprocessing = True
     opt = FlatAdam(trainer.neural_module.parameters())
+    # the device-only time of one step on THIS data: a resident minibatch, stepped repeatedly (what the epoch loop could reach)
+    it = iter(trainer._iter_minibatches(ds, device, True))
+    mb = next(it)
+    it.close()
+    nn = trainer.neural_module.train()
+    for i in range(13):
+        if i == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        opt.zero_grad()
+        nn(**mb).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    dev_ms = (time.perf_counter() - t0) / 10 * 1e3
+    gd = mb["graph_data"]
+    print(f"resident minibatch: {gd['num_graphs']} graphs, {gd['num_nodes']} nodes, {gd['num_messages']} messages, "
+          f"{len(gd['type_ptr_host']) - 1} edge types: {dev_ms:.1f} ms per step = {gd['num_graphs'] / dev_ms * 1e3:.0f} graphs/s on the device alone")
+    # one device event + one host stamp per step (at zero_grad): shows whether the device queue or the host sets the pace
+    marks = []
+    zero_grad = opt.zero_grad
+
+    def marked_zero_grad():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append((time.perf_counter(), ev))
+        zero_grad()
+
+    opt.zero_grad = marked_zero_grad
+    if os.environ.get("PROBE_UPLOAD"):
+        from buglab.data import collate as C
+
+        inner = C.upload_packed
+        probe = {"pin_alloc": 0.0, "memcpy": 0.0, "rest": 0.0, "n": 0}
+
+        def timed_upload(blob, meta, device):
+            t0 = time.perf_counter()
+            total = int(meta["total"])
+            st = torch.empty(total, dtype=torch.int32, pin_memory=True)
+            t1 = time.perf_counter()
+            st.numpy()[:] = blob[:total]
+            t2 = time.perf_counter()
+            out = inner(st.numpy(), meta, device)
+            t3 = time.perf_counter()
+            probe["pin_alloc"] += t1 - t0; probe["memcpy"] += t2 - t1; probe["rest"] += t3 - t2; probe["n"] += 1
+            return out
+
+        import buglab.runtime.shardloader as SL
+        C.upload_packed = timed_upload
     for epoch in range(2):  # epoch 0 warms up (first-touch allocations, library load); epoch 1 is reported
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        metrics = trainer._run_training(ds, epoch, device, opt, None, True)
+        if a.profile and epoch == 1:
+            import cProfile
+            import pstats
+
+            prof = cProfile.Profile()
+            metrics = prof.runcall(trainer._run_training, ds, epoch, device, opt, None, True)
+            pstats.Stats(prof).sort_stats("tottime").print_stats(22)
+        else:
+            metrics = trainer._run_training(ds, epoch, device, opt, None, True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"epoch {epoch}: {n_graphs} graphs of ~{a.nodes * 3 // 2} nodes in {dt:.2f} s = {n_graphs / dt:.0f} graphs/s end to end "
               f"({a.workers} loader processes, {os.cpu_count()} host threads); loss {metrics.get('Loss', metrics)}")
+        ms = torch.cuda.memory_stats()
+        print(f"         allocator: {ms['num_device_alloc']} device allocations, {ms['num_device_free']} frees, {ms['num_alloc_retries']} retries so far; "
+              f"reserved {ms['reserved_bytes.all.current'] / 2**30:.1f} GiB, peak allocated {ms['allocated_bytes.all.peak'] / 2**30:.1f} GiB")
+        if len(marks) > 20:
+            host = np.diff([m[0] for m in marks[10:]]) * 1e3
+            devt = np.array([marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(10, len(marks) - 1)])
+            lag = [(marks[i][1].elapsed_time(marks[-1][1])) for i in (10,)]
+            print(f"         per step: host interval median {np.median(host):.1f} ms (p90 {np.percentile(host, 90):.1f}), device interval median {np.median(devt):.1f} ms "
+                  f"(p90 {np.percentile(devt, 90):.1f}); sum host {host.sum():.0f} ms, sum device {devt.sum():.0f} ms")
+        marks.clear()
+        print(f"         prefetch thread: {trainer.last_input_timing}")
+        if os.environ.get("PROBE_UPLOAD"):
+            print(f"         upload probe (ms per minibatch): " + str({k: round(v / max(probe['n'], 1) * 1e3, 2) for k, v in probe.items() if k != "n"}))
+            for k in probe:
+                probe[k] = 0
+        t = trainer.last_epoch_timing
+        steady = (n_graphs - a.minibatch_size) / max(dt - t["first_minibatch_s"], 1e-9)
+        print(f"         first minibatch after {t['first_minibatch_s']:.2f} s (loader start-up); afterwards {steady:.0f} graphs/s, "
+              f"{t['input_wait_s']:.2f} s of {dt - t['first_minibatch_s']:.2f} s blocked on input, {t['steps']} steps")
 
 
 if __name__ == "__main__":
