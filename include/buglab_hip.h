@@ -34,6 +34,16 @@ enum { BL_ACT_NONE = 0, BL_ACT_RELU = 1, BL_ACT_SIGMOID = 2, BL_ACT_TANH = 3, BL
 
 const char* bl_last_error(void);
 int bl_version(void);
+/* Deterministic-gradient mode (also switched on by BL_DETERMINISTIC=1 in the environment at first use).  The kernels that
+ * add into one address from several workgroups -- the split-K weight gradients (bl_gemm_wgrad*, bl_gemm_wgrad_routed_x6),
+ * the column sums of bl_layernorm_bwd / bl_act_bwd / bl_rowdot_bwd -- then flush in a fixed workgroup order (a turn
+ * counter per output tile), bl_scatter_add_rows and bl_embed_subtoken_max_bwd walk their rows serially per column: every
+ * gradient is bit-identical from run to run, at a cost (the flushes serialise).  bl_embed_subtoken_max_bwd_sorted is
+ * reproducible when every token is ONE chunk (the collator does that in this mode).  Not covered: the relational-attention
+ * bias gradients (bl_rel_attn_bias_bwd, bl_rel_value_bias_bwd).  The reference has no counterpart (torch's index_add /
+ * scatter backward are atomic too); this exists so that a parity failure can be reproduced. */
+void bl_set_deterministic(int32_t on);
+int32_t bl_get_deterministic(void);
 
 /* Rows of a (virtually) concatenated, gathered operand:
  *   row r = [ x[0][idx[0][r], 0:width[0]] ; x[1][idx[1][r], 0:width[1]] ; ... ]   (nsrc <= 3)

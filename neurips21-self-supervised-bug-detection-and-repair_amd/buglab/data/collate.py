@@ -100,6 +100,14 @@ HUB_DEGREE = 64  # nodes with more incident messages than this are processed fir
 TOKEN_CHUNK = 256  # occurrences of one token summed by one wave of the embedding-gradient kernel
 
 
+def _token_chunk() -> int:
+    """BL_DETERMINISTIC=1: one chunk per token, so that every embedding row receives exactly one add (no order to fix)."""
+    import os
+
+    return (1 << 30) if os.environ.get("BL_DETERMINISTIC", "0") not in ("", "0") else TOKEN_CHUNK
+
+
+
 def token_occurrence_chunks(token_ids: np.ndarray, token_lens: np.ndarray, chunk: int = TOKEN_CHUNK):
     """Token-sorted list of the valid subtoken slots, cut in chunks of one token each.
 
@@ -136,7 +144,7 @@ def _collate_graph_arrays_numpy(graphs, num_edge_types: int, node_off: np.ndarra
         token_ids[o : o + g.num_nodes, : g.token_ids.shape[1]] = g.token_ids
         token_lens[o : o + g.num_nodes] = g.token_lens
 
-    tok_occ, tok_chunk_ptr, tok_chunk_id = token_occurrence_chunks(token_ids, token_lens)
+    tok_occ, tok_chunk_ptr, tok_chunk_id = token_occurrence_chunks(token_ids, token_lens, _token_chunk())
 
     # all messages of the batch at once: per graph one concatenation (edge lists in type order), then two stable
     # counting sorts -- by target, then by type -- give "type-major, target-sorted inside a type" with ties in
@@ -190,7 +198,7 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
     from buglab.data import native
 
     if native.available() and os.environ.get("BUGLAB_NATIVE_COLLATE", "1") != "0":
-        arr = native.collate_graph_arrays(graphs, num_edge_types, HUB_DEGREE, TOKEN_CHUNK)  # one GIL-free native call
+        arr = native.collate_graph_arrays(graphs, num_edge_types, HUB_DEGREE, _token_chunk())  # one GIL-free native call
     else:
         arr = _collate_graph_arrays_numpy(graphs, num_edge_types, node_off, N)
     token_ids, token_lens, node_order = arr["token_ids"], arr["token_lens"], arr["node_order"]

@@ -48,6 +48,8 @@ class bl_mp_layer_t(Structure):
 
 _SIGNATURES = {
     "bl_version": ([], ctypes.c_int),
+    "bl_set_deterministic": ([c_int32], None),
+    "bl_get_deterministic": ([], c_int32),
     "bl_last_error": ([], ctypes.c_char_p),
     "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
@@ -768,6 +770,18 @@ class _MpLayer(torch.autograd.Function):
 FUSED_LAYER = os.environ.get("BL_FUSED_LAYER", "1") != "0"
 _weights_epoch = 0          # bumped by whoever changes parameters behind autograd's back (FlatAdam's kernel)
 _pack_cache = {}            # id(W) -> (weakref(W), version, epoch, packed [T, *] forward form, packed backward form | None)
+
+
+def set_deterministic(on: bool = True) -> None:
+    """Bit-reproducible gradients (ordered flushes instead of free-running atomics; slower).  BL_DETERMINISTIC=1 in the
+    environment does the same for this process AND the loader processes (the collator must keep every token's
+    occurrences in one chunk); this call only reaches the collators of this process."""
+    load_library().bl_set_deterministic(1 if on else 0)
+    os.environ["BL_DETERMINISTIC"] = "1" if on else "0"
+
+
+def deterministic() -> bool:
+    return bool(load_library().bl_get_deterministic())
 
 
 def invalidate_weight_packs():

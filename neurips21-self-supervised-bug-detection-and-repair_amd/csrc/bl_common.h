@@ -10,6 +10,10 @@
 
 // ---- error plumbing ---------------------------------------------------------------------------
 void bl_set_error(const char* fmt, ...);
+extern "C" int32_t bl_get_deterministic(void);
+// n zeroed turn counters for one launch on `stream`, or nullptr when the deterministic mode is off (bl_core.hip)
+unsigned* bl_order_counters(int n, void* stream);
+
 #define BL_CHECK_ARG(cond, ...)   \
   do {                            \
     if (!(cond)) {                \
@@ -110,3 +114,23 @@ __device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& m, uint16
   const float r2 = r1 - bf2f(m);  // exact
   l = f2bf_rne(r2);
 }
+
+// Ordered flush (deterministic mode): workgroup number `turn` of a counter's sequence may add only after workgroup
+// turn - 1 has left.  Workgroups are dispatched in increasing linear id and the callers number them so that a lower turn
+// never has a higher id within its XCD's range, so the one being waited for is always running or already done; the spin
+// is bounded anyway -- a wrong assumption must cost reproducibility, not hang the device.
+__device__ __forceinline__ void bl_ordered_enter(unsigned* ctr, unsigned turn) {
+  if (ctr == nullptr) return;
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != turn && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(16);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void bl_ordered_leave(unsigned* ctr, unsigned turn) {
+  if (ctr == nullptr) return;
+  __threadfence();  // this workgroup's atomics have reached L2 before the next one is let in
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(ctr, turn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+

@@ -14,3 +14,37 @@ void bl_set_error(const char* fmt, ...) {
 
 extern "C" const char* bl_last_error(void) { return g_err; }
 extern "C" int bl_version(void) { return 1; }
+
+// ---- deterministic-gradient mode ----------------------------------------------------------------------------------
+// Kernels that accumulate into one address from several workgroups (split-K weight gradients, column sums) flush with
+// fp32 atomics: the sum depends on the order the workgroups happen to arrive in.  In deterministic mode every such
+// flush takes its TURN -- a counter per output tile, workgroup t adds after workgroup t-1 (bl_ordered_enter/leave in
+// bl_common.h) -- so the order, and with it every bit of the gradient, is the same in every run.  The counters come
+// from a per-device ring that is zeroed on the launch stream right before the kernel.
+#include <stdlib.h>
+
+static int g_deterministic = -1;
+
+extern "C" void bl_set_deterministic(int32_t on) { g_deterministic = on ? 1 : 0; }
+extern "C" int32_t bl_get_deterministic(void) {
+  if (g_deterministic < 0) {
+    const char* e = getenv("BL_DETERMINISTIC");
+    g_deterministic = (e && e[0] && e[0] != '0') ? 1 : 0;
+  }
+  return g_deterministic;
+}
+
+unsigned* bl_order_counters(int n, void* stream) {
+  if (!bl_get_deterministic() || n <= 0) return nullptr;
+  constexpr int RING = 1 << 20, MAXDEV = 16;
+  static unsigned* ring[MAXDEV] = {nullptr};
+  static int pos[MAXDEV] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV || n > RING) return nullptr;
+  if (ring[dev] == nullptr && hipMalloc((void**)&ring[dev], (size_t)RING * sizeof(unsigned)) != hipSuccess) return nullptr;
+  if (pos[dev] + n > RING) pos[dev] = 0;  // thousands of launches later: whatever used the start of the ring is long done
+  unsigned* out = ring[dev] + pos[dev];
+  pos[dev] += (n + 31) / 32 * 32;
+  if (hipMemsetAsync(out, 0, (size_t)n * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return nullptr;
+  return out;
+}

@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, cons
                                                                const int* __restrict__ group_ptr,
                                                                const int* __restrict__ group_w, int G, int M, int N,
                                                                int K, int kchunk, float* __restrict__ gw_base,
-                                                               long long strideW, int ldw, int ntiles_n) {
+                                                               long long strideW, int ldw, int ntiles_n,
+                                                               unsigned* __restrict__ order_ctr) {
   constexpr int LDS_K = 128;
   constexpr int T_SZ = BK * LDS_K;
   constexpr int NLD = BK / 8;
@@ -410,6 +411,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, cons
   }
 
   float* __restrict__ gw = gw_base + (long long)wsel * strideW;
+  // deterministic mode: the row chunks of one (group, tile) add in chunk order
+  unsigned* ctr = order_ctr ? order_ctr + (size_t)g * gridDim.y + blockIdx.y : nullptr;
+  const unsigned turn = (unsigned)((e0 - (group_ptr ? group_ptr[g] : 0)) / kchunk);
+  bl_ordered_enter(ctr, turn);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_wgrad_kernel(ROWS_PARAMS, cons
         if (f < K) unsafeAtomicAdd(&gw[(size_t)f * ldw + n], acc[ti][tj][r]);
       }
     }
+  bl_ordered_leave(ctr, turn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -554,16 +560,18 @@ static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, c
   if (kchunk < 256) kchunk = 256;
   const int ntiles_n = (N + BN - 1) / BN;
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ((K + BM - 1) / BM) * ntiles_n);
+  // (groups that share a weight slice through group_w have no defined order among themselves: not ordered)
+  unsigned* order_ctr = group_w ? nullptr : bl_order_counters((group_ptr ? G : 1) * (int)grid.y, stream);
 #define WGRAD_GO(...)                                                                                                      \
   {                                                                                                                        \
     if (g_mask)                                                                                                            \
       hipLaunchKernelGGL((gemm_wgrad_kernel<__VA_ARGS__, true>), grid, dim3(256), 0, (hipStream_t)stream, ROWS_ARGS(d), g_c, \
                          ld_g, g_idx, g_mask, ld_mask, group_ptr, group_w, G, M, N, K, kchunk, gw,                           \
-                         (long long)gw_group_stride, ld_gw, ntiles_n);                                                       \
+                         (long long)gw_group_stride, ld_gw, ntiles_n, order_ctr);                                            \
     else                                                                                                                   \
       hipLaunchKernelGGL((gemm_wgrad_kernel<__VA_ARGS__, false>), grid, dim3(256), 0, (hipStream_t)stream, ROWS_ARGS(d),   \
                          g_c, ld_g, g_idx, g_mask, ld_mask, group_ptr, group_w, G, M, N, K, kchunk, gw,                      \
-                         (long long)gw_group_stride, ld_gw, ntiles_n);                                                       \
+                         (long long)gw_group_stride, ld_gw, ntiles_n, order_ctr);                                            \
   }
   WGRAD_GO(32, 1, 2)
   BL_LAUNCH_CHECK("bl_gemm_wgrad");

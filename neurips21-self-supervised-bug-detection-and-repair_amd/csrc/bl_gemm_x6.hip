@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
     int koff1, int koff2, int nsrc, const uint4* __restrict__ gp, const int* __restrict__ g_idx,
     const uint32_t* __restrict__ win_bits, int ld_bits, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G,
-    int M, int N, int K, int kchunk, float* __restrict__ gw_base, long long strideW, int ldw, int ntiles_n, int xcd_remap) {
+    int M, int N, int K, int kchunk, float* __restrict__ gw_base, long long strideW, int ldw, int ntiles_n, int xcd_remap,
+    unsigned* __restrict__ order_ctr) {
   __shared__ __attribute__((aligned(16))) short As[WOPER];
   __shared__ __attribute__((aligned(16))) short Bs[WOPER];
 
@@ -463,6 +464,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
   }
 
   float* __restrict__ gw = gw_base + (long long)wsel * strideW;
+  // deterministic mode (launched without the XCD remap): the message chunks of one (group, tile) add in chunk order
+  unsigned* ctr = order_ctr ? order_ctr + (size_t)g * gridDim.y + tile_y : nullptr;
+  const unsigned turn = (unsigned)((e0 - (group_ptr ? group_ptr[g] : 0)) / kchunk);
+  bl_ordered_enter(ctr, turn);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
         if (f < K) unsafeAtomicAdd(&gw[(size_t)f * ldw + n], acc[ti][tj][r]);
       }
     }
+  bl_ordered_leave(ctr, turn);
 }
 
 // ================================================================================================
@@ -593,15 +599,16 @@ extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t
     }
   }
   if (kchunk < 256) kchunk = 256;
-  const int xcd = 1;
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ntiles_all);
+  unsigned* order_ctr = group_w ? nullptr : bl_order_counters((group_ptr ? G : 1) * ntiles_all, stream);
+  const int xcd = order_ctr ? 0 : 1;  // ordered flushes want "lower chunk = lower workgroup id"
   hipLaunchKernelGGL(gemm_wgrad_x6_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const uint4*>(a->xp[0]), a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr,
                      a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr, a->idx[0],
                      a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],
                      a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc,
                      reinterpret_cast<const uint4*>(g_node_packed), g_idx, win_bits, ld_bits, group_ptr, group_w, G, M, N, K,
-                     kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n, xcd);
+                     kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n, xcd, order_ctr);
   BL_LAUNCH_CHECK("bl_gemm_wgrad_routed_x6");
   return BL_OK;
 }

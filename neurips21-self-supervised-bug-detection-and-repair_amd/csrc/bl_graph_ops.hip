@@ -63,6 +63,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   }
 }
 
+// deterministic mode: thread h owns column h and walks the nodes in order (slow; the token-sorted kernel is the fast path)
+__global__ __launch_bounds__(256) void embed_bwd_serial_kernel(const float* __restrict__ g_out, int ld_g, const int* __restrict__ ids,
+                                                               const int8_t* __restrict__ argsub, int N, int S, int H, bl_drop_dev drop,
+                                                               float* __restrict__ g_table) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  for (int n = 0; n < N; ++n) {
+    float g = g_out[(size_t)n * ld_g + h];
+    if (drop.thresh) g = bl_keep(drop, (uint32_t)n * (uint32_t)H + (uint32_t)h) ? g * drop.scale : 0.f;
+    if (g != 0.f) g_table[(size_t)ids[(size_t)n * S + argsub[(size_t)n * H + h]] * H + h] += g;
+  }
+}
+
 // The same gradient from a token-sorted occurrence list (built by the collator): one wave per chunk of
 // <= 256 occurrences (node, slot) of ONE token, channel sums kept in registers, one atomic per channel
 // and chunk.  Subtoken frequencies are Zipfian: with one atomic per (node, channel) the hottest table
@@ -304,7 +317,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ g_x, float* __restrict__ g_gamma,
                                                             float* __restrict__ g_beta,
                                                             const float* __restrict__ post_scale,
-                                                            uint32_t* __restrict__ g_x_packed) {
+                                                            uint32_t* __restrict__ g_x_packed,
+                                                            unsigned* __restrict__ order_ctr) {
   __shared__ float red[2][4][128 * NP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nw = gridDim.x * 4;
@@ -380,10 +394,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     red[1][w][2 * lane + 128 * j] = db[j].x; red[1][w][2 * lane + 128 * j + 1] = db[j].y;
   }
   __syncthreads();
+  bl_ordered_enter(order_ctr, blockIdx.x);  // deterministic mode: blocks flush in block order
   for (int d = threadIdx.x; d < D; d += 256) {
     unsafeAtomicAdd(&g_gamma[d], red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
     unsafeAtomicAdd(&g_beta[d], red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
   }
+  bl_ordered_leave(order_ctr, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,7 +412,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #define ACT_BWD_MAX_BLOCKS 512
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const float* __restrict__ y, int nrows, int N,
                                                       int ld, int act, bl_drop_dev drop, float* g_z,
-                                                      float* __restrict__ g_bias, int tpr_log2) {
+                                                      float* __restrict__ g_bias, int tpr_log2,
+                                                      unsigned* __restrict__ order_ctr) {
   __shared__ float4 red[256];
   const int tpr = 1 << tpr_log2;
   const int tx = threadIdx.x & (tpr - 1), ty = threadIdx.x >> tpr_log2;
@@ -441,6 +458,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const fl
   if (g_bias) {
     red[threadIdx.x] = acc;
     __syncthreads();
+    unsigned* ctr = order_ctr ? order_ctr + blockIdx.y : nullptr;  // deterministic mode: row blocks of a column block in order
+    bl_ordered_enter(ctr, blockIdx.x);
     if (ty == 0 && c < N) {
       float4 t = red[tx];
       for (int k = 1; k < rows_per_iter; ++k) {
@@ -452,6 +471,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const fl
       unsafeAtomicAdd(&g_bias[c + 2], t.z);
       unsafeAtomicAdd(&g_bias[c + 3], t.w);
     }
+    bl_ordered_leave(ctr, blockIdx.x);
   }
 }
 
@@ -610,8 +630,12 @@ extern "C" int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const
   if (N == 0) return BL_OK;
   BL_CHECK_ARG(g_out && ids && argsub && g_table && V > 0, "bl_embed_subtoken_max_bwd: null pointer");
   const long long total = (long long)N * H;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out,
-                     ld_g, ids, argsub, N, S, H, bl_make_drop(drop), g_table);
+  if (bl_get_deterministic())
+    hipLaunchKernelGGL(embed_bwd_serial_kernel, dim3((H + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_out, ld_g, ids, argsub, N,
+                       S, H, bl_make_drop(drop), g_table);
+  else
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out,
+                       ld_g, ids, argsub, N, S, H, bl_make_drop(drop), g_table);
   BL_LAUNCH_CHECK("bl_embed_subtoken_max_bwd");
   return BL_OK;
 }
@@ -678,7 +702,7 @@ extern "C" int bl_layernorm_bwd(const float* g_y, const float* x, const float* m
   const int blocks = min((nrows + 4 * LN_RIF - 1) / (4 * LN_RIF), 512);  // also bounds the same-address atomics on g_gamma / g_beta
   hipStream_t st = (hipStream_t)stream;
   uint32_t* gp = reinterpret_cast<uint32_t*>(g_x_packed);
-#define LN_BWD_GO(NP_) hipLaunchKernelGGL((layernorm_bwd_kernel<NP_>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd, gamma, nrows, D, g_x, g_gamma, g_beta, post_scale, gp)
+#define LN_BWD_GO(NP_) hipLaunchKernelGGL((layernorm_bwd_kernel<NP_>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd, gamma, nrows, D, g_x, g_gamma, g_beta, post_scale, gp, bl_order_counters(1, stream))
   if (D <= 128) LN_BWD_GO(1);
   else if (D <= 256) LN_BWD_GO(2);
   else LN_BWD_GO(4);
@@ -697,7 +721,7 @@ extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32
   const int gy = (N / 4 + (1 << tpr_log2) - 1) >> tpr_log2;
   dim3 grid(min((nrows + ACT_BWD_ROWS - 1) / ACT_BWD_ROWS, max(1, ACT_BWD_MAX_BLOCKS / gy)), gy);
   hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g_y, y, nrows, N, ld, act,
-                     bl_make_drop(drop), g_z, g_bias, tpr_log2);
+                     bl_make_drop(drop), g_z, g_bias, tpr_log2, g_bias ? bl_order_counters(gy, stream) : nullptr);
   BL_LAUNCH_CHECK("bl_act_bwd");
   return BL_OK;
 }

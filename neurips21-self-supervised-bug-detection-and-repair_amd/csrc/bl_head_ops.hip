@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ g_y, const float* __restrict__ x,
                                                          int ldx, const float* __restrict__ w, int R, int H,
                                                          float* __restrict__ g_x, int ld_gx, float* __restrict__ g_w,
-                                                         float* __restrict__ g_b) {
+                                                         float* __restrict__ g_b, unsigned* __restrict__ order_ctr) {
   // thread t owns column h = t (+ blockDim multiples); rows are split over blocks
   const int rows_per_block = (R + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  bl_ordered_enter(order_ctr, blockIdx.x);  // deterministic mode: blocks add their column sums in block order
   for (int h = threadIdx.x; h < H; h += blockDim.x) {
     const float wh = w[h];
     float acc = 0.f;
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     for (int r = r0; r < r1; ++r) acc += g_y[r];
     unsafeAtomicAdd(g_b, acc);
   }
+  bl_ordered_leave(order_ctr, blockIdx.x);
 }
 
 // out[idx[r], :] += src[r, col_off : col_off + width]
@@ -93,6 +95,15 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
   if (t >= R * width) return;
   const int r = (int)(t / width), c = (int)(t % width);
   unsafeAtomicAdd(&out[(size_t)idx[r] * ld_out + c], src[(size_t)r * ld_src + col_off + c]);
+}
+
+// deterministic mode: thread c owns column c and walks the rows in order
+__global__ __launch_bounds__(256) void scatter_add_rows_serial_kernel(const float* __restrict__ src, int ld_src, int col_off, int width,
+                                                                      const int* __restrict__ idx, long long R, float* __restrict__ out,
+                                                                      int ld_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= width) return;
+  for (long long r = 0; r < R; ++r) out[(size_t)idx[r] * ld_out + c] += src[(size_t)r * ld_src + col_off + c];
 }
 
 // out[r, :] = x[idx[r], 0:width]  (float4 per thread)
@@ -199,7 +210,7 @@ extern "C" int bl_rowdot_bwd(const float* g_y, const float* x, int32_t ldx, cons
   BL_CHECK_ARG(g_y && x && w && g_x && g_w && H > 0, "bl_rowdot_bwd: null pointer");
   const int blocks = min(256, (R + 15) / 16);
   hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_y, x, ldx, w, R, H, g_x,
-                     ld_gx, g_w, g_b);
+                     ld_gx, g_w, g_b, bl_order_counters(1, stream));
   BL_LAUNCH_CHECK("bl_rowdot_bwd");
   return BL_OK;
 }
@@ -209,8 +220,12 @@ extern "C" int bl_scatter_add_rows(const float* src, int32_t ld_src, int32_t col
   if (R == 0) return BL_OK;
   BL_CHECK_ARG(src && idx && out && width > 0, "bl_scatter_add_rows: null pointer");
   const long long total = (long long)R * width;
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     src, ld_src, col_off, width, idx, (long long)R, out, ld_out);
+  if (bl_get_deterministic())
+    hipLaunchKernelGGL(scatter_add_rows_serial_kernel, dim3((width + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                       col_off, width, idx, (long long)R, out, ld_out);
+  else
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, ld_src, col_off, width, idx, (long long)R, out, ld_out);
   BL_LAUNCH_CHECK("bl_scatter_add_rows");
   return BL_OK;
 }
