@@ -457,7 +457,10 @@ static int fill_rows(const bl_rows_t* a, RowsDev& d, int& K, const char* who) {
   return BL_OK;
 }
 
-#define ROWS_CFG_DEFAULT 32, 1, 2
+// 32-k stages, one LDS buffer; four workgroups per CU (<= 128 VGPRs): the node-level GEMMs have ~1000 row tiles, which
+// is one round at 4 x 256 resident workgroups and 1.3 rounds at 3 x 256.  The routed form needs its registers: two.
+#define ROWS_CFG_DEFAULT 32, 1, 4
+#define ROWS_CFG_ROUTED 32, 1, 2
 
 static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t mask_ld, const float* b, int64_t b_group_stride, int32_t ldb, int32_t b_is_nk,
                             const float* bias, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
@@ -480,7 +483,7 @@ static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t m
   if (b_is_nk) {
     BL_CHECK_ARG(act == BL_ACT_NONE, "bl_gemm_rows: the transposed-B (input gradient) form takes no activation");
     if (mask_arg)
-      hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, ROWS_CFG_DEFAULT, true, BM>), grid, dim3(256), 0, st, ROWS_LAUNCH);
+      hipLaunchKernelGGL((gemm_rows_kernel<true, BL_ACT_NONE, ROWS_CFG_ROUTED, true, BM>), grid, dim3(256), 0, st, ROWS_LAUNCH);
     else
       ROWS_GO(true, BL_ACT_NONE);
   } else {
