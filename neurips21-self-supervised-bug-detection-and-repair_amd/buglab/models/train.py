@@ -74,6 +74,10 @@ def run(arguments):
                            enable_amp=arguments["--amp"])
     if nn is not None:
         trainer.neural_module = nn
+        # continuing from a checkpoint: Adam's moments / warm-up position live in `<checkpoint>.optim` when this
+        # trainer wrote it (the model pickle itself stays what the reference's callers expect)
+        restored_from = arguments.get("--restore-path") or model_path
+        trainer.restore_optimizer_state_from = Path(restored_from)
     trainer.register_train_epoch_end_hook(lambda model, nn, epoch, metrics: LOGGER.info("train epoch %s: %s", epoch, metrics))
     trainer.register_validation_epoch_end_hook(lambda model, nn, epoch, metrics: LOGGER.info("valid epoch %s: %s", epoch, metrics))
     if initialize_metadata:

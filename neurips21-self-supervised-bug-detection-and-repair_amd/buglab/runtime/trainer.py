@@ -326,6 +326,40 @@ class ModelTrainer:
         LOGGER.info("Epoch %s: validation loss %.5f. Metrics: %s", epoch, val_loss, metrics)
         return target, improved
 
+    # ---- optimiser state next to the checkpoint -----------------------------------------------------------------
+    # The model pickle is what the reference's callers exchange; Adam's moments and step count (warm-up position) go
+    # to a sidecar `<checkpoint>.optim` so that continuing from a checkpoint does not restart them.  Optional on both
+    # sides: an optimiser without state_dict() writes nothing, a missing or mismatching sidecar is ignored with a note.
+    @staticmethod
+    def _optimizer_sidecar(path) -> Path:
+        path = Path(path)
+        return path.with_name(path.name + ".optim")
+
+    def _save_optimizer_state(self, optimizer) -> None:
+        if not hasattr(optimizer, "state_dict"):
+            return
+        import os
+
+        target = self._optimizer_sidecar(self._save_location)
+        tmp = target.with_name(target.name + ".tmp")
+        state = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in optimizer.state_dict().items()}
+        torch.save(state, tmp)
+        os.replace(tmp, target)
+
+    def _restore_optimizer_state(self, optimizer, device) -> None:
+        source = getattr(self, "restore_optimizer_state_from", None)
+        if source is None or not hasattr(optimizer, "load_state_dict"):
+            return
+        sidecar = self._optimizer_sidecar(source)
+        if not sidecar.exists():
+            LOGGER.info("No optimiser state next to %s: moments and warm-up start afresh.", source)
+            return
+        try:
+            optimizer.load_state_dict(torch.load(sidecar, map_location=device, weights_only=False))
+            LOGGER.info("Optimiser state restored from %s.", sidecar)
+        except Exception as e:  # a checkpoint of another architecture: shapes differ
+            LOGGER.warning("Optimiser state in %s does not fit this model (%s): starting afresh.", sidecar, e)
+
     def train(self, training_data: Iterable, validation_data: Iterable, *, show_progress_bar: bool = True,
               initialize_metadata: bool = True, parallelize: bool = True, use_multiprocessing: bool = False, patience: int = 5,
               device=None):
@@ -344,6 +378,7 @@ class ModelTrainer:
             else:
                 LOGGER.warning("clip_gradient_norm=%s was requested but %s cannot apply it (only FlatAdam fuses the clip); "
                                "gradients are NOT clipped", self._clip, type(optimizer).__name__)
+        self._restore_optimizer_state(optimizer, device)
         _, world = self._world()
         if world > 1:
             # replicas must be identical before the first step: rank 0's parameters (and moments) win
@@ -367,6 +402,7 @@ class ModelTrainer:
                 best, bad_epochs = target, 0
                 if rank == 0:
                     self.model.save(self._save_location, self._nn)
+                    self._save_optimizer_state(optimizer)
             else:
                 bad_epochs += 1
                 if bad_epochs >= patience:

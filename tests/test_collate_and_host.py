@@ -460,3 +460,41 @@ def test_trainer_epoch_loop_with_loader_processes_on_cpu(tmp_path, monkeypatch):
     trainer.neural_module.graphs = 0
     trainer._run_training(ds, 1, torch.device("cpu"), FakeOpt(), None, True)
     assert trainer.neural_module.graphs == 30
+
+
+def test_optimizer_state_travels_in_a_sidecar_next_to_the_checkpoint(tmp_path):
+    """Adam moments + step count (warm-up position) are written to `<checkpoint>.optim` with the best checkpoint and
+    picked up when training continues from it; a sidecar of another architecture is ignored, a missing one is fine."""
+    import torch
+
+    from buglab.runtime.optim import FlatAdam
+    from buglab.runtime.trainer import ModelTrainer
+
+    def make(n=7):
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.randn(n, 3)), torch.nn.Parameter(torch.randn(5))]
+        return FlatAdam(ps, lr=1e-3, num_warmup_steps=10, distributed=False)
+
+    ckpt = tmp_path / "model.pkl.gz"
+    trainer = ModelTrainer(model=None, save_location=ckpt)
+    opt = make()
+    opt.m.uniform_(-1, 1)
+    opt.v.uniform_(0, 1)
+    opt.step_count = 42
+    trainer._save_optimizer_state(opt)
+    assert (tmp_path / "model.pkl.gz.optim").exists() and not (tmp_path / "model.pkl.gz.optim.tmp").exists()
+
+    fresh = make()
+    other = ModelTrainer(model=None, save_location=tmp_path / "elsewhere.pkl.gz")
+    other._restore_optimizer_state(fresh, "cpu")  # nothing asked for: untouched
+    assert fresh.step_count == 0
+    other.restore_optimizer_state_from = ckpt
+    other._restore_optimizer_state(fresh, "cpu")
+    assert fresh.step_count == 42 and torch.equal(fresh.m, opt.m) and torch.equal(fresh.v, opt.v)
+
+    mismatched = make(n=9)
+    other._restore_optimizer_state(mismatched, "cpu")  # different parameter count: ignored with a warning
+    assert mismatched.step_count == 0 and float(mismatched.m.abs().sum()) == 0.0
+    other.restore_optimizer_state_from = tmp_path / "missing.pkl.gz"
+    other._restore_optimizer_state(fresh, "cpu")
+    assert fresh.step_count == 42
