@@ -2,9 +2,13 @@
 """End-to-end training rate through the kept entry points: shard files on disk -> loader processes (native reader,
 tensorise, native collator) -> ModelTrainer's epoch loop on the GPU (forward + backward + clip + Adam).
 
-    python tools/e2e_train_bench.py [--graphs 1024] [--nodes 1500] [--shards 16] [--workers 8] [--dry-run]
+    python tools/e2e_train_bench.py [--graphs 1024] [--nodes 1500] [--shards 16] [--workers 8] [--dry-run] [--profile]
 
---dry-run skips the device step (host pipeline only; runs without a GPU)."""
+--dry-run skips the device step (host pipeline only; runs without a GPU); --profile prints a cProfile of the trainer
+thread for the reported epoch.  Besides the rate it reports the device-only step time on a resident minibatch of the
+same data, per-step host / device intervals (median, p90), the time blocked on input, what the prefetch thread spent
+waiting for the loaders and uploading, and the caching allocator's footprint -- enough to tell an input-bound epoch
+from a host-bound or a device-bound one."""
 import argparse
 import os
 import sys
@@ -64,8 +68,8 @@ def main():
     from buglab.runtime.trainer import ModelTrainer
 
     hip_ops.load_library()
-    if os.environ.get("SWITCH_INTERVAL"):
-        sys.setswitchinterval(float(os.environ["SWITCH_INTERVAL"]))
+    if os.environ.get("SWITCH_INTERVAL"):  # stress knob: a short GIL switch interval interleaves the prefetch thread's
+        sys.setswitchinterval(float(os.environ["SWITCH_INTERVAL"]))  # allocations with the trainer's much more finely
     device = torch.device("cuda", 0)
     trainer = ModelTrainer(model, Path(d) / "m.pkl.gz", minibatch_size=a.minibatch_size, clip_gradient_norm=0.5)
     trainer.neural_module = model.build_neural_module().to(device)
@@ -99,26 +103,6 @@ def main():
         zero_grad()
 
     opt.zero_grad = marked_zero_grad
-    if os.environ.get("PROBE_UPLOAD"):
-        from buglab.data import collate as C
-
-        inner = C.upload_packed
-        probe = {"pin_alloc": 0.0, "memcpy": 0.0, "rest": 0.0, "n": 0}
-
-        def timed_upload(blob, meta, device):
-            t0 = time.perf_counter()
-            total = int(meta["total"])
-            st = torch.empty(total, dtype=torch.int32, pin_memory=True)
-            t1 = time.perf_counter()
-            st.numpy()[:] = blob[:total]
-            t2 = time.perf_counter()
-            out = inner(st.numpy(), meta, device)
-            t3 = time.perf_counter()
-            probe["pin_alloc"] += t1 - t0; probe["memcpy"] += t2 - t1; probe["rest"] += t3 - t2; probe["n"] += 1
-            return out
-
-        import buglab.runtime.shardloader as SL
-        C.upload_packed = timed_upload
     for epoch in range(2):  # epoch 0 warms up (first-touch allocations, library load); epoch 1 is reported
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -146,10 +130,6 @@ def main():
                   f"(p90 {np.percentile(devt, 90):.1f}); sum host {host.sum():.0f} ms, sum device {devt.sum():.0f} ms")
         marks.clear()
         print(f"         prefetch thread: {trainer.last_input_timing}")
-        if os.environ.get("PROBE_UPLOAD"):
-            print(f"         upload probe (ms per minibatch): " + str({k: round(v / max(probe['n'], 1) * 1e3, 2) for k, v in probe.items() if k != "n"}))
-            for k in probe:
-                probe[k] = 0
         t = trainer.last_epoch_timing
         steady = (n_graphs - a.minibatch_size) / max(dt - t["first_minibatch_s"], 1e-9)
         print(f"         first minibatch after {t['first_minibatch_s']:.2f} s (loader start-up); afterwards {steady:.0f} graphs/s, "
