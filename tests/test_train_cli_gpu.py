@@ -76,3 +76,45 @@ def test_training_reduces_loss_on_a_fixed_minibatch():
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     assert all(math.isfinite(l) for l in losses)
+
+
+def test_epoch_loop_with_loader_processes_under_fine_thread_interleaving(tmp_path):
+    """The trainer's epoch loop as deployed: forked loader processes -> shared memory -> prefetch thread uploading on its
+    own stream -> training with free-running side-stream weight gradients.  A short GIL switch interval interleaves the
+    prefetch thread's allocations with the trainer's far more finely than the default 5 ms; with the upload on the
+    TRAINING stream's allocator pool this setting produced GPU memory faults.  Every graph must be consumed once per
+    epoch, losses finite, and the second epoch (fork from a process that already holds device garbage) must work too."""
+    import sys
+
+    from buglab.data.synthetic import make_buglab_datapoint
+    from buglab.models.modelregistry import load_model
+    from buglab.runtime.optim import FlatAdam
+    from buglab.runtime.shardloader import ShardDataset
+    from buglab.runtime.trainer import ModelTrainer
+    from buglab.utils.msgpackutils import save_msgpack_l_gz
+
+    os.environ["BUGLAB_LOADER_WORKERS"] = "6"
+    rng = np.random.default_rng(0)
+    base = [make_buglab_datapoint(rng, num_syntax_nodes=250, num_tokens=120, buggy=bool(i % 2)) for i in range(32)]
+    for i in range(12):
+        save_msgpack_l_gz(base, tmp_path / f"s{i:02d}.msgpack.l.gz")
+    ds = ShardDataset(str(tmp_path), shuffle=True)
+    model, _, _ = load_model({"modelName": "gnn-mlp", "hidden_state_size": 64}, tmp_path / "m.pkl.gz")
+    for x in list(ds)[:32]:
+        model.update_metadata_from(x)
+    model.finalize_metadata()
+    trainer = ModelTrainer(model, tmp_path / "m.pkl.gz", minibatch_size=16, clip_gradient_norm=0.5)
+    trainer.neural_module = model.build_neural_module().to("cuda")
+    trainer._use_multiprocessing = True
+    opt = FlatAdam(trainer.neural_module.parameters())
+    previous = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
+    try:
+        for epoch in range(2):
+            metrics = trainer._run_training(ds, epoch, torch.device("cuda", 0), opt, None, True)
+            torch.cuda.synchronize()
+            assert trainer.last_epoch_timing["steps"] == 12 * 32 // 16
+            assert all(math.isfinite(float(v)) for v in metrics.values() if isinstance(v, (int, float)))
+    finally:
+        sys.setswitchinterval(previous)
+    assert all(bool(torch.isfinite(p).all()) for p in trainer.neural_module.parameters())
