@@ -509,13 +509,20 @@ USE_SIDE_STREAM = os.environ.get("BL_SIDE_STREAM", "1") != "0"
 DIRECT_PARAM_GRAD = os.environ.get("BL_DIRECT_GRAD", "1") != "0"
 
 
+_held_for_side_stream: list = []  # tensors the free-running side-stream GEMMs read: kept alive until the join
+
+
 def join_side_stream():
-    """Make the current stream wait for every weight-gradient GEMM still running on the side stream."""
+    """Make the current stream wait for every weight-gradient GEMM still running on the side stream.  What those GEMMs
+    read is released only now, i.e. behind the wait in this stream's order: the allocator may hand the blocks to the next
+    step at once (with `record_stream` instead they stayed unusable until their events completed, and a run settled
+    at ~100 GiB reserved for a 6 GiB peak)."""
     global _free_running
     if torch.cuda.is_available():
         key = torch.cuda.current_device()
         if key in _side_streams:
             torch.cuda.current_stream().wait_stream(_side_streams[key])
+    _held_for_side_stream.clear()
     _free_running = False
 
 
@@ -567,13 +574,10 @@ class _on_side_stream:
             _overlap_depth -= 1
 
     def detach(self, *tensors):
-        """Leave the side-stream work running: the tensors it reads are pinned to the side stream
-        (the caching allocator will not recycle them before that work is done)."""
+        """Leave the side-stream work running: the tensors it reads stay referenced until `join_side_stream()`."""
         global _overlap_depth
         if self.enabled:
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(self.side)
+            _held_for_side_stream.extend(t for t in tensors if t is not None)
             _overlap_depth -= 1
 
 
@@ -890,11 +894,10 @@ class _MpLayerFused(torch.autograd.Function):
                                    side.cuda_stream if side is not None else None, 0 if free_running else 1), "bl_mp_layer_bwd")
         if free_running:
             # the two weight-gradient GEMMs keep running behind the main chain (joined by join_side_stream()):
-            # what they read must not be recycled by the allocator before they are done
+            # what they read must not be recycled by the allocator before they are done -- held until the join
             global _free_running
             _free_running = True
-            for t in (saved, ws, g_W, g_Wd):
-                t.record_stream(side)
+            _held_for_side_stream.extend((saved, ws))
         ret = [None if d is not None else t for d, t in zip(direct, tgt)]
         return g_lo, g_hi, ret[4], ret[1], ret[2], ret[3], ret[0], None, None, None
 
