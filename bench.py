@@ -216,13 +216,19 @@ def main():
         mb = to_device(collate_samples(samples, args.types), device)
         module = build_gnn_mlp_module(args.hidden, args.layers, args.types, dropout_rate=args.dropout, dropout_base_seed=rank).to(device).train()
     opt = FlatAdam(module.parameters())
-    weight = D.global_batch_weight(args.graphs, device)
+    if world > 1:
+        opt.broadcast_parameters(0)  # what the trainer does before its first step
 
     def step():
         opt.zero_grad()
         loss = module(**mb)
         loss.backward()
-        opt.step(weight)
+        if world > 1:
+            # the trainer's data-parallel step: ONE all-reduce of [graphs x gradient | graphs, has-batch flag], the fused
+            # clip + Adam divides by the global graph count on the device
+            opt.step_data_parallel(args.graphs)
+        else:
+            opt.step()
         return loss
 
     for _ in range(args.warmup):
