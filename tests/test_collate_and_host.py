@@ -498,3 +498,19 @@ def test_optimizer_state_travels_in_a_sidecar_next_to_the_checkpoint(tmp_path):
     other.restore_optimizer_state_from = tmp_path / "missing.pkl.gz"
     other._restore_optimizer_state(fresh, "cpu")
     assert fresh.step_count == 42
+
+
+def test_deterministic_mode_keeps_every_token_in_one_chunk(monkeypatch):
+    """BL_DETERMINISTIC=1: the embedding-gradient kernel adds once per table row (one chunk per token) -- both collators."""
+    from buglab.data import collate as C
+    from buglab.data.synthetic import make_samples
+
+    samples = make_samples(6, seed=3, num_nodes=400, num_messages=1500, num_edge_types=4, vocab_size=20)  # few tokens: hot rows
+    monkeypatch.delenv("BL_DETERMINISTIC", raising=False)
+    free = C.collate_samples(samples, 4)["graph_data"]
+    assert len(free["tok_chunk_id"]) > len(np.unique(free["tok_chunk_id"]))  # hot tokens are cut into chunks of <= 256
+    monkeypatch.setenv("BL_DETERMINISTIC", "1")
+    det = C.collate_samples(samples, 4)["graph_data"]
+    assert len(det["tok_chunk_id"]) == len(np.unique(det["tok_chunk_id"]))
+    assert np.array_equal(np.sort(det["tok_occ"]), np.sort(free["tok_occ"]))  # the same occurrences, differently grouped
+    assert det["tok_chunk_ptr"][-1] == len(det["tok_occ"])
