@@ -105,3 +105,22 @@ def test_config_c1_plumbing_on_cpu_oracle():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     lp = out["loc_logprobs"]
     assert abs(float(torch.logsumexp(lp, 0))) < 1e-5  # one graph: candidates + NO_BUG form one distribution
+
+
+def test_optimiser_trajectory_matches_the_reference_pieces(golden_dir):
+    """T1: oracle.adam_clip_step against a trajectory produced by the reference's own `optimizer()` +
+    `LinearWarmupScheduler` (utils.py:51-66) + torch's Adam and clip_grad_norm_(0.5), stepped optimiser-then-scheduler
+    like ptgnn's trainer (tests/golden/make_golden_optim.py).  The HIP optimiser is compared with this oracle function on
+    the GPU (tests/test_hip_kernels.py::test_flat_adam_matches_oracle), which closes the chain to the reference."""
+    z = np.load(os.path.join(golden_dir, "optim_trajectory.npz"))
+    params = {0: torch.from_numpy(z["init0"].copy()), 1: torch.from_numpy(z["init1"].copy())}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(p) for k, p in params.items()}
+    for k in range(int(z["steps"])):
+        grads = {0: torch.from_numpy(z["grads0"][k].copy()), 1: torch.from_numpy(z["grads1"][k].copy())}
+        O.adam_clip_step(params, grads, m, v, k + 1, lr=float(z["lr"]), clip=float(z["clip"]), warmup=int(z["warmup"]))
+        for i in (0, 1):
+            want = torch.from_numpy(z[f"after{i}"][k])
+            assert (params[i] - want).abs().max() < 2e-6, (k, i, float((params[i] - want).abs().max()))
+    # the first step ran with learning-rate factor 0 (LambdaLR semantics): parameters unchanged after it
+    assert np.array_equal(z["after0"][0], z["init0"])
