@@ -157,3 +157,39 @@ def test_native_collator_equals_numpy_collator(degree, monkeypatch):
     # an empty minibatch of graphs without edges
     empty = C.collate_graphs([], 4)
     assert empty["msg_src"].size == 0 and empty["type_ptr"].tolist() == [0] * 5
+
+
+def test_shard_written_by_the_reference_reads_back_identically(tmp_path):
+    """On-disk format, pinned: `tests/golden/reference_shard.msgpack.l.gz` was written by the reference's own
+    `save_msgpack_l_gz` and `reference_shard.json` is what its `load_msgpack_l_gz` reads back
+    (tests/golden/make_golden_shard.py).  Both readers here must return the same elements (the `None` element included),
+    and the writer here must produce the same msgpack stream byte for byte."""
+    import gzip
+    import json
+
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    shard = os.path.join(gdir, "reference_shard.msgpack.l.gz")
+    with open(os.path.join(gdir, "reference_shard.json")) as f:
+        want = json.load(f)
+    plain = lambda x: json.loads(json.dumps(x))  # OrderedDict / tuples -> plain JSON types
+    py = list(load_msgpack_l_gz(shard, native=False))
+    assert len(py) == len(want) == 6 and py[1] is None
+    assert plain(py) == want
+    nat = list(load_msgpack_l_gz(shard, native=True))
+    assert len(nat) == 6 and nat[1] is None
+    for got, ref in zip(nat, want):
+        if ref is None:
+            continue
+        g = got["graph"]
+        ga = dict(ref["graph"])
+        add_open_vocab_nodes_and_edges(ga)  # the native reader adds the subtoken nodes / HasSubtoken edges while reading
+        assert list(g["nodes"]) == ga["nodes"]
+        assert {k: [list(e) for e in v] for k, v in g["edges"].items()} == {k: [list(e) for e in v] for k, v in ga["edges"].items()}
+        assert list(g["reference_nodes"]) == list(ga["reference_nodes"])
+        for k in ref:
+            if k != "graph":
+                assert plain(got[k]) == ref[k], k
+    out = str(tmp_path / "again.msgpack.l.gz")
+    save_msgpack_l_gz(py, out)
+    with gzip.open(out) as a, gzip.open(shard) as b:
+        assert a.read() == b.read()
