@@ -1,7 +1,9 @@
 // Routed input gradient from the non-zeros, second form.  Measured with the last GPU minutes of round 2
 // (`vec_dgrad_bench.py`, c2 H=128 layer, same box): shipped routed bf16x6 GEMM 0.395 ms, first form 0.558 ms, this form
 // 0.405 ms as first written and 0.364 ms with the padded pair list (16-byte pair reads, no index clamps); results equal
-// to the shipped kernel's to 2.4e-6.  Not integrated: there was no GPU time left to validate it inside bl_mp_layer_bwd
+// to the shipped kernel's to 2.4e-6.  NOT YET MEASURED: the explicit packed FMAs below (the ISA of the measured version
+// spent 8 VALU instructions per non-zero on v_mul + v_pk_add + v_mov shuffles; this one 3.6, which leaves the LDS reads
+// -- 6 clocks per non-zero -- as the bound: ~0.2 ms expected).  Not integrated: there was no GPU time left to validate it inside bl_mp_layer_bwd
 // (the integration of the first form is bl_routed_dgrad_vec_integration.patch).
 //
 // The first form (bl_routed_dgrad_vec.hip) enumerates a message's set routing bits on the SCALAR unit (s_ff1, clear,
@@ -51,6 +53,9 @@ __device__ __forceinline__ bool v2_find_piece(const int* __restrict__ type_ptr, 
   }
   return false;
 }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Pair {
   int row_off;  // channel * NOUT (floats): offset of the channel's weight row in the LDS block
@@ -123,9 +128,8 @@ __global__ __launch_bounds__(V2_THREADS, 1) void routed_dgrad_vec2_kernel(
         mine[total + lane] = z;
       }
       // (2) multiply: four non-zeros per trip; the pair reads are wave-uniform (LDS broadcast), two pairs per 16-byte read
-      float acc[OPL];
-#pragma unroll
-      for (int u = 0; u < OPL; ++u) acc[u] = 0.f;
+      f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll 2  // (the compiler's own choice of 4 runs into the 128-register cap of a 16-wave workgroup and spills)
       for (int i = 0; i < total; i += 4) {
         Pair pr[4];
         const int4 lo = *reinterpret_cast<const int4*>(mine + i), hi = *reinterpret_cast<const int4*>(mine + i + 2);
@@ -133,30 +137,39 @@ __global__ __launch_bounds__(V2_THREADS, 1) void routed_dgrad_vec2_kernel(
         pr[1].row_off = lo.z; pr[1].g = __builtin_bit_cast(float, lo.w);
         pr[2].row_off = hi.x; pr[2].g = __builtin_bit_cast(float, hi.y);
         pr[3].row_off = hi.z; pr[3].g = __builtin_bit_cast(float, hi.w);
+        // explicit packed FMAs: left to itself hipcc turns half of these into separate v_mul + v_pk_add with a dozen v_mov
+        // shuffles per trip (8 VALU instructions per non-zero instead of 3)
         if (OPL == 4) {
-          float4 r[4];
+          f32x4 r[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const float4*>(wl_lane + pr[q].row_off);
+          for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const f32x4*>(wl_lane + pr[q].row_off);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { acc[0] += pr[q].g * r[q].x; acc[1] += pr[q].g * r[q].y; acc[2] += pr[q].g * r[q].z; acc[3] += pr[q].g * r[q].w; }
+          for (int q = 0; q < 4; ++q) {
+            const f32x2 g2 = {pr[q].g, pr[q].g};
+            a01 = __builtin_elementwise_fma(g2, __builtin_shufflevector(r[q], r[q], 0, 1), a01);
+            a23 = __builtin_elementwise_fma(g2, __builtin_shufflevector(r[q], r[q], 2, 3), a23);
+          }
         } else if (OPL == 2) {
-          float2 r[4];
+          f32x2 r[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const float2*>(wl_lane + pr[q].row_off);
+          for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const f32x2*>(wl_lane + pr[q].row_off);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { acc[0] += pr[q].g * r[q].x; acc[1] += pr[q].g * r[q].y; }
+          for (int q = 0; q < 4; ++q) {
+            const f32x2 g2 = {pr[q].g, pr[q].g};
+            a01 = __builtin_elementwise_fma(g2, r[q], a01);
+          }
         } else {
           float r[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) r[q] = wl_lane[pr[q].row_off];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[0] += pr[q].g * r[q];
+          for (int q = 0; q < 4; ++q) a01.x = __builtin_fmaf(pr[q].g, r[q], a01.x);
         }
       }
       float* __restrict__ out = g_a + (size_t)e * ld_ga + lane * OPL;
-      if (OPL == 4) *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      else if (OPL == 2) *reinterpret_cast<float2*>(out) = make_float2(acc[0], acc[1]);
-      else out[0] = acc[0];
+      if (OPL == 4) *reinterpret_cast<float4*>(out) = make_float4(a01.x, a01.y, a23.x, a23.y);
+      else if (OPL == 2) *reinterpret_cast<float2*>(out) = make_float2(a01.x, a01.y);
+      else out[0] = a01.x;
     }
   }
 }
