@@ -1,9 +1,9 @@
 // Routed input gradient from the non-zeros, second form.  Measured with the last GPU minutes of round 2
 // (`vec_dgrad_bench.py`, c2 H=128 layer, same box): shipped routed bf16x6 GEMM 0.395 ms, first form 0.558 ms, this form
 // 0.405 ms as first written and 0.364 ms with the padded pair list (16-byte pair reads, no index clamps); results equal
-// to the shipped kernel's to 2.4e-6.  NOT YET MEASURED: the explicit packed FMAs below (the ISA of the measured version
-// spent 8 VALU instructions per non-zero on v_mul + v_pk_add + v_mov shuffles; this one 3.6, which leaves the LDS reads
-// -- 6 clocks per non-zero -- as the bound: ~0.2 ms expected).  Not integrated: there was no GPU time left to validate it inside bl_mp_layer_bwd
+// to the shipped kernel's to 2.6e-6; and **0.304 ms** with the explicit packed FMAs below (the ISA of the version before
+// spent 8 VALU instructions per non-zero on v_mul + v_pk_add + v_mov shuffles; this one 3.6).  That is 9.7 clocks per
+// non-zero per CU against 6 for its LDS reads: the compaction and the operand fetch are what is left to look at.  Not integrated: there was no GPU time left to validate it inside bl_mp_layer_bwd
 // (the integration of the first form is bl_routed_dgrad_vec_integration.patch).
 //
 // The first form (bl_routed_dgrad_vec.hip) enumerates a message's set routing bits on the SCALAR unit (s_ff1, clear,
