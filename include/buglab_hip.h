@@ -208,6 +208,28 @@ int bl_mp_scatter_grad_split(const float* g_a, int32_t ld_ga, const int32_t* src
                              float* g_h_lo, int32_t ld_lo, float* g_h_hi, int32_t ld_hi, const int32_t* node_order,
                              void* stream);
 
+/* Routed input gradient of the message layer from the NON-ZEROS of the message gradient alone (vector units, exact
+ * fp32): the max aggregation gives every (node, channel) gradient to ONE message, so only N * Dm of the E * Dm entries
+ * the routed GEMM multiplies are non-zero.  gq [*, Dm] fp32 = d loss / d (winning pre-activation) per node, wt =
+ * W transposed [T, Dm, 2 Din], win_bits / type_ptr as in bl_gemm_rows_x6 (messages type-major, target-sorted inside a type).
+ *   bl_routed_dgrad_vec    writes the per-message rows g_a[e, :] = sum_{d won by e} gq[tgt(e), d] * W[type(e)][:, d]
+ *                          (the result of the routed bl_gemm_rows_x6 up to fp32 summation order);
+ *   bl_routed_dgrad_nodes  adds them straight into the node gradient: g_h[src(e), 0:Din] += g_a[e, 0:Din] per message,
+ *                          g_h[tgt, 0:Din] += sum over a run of messages sharing the target of g_a[e, Din:2Din] (fp32 atomics;
+ *                          the caller zeroes g_h).  Columns < split go to g_h_lo, the rest to g_h_hi (split == Din: one output).
+ *                          = bl_routed_dgrad_vec + bl_mp_scatter_grad without the [E, 2 Din] round trip through memory.
+ * Both replace the autograd of ptgnn's gather + per-type Linear + torch_scatter.scatter_max (call site
+ * buglab/models/gnnlayerdefs.py:6-23).  bl_routed_dgrad_vec_ok: whether (Dm, K2 = 2 Din) is supported (W[t]^T must fit
+ * one 128 KB LDS block: Dm in {64, 128}, K2 in {128, 256}, Dm * K2 <= 32768). */
+int32_t bl_routed_dgrad_vec_ok(int32_t Dm, int32_t K2);
+int bl_routed_dgrad_vec(const float* gq, int32_t ld_gq, const int32_t* msg_tgt, const uint32_t* win_bits, int32_t ld_bits,
+                        const int32_t* type_ptr, int32_t T, const float* wt, int32_t E, int32_t Dm, int32_t K2, float* g_a,
+                        int32_t ld_ga, void* stream);
+int bl_routed_dgrad_nodes(const float* gq, int32_t ld_gq, const int32_t* msg_src, const int32_t* msg_tgt,
+                          const uint32_t* win_bits, int32_t ld_bits, const int32_t* type_ptr, int32_t T, const float* wt,
+                          int32_t E, int32_t Dm, int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi,
+                          int32_t ld_hi, void* stream);
+
 /* GRU cell of the gated (`ggnn`) node update -- the elementwise part of torch.nn.GRUCell (gate order
  * r | z | n) after gi = x W_i + b_i and gh = h W_h + b_h [N, 3D] were produced by bl_gemm_rows:
  *   h' = drop((1 - z) * tanh(gi_n + r * gh_n) + z * h).  Replaces ptgnn GatedMessagePassingLayer's

@@ -59,6 +59,10 @@ _SIGNATURES = {
     "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_pack_weights_x6": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_routed_dgrad_vec_ok": ([c_int32, c_int32], c_int32),
+    "bl_routed_dgrad_vec": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_routed_dgrad_nodes": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                               c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
@@ -1419,6 +1423,32 @@ def adam_clip_step(param, grad, m, v, sqn, *, prescale=1.0, clip=0.5, lr=1e-4, b
                                          param.numel(), _p(sqn), float(prescale), float(clip), float(lr), float(beta1), float(beta2),
                                          float(eps), int(step), _stream()),
         "bl_adam_clip_step")
+
+
+def routed_dgrad_vec(gq, msg_tgt, win_bits, type_ptr, T, wt, E, K2):
+    """g_a [E, K2] = routed message gradient x W^T from its non-zeros only (vector units; csrc/bl_routed_dgrad.hip).
+    gq [N, Dm] fp32, wt [T, Dm, K2] = W transposed, win_bits [E, Dm/32] from segment_max."""
+    Dm = gq.shape[1]
+    out = torch.empty((E, K2), dtype=torch.float32, device=gq.device)
+    with _timed("msg_dgrad_vec", 2.0 * gq.shape[0] * Dm * K2):
+        _check(load_library().bl_routed_dgrad_vec(_f32(gq).data_ptr(), gq.stride(0), _i32(msg_tgt).data_ptr(), win_bits.data_ptr(),
+                                                 win_bits.stride(0), _i32(type_ptr).data_ptr(), int(T), _f32(wt).data_ptr(), int(E), Dm,
+                                                 int(K2), out.data_ptr(), out.stride(0), _stream()), "bl_routed_dgrad_vec")
+    return out
+
+
+def routed_dgrad_nodes(gq, msg_src, msg_tgt, win_bits, type_ptr, T, wt, E, Din, out_lo, out_hi=None):
+    """Adds the routed input gradient straight into the node gradient out_lo [N, split] (+ out_hi [N, Din - split]):
+    routed_dgrad_vec + mp_scatter_grad without the per-message rows (fp32 atomics; the outputs must be zeroed)."""
+    Dm = gq.shape[1]
+    split = out_lo.shape[1]
+    with _timed("msg_dgrad_nodes", 2.0 * gq.shape[0] * Dm * 2 * Din):
+        _check(load_library().bl_routed_dgrad_nodes(_f32(gq).data_ptr(), gq.stride(0), _i32(msg_src).data_ptr(), _i32(msg_tgt).data_ptr(),
+                                                   win_bits.data_ptr(), win_bits.stride(0), _i32(type_ptr).data_ptr(), int(T),
+                                                   _f32(wt).data_ptr(), int(E), Dm, int(Din), int(split), out_lo.data_ptr(), out_lo.stride(0),
+                                                   _p(out_hi), out_hi.stride(0) if out_hi is not None else 0, _stream()),
+               "bl_routed_dgrad_nodes")
+    return out_lo, out_hi
 
 
 def adam_clip_step_dp(param, grad, m, v, sqn, batch_total, *, clip=0.5, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
