@@ -50,6 +50,12 @@ bl_reader* bl_reader_open(const char* path);                 /* NULL on error */
 int32_t bl_reader_next(bl_reader* r, bl_datapoint_t* out);
 void bl_reader_close(bl_reader* r);
 
+/* Iteration order of a CPython (3.7 - 3.12) `set` after inserting the non-negative ints inserted[0..n) in that order; out
+ * has room for n values, the return value is the number of distinct keys (< 0: bad argument).  The reference walks the set
+ * of NextToken endpoints in this order when it creates the subtoken nodes (buglab/representations/data.py:98-109), so the
+ * order is part of the data contract; the reader uses it internally, this entry point exists for the tests. */
+int32_t bl_pyset_order(const int32_t* inserted, int32_t n, int32_t* out);
+
 /* vocabulary of subtokens: token i = text[off[i] .. off[i+1]) */
 bl_vocab* bl_vocab_create(const char* text, const int32_t* off, int32_t n);
 void bl_vocab_free(bl_vocab* v);

@@ -260,9 +260,15 @@ typedef struct {
   int32_t msg_act;                /* BL_ACT_GELU or BL_ACT_NONE */
   float ln_eps;
   bl_dropout_t drop;
+  const float* Wt;                /* optional (backward only): W transposed, [T, Dm, 2 Din].  When given and
+                                   * bl_routed_dgrad_vec_ok(Dm, 2 Din), the input gradient is computed from the non-zeros of
+                                   * the routed message gradient (bl_routed_dgrad_nodes; bl_routed_dgrad_vec + bl_mp_scatter_grad
+                                   * in the deterministic mode) instead of the routed matrix-core GEMM; NULL: matrix cores */
 } bl_mp_layer_t;
 
-/* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call */
+/* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call.
+ * backward: 0 = forward call, 1 = backward call, 2 = backward call that will take the bl_routed_dgrad_nodes path (Wt given,
+ * shape supported, deterministic mode off): no [E, 2 Din] per-message gradient in the workspace */
 int64_t bl_mp_layer_saved_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t msg_act);
 int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t Dout, int32_t backward);
 /* uint16 elements of the packed weights a layer call takes: bl_pack_weights_x6(W, T, 2 Din, Dm, w_is_kn = 1) for

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "bl_reader_open": ([c_char_p], c_void_p),
     "bl_reader_next": ([c_void_p, POINTER(bl_datapoint_t)], c_int32),
     "bl_reader_close": ([c_void_p], None),
+    "bl_pyset_order": ([c_void_p, c_int32, c_void_p], c_int32),
     "bl_vocab_create": ([c_char_p, c_void_p, c_int32], c_void_p),
     "bl_vocab_free": ([c_void_p], None),
     "bl_tensorize_nodes": ([c_void_p, c_int32, c_char_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p], c_int32),
@@ -83,6 +84,17 @@ def load_library():
 
 def available() -> bool:
     return os.path.exists(LIB_PATH)
+
+
+def pyset_order(inserted) -> np.ndarray:
+    """Iteration order of a CPython set after inserting the given non-negative ints in order (bl_pyset_order)."""
+    a = np.ascontiguousarray(inserted, dtype=np.int32)
+    out = np.empty(a.shape[0], dtype=np.int32)
+    lib = load_library()
+    n = lib.bl_pyset_order(a.ctypes.data, int(a.shape[0]), out.ctypes.data)
+    if n < 0:
+        raise ValueError(lib.bl_data_last_error().decode())
+    return out[:n]
 
 
 def counting_sort(keys: np.ndarray, num_keys: int):

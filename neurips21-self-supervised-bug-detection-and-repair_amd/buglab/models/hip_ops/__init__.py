@@ -43,7 +43,7 @@ class bl_mp_layer_t(Structure):
                 ("msg_src", c_void_p), ("msg_tgt", c_void_p), ("type_ptr", c_void_p), ("tgt_ptr", c_void_p), ("tgt_msgs", c_void_p),
                 ("src_ptr", c_void_p), ("src_msgs", c_void_p), ("node_order", c_void_p),
                 ("W", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p), ("Wd", c_void_p), ("bd", c_void_p),
-                ("msg_act", c_int32), ("ln_eps", c_float), ("drop", bl_dropout_t)]
+                ("msg_act", c_int32), ("ln_eps", c_float), ("drop", bl_dropout_t), ("Wt", c_void_p)]
 
 
 _SIGNATURES = {
@@ -822,6 +822,28 @@ def _packed_layer_weights(W: torch.Tensor, need_bwd: bool):
     return ent[3], ent[4]
 
 
+# The routed input gradient of a message-passing layer from the NON-ZEROS of the message gradient, on the vector units, node
+# sums fused in (csrc/bl_routed_dgrad.hip), instead of the matrix-core GEMM over all E x Dm entries + bl_mp_scatter_grad.
+# BL_DGRAD_VEC=0: matrix cores.  Needs W transposed ([T, Dm, 2 Din]); cached per parameter value like the packed forms.
+DGRAD_VEC = os.environ.get("BL_DGRAD_VEC", "1") != "0"
+_wt_cache = {}  # id(W) -> (weakref(W), version, epoch, data_ptr, W transposed)
+
+
+def _transposed_layer_weights(W: torch.Tensor) -> torch.Tensor:
+    import weakref
+
+    key = id(W)
+    ent = _wt_cache.get(key)
+    if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == _weights_epoch and ent[3] == W.data_ptr():
+        return ent[4]
+    if len(_wt_cache) > 256:
+        for k in [k for k, v in _wt_cache.items() if v[0]() is None]:
+            del _wt_cache[k]
+    wt = W.detach().transpose(1, 2).contiguous()
+    _wt_cache[key] = (weakref.ref(W), W._version, _weights_epoch, W.data_ptr(), wt)
+    return wt
+
+
 def _layer_desc(g: "GraphIndex", W, ln_g, ln_b, Wd, bd, Din, msg_act, drop: Dropout) -> bl_mp_layer_t:
     L = bl_mp_layer_t()
     L.N, L.E, L.T, L.Din, L.Dm, L.Dout = g.num_nodes, g.num_messages, W.shape[0], Din, W.shape[2], Wd.shape[1]
@@ -882,7 +904,14 @@ class _MpLayerFused(torch.autograd.Function):
         tgt = [d if d is not None else torch.zeros_like(p) for d, p in zip(direct, (bd, ln_g, ln_b, Wd, W))]
         g_bd, g_lng, g_lnb, g_Wd, g_W = tgt
         L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
-        ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, 1),), dtype=torch.uint8, device=dev)
+        ws_mode = 1
+        wt = None
+        if DGRAD_VEC and E > 0 and lib.bl_routed_dgrad_vec_ok(Dm, 2 * Din):
+            wt = _transposed_layer_weights(W)  # (kept alive by this frame until the call below has been enqueued; cached beyond)
+            L.Wt = wt.data_ptr()
+            if not lib.bl_get_deterministic():
+                ws_mode = 2  # node sums fused into the input-gradient kernel: no [E, 2 Din] scratch
+        ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, ws_mode),), dtype=torch.uint8, device=dev)
         g_lo = torch.empty((N, w_lo), dtype=torch.float32, device=dev)
         g_hi = torch.empty((N, w_hi), dtype=torch.float32, device=dev) if w_hi else None
         side = None

@@ -201,7 +201,11 @@ class SeqBugLabModel(AbstractNeuralModel, AbstractBugLabModel):
         m = lambda ids: np.array([node_to_pos[int(n)] for n in ids], dtype=np.int32)
         ids, lens = self._token_embedder.tensorize_nodes(labels)
         kinds = tuple(k for k in self.edge_types if k in edges) if self.edge_types is not None else tuple(sorted(edges))
-        adj = [np.asarray(edges.get(k, ()), dtype=np.int32).reshape(-1, 2) for k in (self.edge_types or kinds)]
+        if self.edge_types is not None:
+            unseen = sorted(k for k in edges if k not in self.edge_types and len(edges[k]))
+            if unseen:  # the reference's edge-type vocabulary lookup raises a KeyError here (seqmodel.py:776-777)
+                raise KeyError(f"edge kinds {unseen} were not seen when the metadata was computed")
+        adj = [np.asarray(edges.get(k, ()), dtype=np.int32).reshape(-1, 2) for k in (self.edge_types if self.edge_types is not None else kinds)]
         refs = {
             "candidate_nodes": candidate_positions,
             "target_rewrite_nodes": m(target_rewrite_node_ids),

@@ -33,17 +33,20 @@ IS_IDENTIFIER = re.compile(r"[a-zA-Z_][a-zA-Z0-9_]*")
 
 def add_open_vocab_nodes_and_edges(graph: BugLabGraph) -> None:
     """reference data.py:97-121: one node per distinct subtoken of identifier tokens, linked by
-    `HasSubtoken` edges (mutates the graph in place, as the reference does)."""
+    `HasSubtoken` edges (mutates the graph in place, as the reference does).  Like the reference, the token
+    nodes are visited in the iteration order of a Python `set` (data.py:109): that order numbers the subtoken
+    nodes and orders the HasSubtoken edges, so it is part of the data contract (the native reader restates
+    CPython's set layout, csrc_data/bl_data.cpp::cpython_int_set_order)."""
     if "NextToken" not in graph["edges"]:
         return
     token_nodes = set()
     for edge in graph["edges"]["NextToken"]:
-        token_nodes.add(edge[0])
-        token_nodes.add(edge[1])
+        token_nodes.add(int(edge[0]))  # (plain ints also when the edge list is an int32 array: same hashes, same order)
+        token_nodes.add(int(edge[1]))
     vocab_nodes: Dict[str, int] = {}
     vocab_edges: List[Tuple[int, int]] = []
     all_nodes = graph["nodes"]
-    for node_idx in sorted(token_nodes):
+    for node_idx in token_nodes:
         token_str = all_nodes[node_idx]
         if not IS_IDENTIFIER.match(token_str):
             continue

@@ -41,7 +41,7 @@ class RichPath:
 
 def run_and_debug(fn, enable_debugging: bool = False):
     try:
-        fn()
+        return fn()
     except Exception:
         if enable_debugging:
             import pdb

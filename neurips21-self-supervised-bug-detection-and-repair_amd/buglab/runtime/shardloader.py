@@ -47,7 +47,7 @@ class ShardDataset:
     def __iter__(self):
         n = 0
         for f in self.shard_files():  # same (seeded) order as the loader processes use
-            for d in load_msgpack_l_gz(f):
+            for d in _read_shard(f):  # an unreadable shard is reported and skipped (reference msgpackutils.py:45-46)
                 if d is None:
                     continue
                 yield d

@@ -244,6 +244,7 @@ class ModelTrainer:
             training_data.set_epoch(epoch)  # every rank shuffles the shard files with the same per-epoch seed
         it = iter(self._iter_minibatches(training_data, device, parallelize))
         step, num_graphs, t0 = 0, 0, time.time()
+        B = 0
         _, world = self._world()
         fused_dp = world > 1 and hasattr(optimizer, "step_data_parallel")
         waited, first_wait = 0.0, None  # time this thread spent blocked on the input pipeline (first minibatch apart)
@@ -260,7 +261,10 @@ class ModelTrainer:
                     # Ranks stay in lock step through the gradient all-reduce alone: a rank whose loader is exhausted
                     # keeps stepping with an empty contribution until the tail of the all-reduce says that nobody had
                     # a minibatch (read one step late from pinned memory: no device synchronisation, no extra collective)
-                    if step > 0 and optimizer.previous_step_was_idle():
+                    # Only a rank that itself had NOTHING in the previous step can have seen an idle step, and such a rank
+                    # has no work queued behind the read -- so the pinned flag is only waited for when waiting is free;
+                    # a rank that is still training never blocks on its previous step here.
+                    if step > 0 and B == 0 and optimizer.previous_step_was_idle():
                         break
                     optimizer.zero_grad()
                     B = 0
@@ -387,6 +391,9 @@ class ModelTrainer:
             else:
                 for p in self._nn.parameters():
                     dist.broadcast(p.data, src=0)
+                from buglab.models import hip_ops
+
+                hip_ops.invalidate_weight_packs()  # `.data` writes do not bump `_version`: packed / transposed copies are stale
         scheduler = self._scheduler_creator(optimizer) if self._scheduler_creator is not None else None
         for hook in self._training_start_hooks:
             hook(self.model, self._nn, optimizer)

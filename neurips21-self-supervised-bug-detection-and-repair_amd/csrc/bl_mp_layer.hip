@@ -28,7 +28,7 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
 const char* kProfNames[] = {"pack_rows",      "msg_gemm_x6",  "segment_max_ln", "dense_fwd",    "act_bwd",       "dense_wgrad",
-                            "dense_dgrad",    "layernorm_bwd", "msg_wgrad_x6",   "msg_dgrad_x6", "node_grad_sums"};
+                            "dense_dgrad",    "layernorm_bwd", "msg_wgrad_x6",   "msg_dgrad_x6", "node_grad_sums", "msg_dgrad_nodes"};
 constexpr int kProfKinds = sizeof(kProfNames) / sizeof(kProfNames[0]);
 
 hipEvent_t prof_event() {
@@ -133,7 +133,7 @@ struct WsBwd {
   float* g_a;      // [E, 2 Din]
   size_t bytes;
 };
-WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout) {
+WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool with_ga = true) {
   WsBwd w;
   char* p = (char*)base;
   size_t o = 0;
@@ -141,7 +141,7 @@ WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout) {
   w.g_z = (float*)take((size_t)N * Dout * 4);
   w.g_ln = (float*)take((size_t)N * Dm * 4);
   w.gqp = (uint16_t*)take((size_t)N * 3 * Dm * 2);
-  w.g_a = (float*)take((size_t)E * 2 * Din * 4);
+  w.g_a = with_ga ? (float*)take((size_t)E * 2 * Din * 4) : nullptr;
   w.bytes = o;
   return w;
 }
@@ -171,7 +171,7 @@ extern "C" int64_t bl_mp_layer_saved_bytes(int32_t N, int32_t E, int32_t Din, in
 }
 // forward scratch: the [E, Dm] pre-activations; backward scratch: g_z, g_ln, packed node gradient, [E, 2 Din] input gradients
 extern "C" int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t Dout, int32_t backward) {
-  if (backward) return (int64_t)carve_bwd(nullptr, N, E, Din, Dm, Dout).bytes;
+  if (backward) return (int64_t)carve_bwd(nullptr, N, E, Din, Dm, Dout, backward != 2).bytes;
   return (int64_t)al((size_t)E * Dm * 4);
 }
 extern "C" int64_t bl_mp_layer_packed_weight_elems(int32_t T, int32_t Din, int32_t Dm, int32_t for_backward) {
@@ -244,7 +244,11 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   const bool two = side != st;
   if (two) BL_CHECK_ARG(ensure_events(), "bl_mp_layer_bwd: cannot create HIP events");
   Saved S = carve_saved(const_cast<void*>(saved), N, E, Din, Dm, L->msg_act);
-  WsBwd B = carve_bwd(ws, N, E, Din, Dm, Dout);
+  // the input gradient from the non-zeros of the routed message gradient (vector units) when the caller supplied W^T and
+  // W[t]^T fits one LDS block; node sums fused in (atomics) unless the deterministic mode asks for a fixed summation order
+  const bool vec_dgrad = L->Wt != nullptr && E > 0 && bl_routed_dgrad_vec_ok(Dm, 2 * Din);
+  const bool fused_sums = vec_dgrad && !bl_get_deterministic();
+  WsBwd B = carve_bwd(ws, N, E, Din, Dm, Dout, !fused_sums);
 
   {  // y = drop(tanh(z)): g_z, bias gradient
     ProfScope ps(4, 0.0, st, false);
@@ -269,7 +273,8 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   }
   {  // LayerNorm backward x activation derivative at the winners -> packed d loss / d (winning pre-activation)
     ProfScope ps(7, 0.0, st, two);
-    BL_TRY(bl_layernorm_bwd(B.g_ln, S.agg, S.mean, S.rstd, L->ln_g, N, Dm, nullptr, g_ln_g, g_ln_b, S.dact, B.gqp, st));
+    // (the fp32 form of the result, for the vector input gradient, overwrites g_ln in place: the kernel is row-local)
+    BL_TRY(bl_layernorm_bwd(B.g_ln, S.agg, S.mean, S.rstd, L->ln_g, N, Dm, vec_dgrad ? B.g_ln : nullptr, g_ln_g, g_ln_b, S.dact, B.gqp, st));
   }
   if (E > 0) {
     bl_rows_packed_t a;
@@ -289,13 +294,29 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
     bl_rows_packed_t g;
     g.xp[0] = B.gqp; g.xp[1] = g.xp[2] = nullptr; g.idx[0] = L->msg_tgt; g.idx[1] = g.idx[2] = nullptr;
     g.width[0] = Dm; g.width[1] = g.width[2] = 0; g.nsrc = 1;
-    {
+    if (fused_sums) {
+      ProfScope ps(11, 2.0 * N * (2.0 * Din) * Dm, st, two);  // FLOPs of the non-zeros: one winner per (node, channel)
+      const int split = g_h_hi ? width_lo : Din;
+      if (ld_lo == split) {
+        if (hipMemsetAsync(g_h_lo, 0, (size_t)N * split * 4, st) != hipSuccess) { bl_set_error("bl_mp_layer_bwd: memset failed"); return BL_EINVAL; }
+      } else if (hipMemset2DAsync(g_h_lo, (size_t)ld_lo * 4, 0, (size_t)split * 4, N, st) != hipSuccess) { bl_set_error("bl_mp_layer_bwd: memset failed"); return BL_EINVAL; }
+      if (g_h_hi) {
+        if (ld_hi == Din - split) {
+          if (hipMemsetAsync(g_h_hi, 0, (size_t)N * (Din - split) * 4, st) != hipSuccess) { bl_set_error("bl_mp_layer_bwd: memset failed"); return BL_EINVAL; }
+        } else if (hipMemset2DAsync(g_h_hi, (size_t)ld_hi * 4, 0, (size_t)(Din - split) * 4, N, st) != hipSuccess) { bl_set_error("bl_mp_layer_bwd: memset failed"); return BL_EINVAL; }
+      }
+      BL_TRY(bl_routed_dgrad_nodes(B.g_ln, Dm, L->msg_src, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, Din, split, g_h_lo,
+                                   ld_lo, g_h_hi, ld_hi, st));
+    } else if (vec_dgrad) {
+      ProfScope ps(9, 2.0 * N * (2.0 * Din) * Dm, st, two);
+      BL_TRY(bl_routed_dgrad_vec(B.g_ln, Dm, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, 2 * Din, B.g_a, 2 * Din, st));
+    } else {
       ProfScope ps(9, 2.0 * E * (2.0 * Din) * Dm, st, two);
       BL_TRY(bl_gemm_rows_x6(&g, S.bits, Dm / 32, w_packed_bwd, (int64_t)packed_w_elems(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E,
                              2 * Din, Dm, B.g_a, 2 * Din, st));
     }
   }
-  {
+  if (!fused_sums) {
     ProfScope ps(10, 0.0, st, two);
     // E == 0: both CSRs are empty and g_a is never read
     if (g_h_hi == nullptr)

@@ -329,6 +329,61 @@ bool parse_refs(bl_reader* r, P p, P end) {
   return true;
 }
 
+// Iteration order of a CPython `set` of non-negative ints after the given insertion sequence.  The reference walks
+// `token_nodes` (a set filled with n1, n2 of every NextToken edge, buglab/representations/data.py:98-103) in SET order
+// (:109), which numbers the subtoken nodes and orders the HasSubtoken edges -- so the order is part of the data contract.
+// This is Objects/setobject.c of CPython 3.7 - 3.12 restated: open addressing, hash(n) = n, LINEAR_PROBES = 9 probes
+// after the home slot (only when they do not run past the table), then i = 5 i + 1 + (perturb >>= 5); growth when
+// fill * 5 >= mask * 3 to the first power of two above used * 4 (used * 2 beyond 50 000 entries), re-inserting the old
+// table in slot order.  Nothing is ever removed here, so there are no dummy entries.
+std::vector<int32_t> cpython_int_set_order(const std::vector<int32_t>& inserted) {
+  std::vector<int64_t> table(8, -1);  // -1 = unused slot
+  size_t mask = 7, used = 0;
+  auto insert_clean = [](std::vector<int64_t>& tb, size_t m, int64_t key) {
+    size_t perturb = (size_t)key, i = (size_t)key & m;
+    for (;;) {
+      if (tb[i] < 0) { tb[i] = key; return; }
+      if (i + 9 <= m) {
+        for (size_t j = 1; j <= 9; ++j)
+          if (tb[i + j] < 0) { tb[i + j] = key; return; }
+      }
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & m;
+    }
+  };
+  for (int32_t k32 : inserted) {
+    const int64_t key = k32;
+    size_t perturb = (size_t)key, i = (size_t)key & mask;
+    bool found = false, placed = false;
+    while (!found && !placed) {
+      const size_t probes = (i + 9 <= mask) ? 9 : 0;
+      for (size_t j = 0; j <= probes; ++j) {
+        if (table[i + j] < 0) { table[i + j] = key; placed = true; break; }
+        if (table[i + j] == key) { found = true; break; }
+      }
+      if (found || placed) break;
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & mask;
+    }
+    if (!placed) continue;
+    ++used;
+    if (used * 5 < mask * 3) continue;
+    const size_t minused = used > 50000 ? used * 2 : used * 4;
+    size_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    std::vector<int64_t> nt(newsize, -1);
+    for (int64_t v : table)
+      if (v >= 0) insert_clean(nt, newsize - 1, v);
+    table.swap(nt);
+    mask = newsize - 1;
+  }
+  std::vector<int32_t> order;
+  order.reserve(used);
+  for (int64_t v : table)
+    if (v >= 0) order.push_back((int32_t)v);
+  return order;
+}
+
 // buglab/representations/data.py:97-121
 void add_open_vocab(bl_reader* r, bl_datapoint_t* out) {
   int next_token = -1;
@@ -337,10 +392,12 @@ void add_open_vocab(bl_reader* r, bl_datapoint_t* out) {
     if (r->kind_names[k] == "NextToken") next_token = (int)k;
   }
   if (next_token < 0) return;
+  // the reference iterates the SET of token nodes: same order here (node ids are non-negative msgpack ints)
+  bool negative = false;
+  for (int32_t v : r->pairs[next_token]) negative |= v < 0;
+  if (negative) { out->non_ascii_identifier = 1; return; }  // hash(-1) = -2 etc.: leave such a file to the Python path
   out->created_has_subtoken = 1;
-  std::vector<int32_t> toks(r->pairs[next_token]);
-  std::sort(toks.begin(), toks.end());
-  toks.erase(std::unique(toks.begin(), toks.end()), toks.end());
+  const std::vector<int32_t> toks = cpython_int_set_order(r->pairs[next_token]);
   std::unordered_map<std::string, int32_t> vocab_nodes;
   std::vector<int32_t> pr;
   const int32_t n0 = (int32_t)r->node_off.size() - 1;
@@ -433,7 +490,17 @@ bool parse_datapoint(bl_reader* r, P p, P end, bl_datapoint_t* out) {
 }  // namespace
 
 extern "C" const char* bl_data_last_error(void) { return g_err; }
-extern "C" int32_t bl_data_version(void) { return 1; }
+extern "C" int32_t bl_data_version(void) { return 2; }
+
+extern "C" int32_t bl_pyset_order(const int32_t* inserted, int32_t n, int32_t* out) {
+  if (n < 0 || (n > 0 && (!inserted || !out))) { set_err("bl_pyset_order: bad arguments"); return -1; }
+  std::vector<int32_t> in(inserted, inserted + n);
+  for (int32_t v : in)
+    if (v < 0) { set_err("bl_pyset_order: negative key"); return -1; }
+  const std::vector<int32_t> order = cpython_int_set_order(in);
+  std::copy(order.begin(), order.end(), out);
+  return (int32_t)order.size();
+}
 
 extern "C" bl_reader* bl_reader_open(const char* path) {
   gzFile gz = gzopen(path, "rb");
