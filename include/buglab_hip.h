@@ -134,6 +134,11 @@ int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t N, int32_t 
 int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                     int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
                     int32_t N, int32_t K, float* c, int32_t ldc, void* stream);
+/* the same with bl_gemm_rows' epilogue, C = drop(act(A . B_g + bias)): ptgnn MlpMessagePassingLayer's dense node update
+ * Linear -> tanh -> Dropout (call site buglab/models/gnnlayerdefs.py:6-23) on the bf16 matrix cores */
+int bl_gemm_rows_x6_epi(const bl_rows_packed_t* a, const uint16_t* bp, int64_t b_group_stride, const int32_t* group_ptr,
+                        const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, const float* bias, int32_t act,
+                        bl_dropout_t drop, float* c, int32_t ldc, void* stream);
 /* bf16x6 form of bl_gemm_wgrad_routed (below): `a` packed rows, g_node_packed = bl_pack_bf16x3 of the
  * node gradient [*, N]; the message-major operands are transposed on the fly by gfx950's transposing
  * LDS read (ds_read_b64_tr_b16).  N and the source widths must be multiples of 32. */
@@ -141,6 +146,12 @@ int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_pa
                             const uint32_t* win_bits, int32_t ld_bits, const int32_t* group_ptr, const int32_t* group_w,
                             int32_t G, int32_t M, int32_t N, int32_t K, float* gw, int64_t gw_group_stride, int32_t ld_gw,
                             void* stream);
+
+/* bf16x6 form of bl_gemm_wgrad (below), no routing: gw[g] += rows(a)^T . g_packed[g_idx[r] or r, 0:N] -- the weight
+ * gradient of a plain Linear (the dense node update) from packed operands */
+int bl_gemm_wgrad_x6(const bl_rows_packed_t* a, const uint16_t* g_packed, const int32_t* g_idx, const int32_t* group_ptr,
+                     const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw, int64_t gw_group_stride,
+                     int32_t ld_gw, void* stream);
 
 /* Weight-gradient GEMM (reduction over rows, split across row chunks, fp32 atomics):
  *   gw[group_w[g]][0:K, 0:N] += rows(a)[rows of g, 0:K]^T . g_c[rows of g, 0:N]
@@ -264,6 +275,11 @@ typedef struct {
                                    * bl_routed_dgrad_vec_ok(Dm, 2 Din), the input gradient is computed from the non-zeros of
                                    * the routed message gradient (bl_routed_dgrad_nodes; bl_routed_dgrad_vec + bl_mp_scatter_grad
                                    * in the deterministic mode) instead of the routed matrix-core GEMM; NULL: matrix cores */
+  const uint16_t* Wd_packed;      /* optional: bl_pack_weights_x6(Wd, 1, Dm, Dout, w_is_kn = 1).  When given (and Dm, Dout are
+                                   * multiples of 32) the dense node update runs as bf16x6 GEMMs: forward, input gradient and
+                                   * weight gradient; the same layer's backward call must then also carry ... */
+  const uint16_t* Wd_packed_bwd;  /* ... bl_pack_weights_x6(Wd, 1, Dout, Dm, w_is_kn = 0), the form of g_ln = g_z . Wd^T.
+                                   * NULL / NULL: exact-fp32 MFMA GEMMs (bl_gemm_rows / bl_gemm_wgrad) */
 } bl_mp_layer_t;
 
 /* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call.

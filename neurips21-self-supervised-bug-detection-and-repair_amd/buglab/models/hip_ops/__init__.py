@@ -43,7 +43,8 @@ class bl_mp_layer_t(Structure):
                 ("msg_src", c_void_p), ("msg_tgt", c_void_p), ("type_ptr", c_void_p), ("tgt_ptr", c_void_p), ("tgt_msgs", c_void_p),
                 ("src_ptr", c_void_p), ("src_msgs", c_void_p), ("node_order", c_void_p),
                 ("W", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p), ("Wd", c_void_p), ("bd", c_void_p),
-                ("msg_act", c_int32), ("ln_eps", c_float), ("drop", bl_dropout_t), ("Wt", c_void_p)]
+                ("msg_act", c_int32), ("ln_eps", c_float), ("drop", bl_dropout_t), ("Wt", c_void_p),
+                ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p)]
 
 
 _SIGNATURES = {
@@ -59,6 +60,10 @@ _SIGNATURES = {
     "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_pack_weights_x6": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gemm_rows_x6_epi": ([POINTER(bl_rows_packed_t), c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32,
+                             bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gemm_wgrad_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
+                          c_int32, c_void_p], ctypes.c_int),
     "bl_routed_dgrad_vec_ok": ([c_int32, c_int32], c_int32),
     "bl_routed_dgrad_vec": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_routed_dgrad_nodes": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
@@ -325,9 +330,11 @@ def pack_weights_x6(w: torch.Tensor, w_is_kn: bool) -> torch.Tensor:
     return out
 
 
-def gemm_rows_x6(sources, bp, M, N, *, group_ptr=None, group_w=None, G=1, win_bits=None, kind="gemm_rows_x6"):
+def gemm_rows_x6(sources, bp, M, N, *, group_ptr=None, group_w=None, G=1, win_bits=None, kind="gemm_rows_x6", bias=None, act=None,
+                 drop: "Dropout" = None):
     """sources: [(packed int16 [*, 3*width], row index or None, width)]; bp: pack_weights_x6 output [G, *];
-    win_bits: segment_max's per-row routing bitmask -> the routed (winner-masked) left operand."""
+    win_bits: segment_max's per-row routing bitmask -> the routed (winner-masked) left operand;
+    bias / act / drop: the epilogue drop(act(. + bias)) of bl_gemm_rows_x6_epi."""
     r = bl_rows_packed_t()
     K = 0
     for j, (xp, idx, width) in enumerate(sources):
@@ -339,6 +346,14 @@ def gemm_rows_x6(sources, bp, M, N, *, group_ptr=None, group_w=None, G=1, win_bi
     r.nsrc = len(sources)
     out = torch.empty((M, N), dtype=torch.float32, device=bp.device)
     if M == 0:
+        return out
+    if bias is not None or act is not None or drop is not None:
+        with _timed(kind + "_epi", 2.0 * M * N * K):
+            _check(
+                load_library().bl_gemm_rows_x6_epi(ctypes.byref(r), _req(bp, torch.int16, "bp").data_ptr(), int(bp.stride(0)), _p(group_ptr),
+                                                   _p(group_w), int(G), int(M), int(N), int(K), _p(bias), int(act or ACT_NONE),
+                                                   (drop or NO_DROPOUT).c(), out.data_ptr(), out.stride(0), _stream()),
+                "bl_gemm_rows_x6_epi")
         return out
     with _timed(kind + ("_grouped" if group_ptr is not None else ""), 2.0 * M * N * K):
         _check(
@@ -374,6 +389,21 @@ def gemm_wgrad_routed_x6(sources, g_node_packed, node_of_row, win_bits, M, N, gw
                                                    _p(group_ptr), _p(group_w), int(G), int(M), int(N), int(K),
                                                    _f32(gw).data_ptr(), int(gw_group_stride), int(gw.shape[-1]), _stream()),
             "bl_gemm_wgrad_routed_x6")
+    return gw
+
+
+def gemm_wgrad_x6(sources, g_packed, M, N, gw, *, g_idx=None, gw_group_stride=0, group_ptr=None, group_w=None, G=1):
+    """gw[g] += rows(sources)^T . g_packed[(g_idx[r] or r)] from bf16x3-packed operands (no routing): the weight gradient of a
+    plain Linear.  sources as in gemm_rows_x6; g_packed int16 [*, 3 N]."""
+    r, K = _rows_packed(sources)
+    if M == 0:
+        return gw
+    with _timed("gemm_wgrad_x6", 2.0 * M * N * K):
+        _check(
+            load_library().bl_gemm_wgrad_x6(ctypes.byref(r), _req(g_packed, torch.int16, "g_packed").data_ptr(), _p(g_idx), _p(group_ptr),
+                                            _p(group_w), int(G), int(M), int(N), int(K), _f32(gw, "gw").data_ptr(), int(gw_group_stride),
+                                            int(gw.shape[-1]), _stream()),
+            "bl_gemm_wgrad_x6")
     return gw
 
 
@@ -798,10 +828,20 @@ def invalidate_weight_packs():
     _weights_epoch += 1
 
 
+# The dense node update (LayerNorm -> Linear -> tanh -> Dropout) as bf16x6 GEMMs too (forward, input gradient, weight
+# gradient); BL_DENSE_X6=0: exact-fp32 MFMA GEMMs.
+DENSE_X6 = os.environ.get("BL_DENSE_X6", "1") != "0"
+
+
+def _as_groups(w: torch.Tensor) -> torch.Tensor:
+    return w if w.dim() == 3 else w.unsqueeze(0)
+
+
 def _packed_layer_weights(W: torch.Tensor, need_bwd: bool):
     """bf16x3-packed, tiled copies of a layer's per-type weights: the forward form (C = A . W[t]) and, when a
     backward pass will follow, the form of the routed input-gradient GEMM (C = G . W[t]^T).  Packed once per
-    parameter value: eval / predict passes re-use them, a training step packs each form once."""
+    parameter value: eval / predict passes re-use them, a training step packs each form once.  A 2-D weight
+    (the dense node update's Wd [Dm, Dout]) is packed as one group."""
     import weakref
 
     key = id(W)
@@ -809,13 +849,13 @@ def _packed_layer_weights(W: torch.Tensor, need_bwd: bool):
     if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == _weights_epoch and ent[5] == W.data_ptr():
         if not need_bwd or ent[4] is not None:
             return ent[3], ent[4]
-        ent = (ent[0], ent[1], ent[2], ent[3], pack_weights_x6(W.detach(), False), ent[5])
+        ent = (ent[0], ent[1], ent[2], ent[3], pack_weights_x6(_as_groups(W.detach()), False), ent[5])
         _pack_cache[key] = ent
         return ent[3], ent[4]
     if len(_pack_cache) > 256:
         for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
             del _pack_cache[k]
-    wd = W.detach()
+    wd = _as_groups(W.detach())
     ent = (weakref.ref(W), W._version, _weights_epoch, pack_weights_x6(wd, True), pack_weights_x6(wd, False) if need_bwd else None,
            W.data_ptr())
     _pack_cache[key] = ent
@@ -876,6 +916,11 @@ class _MpLayerFused(torch.autograd.Function):
         wkn, wnk = _packed_layer_weights(W, need_bwd)
         dev = h_lo.device
         L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
+        dense_x6 = DENSE_X6 and Dm % 32 == 0 and Dout % 32 == 0
+        wd_kn = wd_nk = None
+        if dense_x6:
+            wd_kn, wd_nk = _packed_layer_weights(Wd, need_bwd)
+            L.Wd_packed = wd_kn.data_ptr()
         saved = torch.empty((lib.bl_mp_layer_saved_bytes(N, E, Din, Dm, msg_act),), dtype=torch.uint8, device=dev)
         ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, 0),), dtype=torch.uint8, device=dev)
         out = torch.empty((N, Dout), dtype=torch.float32, device=dev)
@@ -885,12 +930,13 @@ class _MpLayerFused(torch.autograd.Function):
                                    saved.data_ptr(), ws.data_ptr() if E > 0 else None, _stream()), "bl_mp_layer_fwd")
         if winner is not None:
             WINNER_SINK.append(winner)
-        ctx.saved = (h_lo.shape[1], h_hi.shape[1] if h_hi is not None else 0, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk)
+        ctx.saved = (h_lo.shape[1], h_hi.shape[1] if h_hi is not None else 0, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk,
+                     dense_x6, wd_kn, wd_nk)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk = ctx.saved
+        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk, dense_x6, wd_kn, wd_nk = ctx.saved
         ctx.saved = None
         lib = load_library()
         N, E = g.num_nodes, g.num_messages
@@ -904,6 +950,10 @@ class _MpLayerFused(torch.autograd.Function):
         tgt = [d if d is not None else torch.zeros_like(p) for d, p in zip(direct, (bd, ln_g, ln_b, Wd, W))]
         g_bd, g_lng, g_lnb, g_Wd, g_W = tgt
         L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
+        if dense_x6:  # (forward kept the LayerNorm output in packed form: backward must take the same path)
+            if wd_nk is None:
+                wd_nk = pack_weights_x6(_as_groups(Wd.detach()), False)
+            L.Wd_packed, L.Wd_packed_bwd = wd_kn.data_ptr(), wd_nk.data_ptr()
         ws_mode = 1
         wt = None
         if DGRAD_VEC and E > 0 and lib.bl_routed_dgrad_vec_ok(Dm, 2 * Din):

@@ -14,6 +14,15 @@ extern "C" int32_t bl_get_deterministic(void);
 // n zeroed turn counters for one launch on `stream`, or nullptr when the deterministic mode is off (bl_core.hip)
 unsigned* bl_order_counters(int n, void* stream);
 
+// internal forms of two exported entry points with an extra bf16x3-packed output (csrc/bl_graph_ops.hip; used by the
+// fused layer calls, whose dense node-update GEMMs run as bf16x6)
+int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg, int32_t D,
+                            int32_t act, float* out, int32_t* arg, const float* ln_g, const float* ln_b, float eps, float* ln_out,
+                            float* mean, float* rstd, float* dact, uint32_t* winbits, const int32_t* seg_order,
+                            uint16_t* ln_out_packed, void* stream);
+int bl_act_bwd_impl(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act, bl_dropout_t drop,
+                    float* g_z, float* g_bias, uint16_t* g_z_packed, void* stream);
+
 #define BL_CHECK_ARG(cond, ...)   \
   do {                            \
     if (!(cond)) {                \

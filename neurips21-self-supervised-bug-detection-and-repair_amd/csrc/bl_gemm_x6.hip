@@ -162,15 +162,26 @@ __device__ __forceinline__ uint4 keep_from_bits(uint32_t b) {
   return k;
 }
 
+// optional epilogue of the row GEMM: C = drop(act(A . B + bias)) -- the dense node update of the message-passing layer
+// (ptgnn MlpMessagePassingLayer's Linear -> tanh -> Dropout tail; call site buglab/models/gnnlayerdefs.py:6-23)
+struct X6Epi {
+  const float* bias;  // [N] or nullptr
+  int act;            // BL_ACT_*
+  uint32_t drop_key, drop_thresh;
+  float drop_scale;
+};
+
 // The plain form fits three workgroups per CU (3 x 52 KB of LDS, <= 168 registers); the routed form
 // keeps its routing bytes and masks in registers and runs two.
-template <bool MASKED>
+// EPI: -1 = no epilogue, else the activation code (a template parameter: with a run-time switch the compiler evaluates
+// every activation's libm call for every element -- measured 0.12 vs 0.05 ms on the c2 dense shape)
+template <bool MASKED, int EPI>
 __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
     int koff1, int koff2, int nsrc, const uint32_t* __restrict__ win_bits, int ld_bits, const uint4* __restrict__ bp,
     long long strideB, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G, int M, int N, int K,
-    float* __restrict__ c, int ldc, int xcd_remap) {
+    float* __restrict__ c, int ldc, int xcd_remap, X6Epi epi) {
   __shared__ uint4 As[XBM * XROW];
   __shared__ uint4 Bs[XBN * XROW];
 
@@ -306,8 +317,21 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
       for (int gq = 0; gq < 4; ++gq) {
         const int n = n0 + wn * 64 + tj * 32 + 8 * gq + 4 * half;
         if (n >= N) continue;
-        *reinterpret_cast<float4*>(crow + n) =
-            make_float4(acc[ti][tj][4 * gq + 0], acc[ti][tj][4 * gq + 1], acc[ti][tj][4 * gq + 2], acc[ti][tj][4 * gq + 3]);
+        float v[4] = {acc[ti][tj][4 * gq + 0], acc[ti][tj][4 * gq + 1], acc[ti][tj][4 * gq + 2], acc[ti][tj][4 * gq + 3]};
+        if (EPI >= 0) {
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (epi.bias) bv = *reinterpret_cast<const float4*>(epi.bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v[u] = bl_act(EPI, v[u]);
+            if (epi.drop_thresh) {  // same counter as the fp32 row GEMM: element index row * N + column
+              const uint32_t idx = (uint32_t)(row0 + m) * (uint32_t)N + (uint32_t)(n + u);
+              v[u] = ((bl_lowbias32(idx + epi.drop_key) >> 8) >= epi.drop_thresh) ? v[u] * epi.drop_scale : 0.f;
+            }
+          }
+        }
+        *reinterpret_cast<float4*>(crow + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
   }
 }
@@ -336,6 +360,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const short* p) {
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+template <bool ROUTED>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
   const int awg = (aj == 0 ? w0 : (aj == 1 ? w1 : w2)) >> 3;  // uint4 per plane of an A row
   const int gwg = N >> 3;                                      // uint4 per plane of a G row
   const uint4* __restrict__ gbase = gp + (nnc >> 3);
-  const uint32_t* __restrict__ mbase = win_bits + (nnc >> 5);
+  const uint32_t* __restrict__ mbase = ROUTED ? win_bits + (nnc >> 5) : nullptr;
   const int mshift = nnc & 31;
 
   uint4 ra[2][3], rb[2][3];
@@ -380,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
       const int e_ = (k0_) + msg0 + 16 * i;                        \
       const int ec_ = e_ < e1 ? e_ : e0;                           \
       arow[i] = aidx ? aidx[ec_] : ec_;                            \
-      grow[i] = g_idx[ec_];                                        \
+      grow[i] = g_idx ? g_idx[ec_] : ec_;                          \
       mrow[i] = ec_;                                               \
     }                                                              \
   }
@@ -395,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
       rb[i][0] = g_[0];                                                                          \
       rb[i][1] = g_[gwg];                                                                        \
       rb[i][2] = g_[2 * gwg];                                                                    \
-      mk[i] = mbase[(size_t)mrow[i] * ld_bits];                                                  \
+      mk[i] = ROUTED ? mbase[(size_t)mrow[i] * ld_bits] : 0u;                                    \
     }                                                                                            \
   }
 #define WX6_STORE_STAGE(k0_)                                                                     \
@@ -403,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
       const int eid_ = (k0_) + msg0 + 16 * i;                                                    \
       const bool eok_ = eid_ < e1;                                                               \
-      uint4 keep_ = keep_from_bits(mk[i] >> mshift);                                             \
+      uint4 keep_ = ROUTED ? keep_from_bits(mk[i] >> mshift) : make_uint4(~0u, ~0u, ~0u, ~0u);   \
       if (!(eok_ && b_ok)) keep_ = make_uint4(0u, 0u, 0u, 0u);                                   \
       const int slot_ = (msg0 + 16 * i) * WRS + 8 * fg;                                          \
       _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
@@ -520,64 +545,64 @@ extern "C" int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t 
   return BL_OK;
 }
 
-extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
-                               int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G,
-                               int32_t M, int32_t N, int32_t K, float* c, int32_t ldc, void* stream) {
+namespace {
+int gemm_rows_x6_impl(const char* who, const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
+                      int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M, int32_t N,
+                      int32_t K, const X6Epi* epi, float* c, int32_t ldc, void* stream) {
   if (M == 0) return BL_OK;
-  BL_CHECK_ARG(a && a->nsrc >= 1 && a->nsrc <= 3, "bl_gemm_rows_x6: rows descriptor needs 1..3 sources");
+  BL_CHECK_ARG(a && a->nsrc >= 1 && a->nsrc <= 3, "%s: rows descriptor needs 1..3 sources", who);
   int off = 0, koff[3] = {0, 0, 0};
   for (int j = 0; j < a->nsrc; ++j) {
     BL_CHECK_ARG(a->xp[j] && bl_aligned16(a->xp[j]) && a->width[j] > 0 && a->width[j] % 32 == 0,
-                 "bl_gemm_rows_x6: source %d: packed pointer 16-byte aligned and width a multiple of 32 required", j);
+                 "%s: source %d: packed pointer 16-byte aligned and width a multiple of 32 required", who, j);
     koff[j] = off;
     off += a->width[j];
   }
-  BL_CHECK_ARG(off == K, "bl_gemm_rows_x6: K (%d) != sum of source widths (%d)", K, off);
+  BL_CHECK_ARG(off == K, "%s: K (%d) != sum of source widths (%d)", who, K, off);
   BL_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0 && bp && c && bl_aligned16(bp) && bl_aligned16(c),
-               "bl_gemm_rows_x6: N/ldc multiples of 4, aligned pointers required");
+               "%s: N/ldc multiples of 4, aligned pointers required", who);
   BL_CHECK_ARG(b_group_stride % 8 == 0 && (G <= 1 || b_group_stride >= (int64_t)((N + 127) / 128) * (K / 32) * 12288),
-               "bl_gemm_rows_x6: packed group stride must cover one group's tiled weights (bl_pack_weights_x6)");
+               "%s: packed group stride must cover one group's tiled weights (bl_pack_weights_x6)", who);
   BL_CHECK_ARG(win_bits == nullptr || (a->nsrc == 1 && a->idx[0] && ld_bits * 32 >= K),
-               "bl_gemm_rows_x6: the routed form needs exactly one gathered source and ld_bits >= K / 32");
+               "%s: the routed form needs exactly one gathered source and ld_bits >= K / 32", who);
+  BL_CHECK_ARG(!(win_bits && epi), "%s: the routed form has no epilogue", who);
   dim3 grid((M + XBM - 1) / XBM + (group_ptr ? G : 0), (N + XBN - 1) / XBN);
   const int xcd = 1;  // XCD-contiguous tile order (x6_locate)
   const uint4* x0 = reinterpret_cast<const uint4*>(a->xp[0]);
   const uint4* x1 = a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr;
   const uint4* x2 = a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr;
+  X6Epi e = {nullptr, BL_ACT_NONE, 0u, 0u, 1.f};
+  if (epi) e = *epi;
 #define X6_ARGS                                                                                                          \
   x0, x1, x2, a->idx[0], a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],              \
       a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc, win_bits, ld_bits,        \
-      reinterpret_cast<const uint4*>(bp), (long long)(b_group_stride / 8), group_ptr, group_w, G, M, N, K, c, ldc, xcd
+      reinterpret_cast<const uint4*>(bp), (long long)(b_group_stride / 8), group_ptr, group_w, G, M, N, K, c, ldc, xcd, e
   if (win_bits)
-    hipLaunchKernelGGL((gemm_rows_x6_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
-  else
-    hipLaunchKernelGGL((gemm_rows_x6_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
-  BL_LAUNCH_CHECK("bl_gemm_rows_x6");
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<true, -1>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else if (epi == nullptr)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false, -1>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else if (e.act == BL_ACT_TANH)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false, BL_ACT_TANH>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else if (e.act == BL_ACT_RELU)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false, BL_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else if (e.act == BL_ACT_SIGMOID)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false, BL_ACT_SIGMOID>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else if (e.act == BL_ACT_NONE)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false, BL_ACT_NONE>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else {
+    bl_set_error("%s: activation %d has no bf16x6 epilogue (none / relu / sigmoid / tanh)", who, e.act);
+    return BL_EINVAL;
+  }
+  BL_LAUNCH_CHECK(who);
   return BL_OK;
 }
 
-extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_packed, const int32_t* g_idx,
-                                       const uint32_t* win_bits, int32_t ld_bits, const int32_t* group_ptr,
-                                       const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
-                                       int64_t gw_group_stride, int32_t ld_gw, void* stream) {
-  if (M == 0) return BL_OK;
-  BL_CHECK_ARG(a && a->nsrc >= 1 && a->nsrc <= 3, "bl_gemm_wgrad_routed_x6: rows descriptor needs 1..3 sources");
-  int off = 0, koff[3] = {0, 0, 0};
-  for (int j = 0; j < a->nsrc; ++j) {
-    BL_CHECK_ARG(a->xp[j] && bl_aligned16(a->xp[j]) && a->width[j] > 0 && a->width[j] % 32 == 0,
-                 "bl_gemm_wgrad_routed_x6: source %d: packed pointer 16-byte aligned and width a multiple of 32 required", j);
-    koff[j] = off;
-    off += a->width[j];
-  }
-  BL_CHECK_ARG(off == K, "bl_gemm_wgrad_routed_x6: K (%d) != sum of source widths (%d)", K, off);
-  BL_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && g_node_packed && gw && bl_aligned16(g_node_packed),
-               "bl_gemm_wgrad_routed_x6: N a multiple of 32 and aligned pointers required");
-  BL_CHECK_ARG(g_idx && win_bits && ld_bits * 32 >= N, "bl_gemm_wgrad_routed_x6: needs g_idx and the winner bitmask (ld_bits >= N / 32)");
-  // rows reduced by one workgroup: an integer number of rounds of resident workgroups (see bl_gemm.hip)
+template <bool ROUTED>
+int wgrad_x6_resident() {
   static int resident = 0;
   if (resident == 0) {
     int per_cu = 0;
-    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_x6_kernel, 256, 0);
+    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_x6_kernel<ROUTED>, 256, 0);
     if (oe != hipSuccess || per_cu <= 0) per_cu = 2;
     int dev = 0, ncu = 256;
     hipDeviceProp_t prop;
@@ -585,6 +610,28 @@ extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t
       ncu = prop.multiProcessorCount;
     resident = per_cu * ncu;
   }
+  return resident;
+}
+
+int gemm_wgrad_x6_impl(const char* who, const bl_rows_packed_t* a, const uint16_t* g_packed, const int32_t* g_idx,
+                       const uint32_t* win_bits, int32_t ld_bits, const int32_t* group_ptr, const int32_t* group_w, int32_t G,
+                       int32_t M, int32_t N, int32_t K, float* gw, int64_t gw_group_stride, int32_t ld_gw, void* stream) {
+  if (M == 0) return BL_OK;
+  BL_CHECK_ARG(a && a->nsrc >= 1 && a->nsrc <= 3, "%s: rows descriptor needs 1..3 sources", who);
+  int off = 0, koff[3] = {0, 0, 0};
+  for (int j = 0; j < a->nsrc; ++j) {
+    BL_CHECK_ARG(a->xp[j] && bl_aligned16(a->xp[j]) && a->width[j] > 0 && a->width[j] % 32 == 0,
+                 "%s: source %d: packed pointer 16-byte aligned and width a multiple of 32 required", who, j);
+    koff[j] = off;
+    off += a->width[j];
+  }
+  BL_CHECK_ARG(off == K, "%s: K (%d) != sum of source widths (%d)", who, K, off);
+  BL_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && g_packed && gw && bl_aligned16(g_packed),
+               "%s: N a multiple of 32 and aligned pointers required", who);
+  const bool routed = win_bits != nullptr;
+  BL_CHECK_ARG(!routed || (g_idx && ld_bits * 32 >= N), "%s: the routed form needs g_idx and ld_bits >= N / 32", who);
+  // rows reduced by one workgroup: an integer number of rounds of resident workgroups (see bl_gemm.hip)
+  const int resident = routed ? wgrad_x6_resident<true>() : wgrad_x6_resident<false>();
   const int ntiles_n = (N + XBN - 1) / XBN;
   const int ntiles_all = ((K + XBM - 1) / XBM) * ntiles_n;
   const int extra = (group_ptr ? G : 0) * ntiles_all;
@@ -602,13 +649,50 @@ extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t
   dim3 grid((M + kchunk - 1) / kchunk + (group_ptr ? G : 0), ntiles_all);
   unsigned* order_ctr = group_w ? nullptr : bl_order_counters((group_ptr ? G : 1) * ntiles_all, stream);
   const int xcd = order_ctr ? 0 : 1;  // ordered flushes want "lower chunk = lower workgroup id"
-  hipLaunchKernelGGL(gemm_wgrad_x6_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const uint4*>(a->xp[0]), a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr,
-                     a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr, a->idx[0],
-                     a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],
-                     a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc,
-                     reinterpret_cast<const uint4*>(g_node_packed), g_idx, win_bits, ld_bits, group_ptr, group_w, G, M, N, K,
-                     kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n, xcd, order_ctr);
-  BL_LAUNCH_CHECK("bl_gemm_wgrad_routed_x6");
+#define WX6_ARGS                                                                                                               \
+  reinterpret_cast<const uint4*>(a->xp[0]), a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr,                  \
+      a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr, a->idx[0], a->nsrc > 1 ? a->idx[1] : nullptr,          \
+      a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0], a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1],   \
+      koff[2], a->nsrc, reinterpret_cast<const uint4*>(g_packed), g_idx, win_bits, ld_bits, group_ptr, group_w, G, M, N, K,     \
+      kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n, xcd, order_ctr
+  if (routed)
+    hipLaunchKernelGGL((gemm_wgrad_x6_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, WX6_ARGS);
+  else
+    hipLaunchKernelGGL((gemm_wgrad_x6_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, WX6_ARGS);
+  BL_LAUNCH_CHECK(who);
   return BL_OK;
+}
+}  // namespace
+
+extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
+                               int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G,
+                               int32_t M, int32_t N, int32_t K, float* c, int32_t ldc, void* stream) {
+  return gemm_rows_x6_impl("bl_gemm_rows_x6", a, win_bits, ld_bits, bp, b_group_stride, group_ptr, group_w, G, M, N, K, nullptr, c, ldc,
+                           stream);
+}
+
+extern "C" int bl_gemm_rows_x6_epi(const bl_rows_packed_t* a, const uint16_t* bp, int64_t b_group_stride, const int32_t* group_ptr,
+                                   const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, const float* bias,
+                                   int32_t act, bl_dropout_t drop, float* c, int32_t ldc, void* stream) {
+  BL_CHECK_ARG((uint64_t)M * (uint64_t)N < (1ull << 32) || drop.p <= 0.f, "bl_gemm_rows_x6_epi: dropout index space is 32 bit");
+  BL_CHECK_ARG(bias == nullptr || bl_aligned16(bias), "bl_gemm_rows_x6_epi: misaligned bias");
+  const bl_drop_dev d = bl_make_drop(drop);
+  X6Epi e = {bias, act, d.key, d.thresh, d.scale};
+  return gemm_rows_x6_impl("bl_gemm_rows_x6_epi", a, nullptr, 0, bp, b_group_stride, group_ptr, group_w, G, M, N, K, &e, c, ldc, stream);
+}
+
+extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_packed, const int32_t* g_idx,
+                                       const uint32_t* win_bits, int32_t ld_bits, const int32_t* group_ptr,
+                                       const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
+                                       int64_t gw_group_stride, int32_t ld_gw, void* stream) {
+  BL_CHECK_ARG(M == 0 || (g_idx && win_bits), "bl_gemm_wgrad_routed_x6: needs g_idx and the winner bitmask");
+  return gemm_wgrad_x6_impl("bl_gemm_wgrad_routed_x6", a, g_node_packed, g_idx, win_bits, ld_bits, group_ptr, group_w, G, M, N, K, gw,
+                            gw_group_stride, ld_gw, stream);
+}
+
+extern "C" int bl_gemm_wgrad_x6(const bl_rows_packed_t* a, const uint16_t* g_packed, const int32_t* g_idx, const int32_t* group_ptr,
+                                const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float* gw,
+                                int64_t gw_group_stride, int32_t ld_gw, void* stream) {
+  return gemm_wgrad_x6_impl("bl_gemm_wgrad_x6", a, g_packed, g_idx, nullptr, 0, group_ptr, group_w, G, M, N, K, gw, gw_group_stride, ld_gw,
+                            stream);
 }

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
                                                           float eps, float* __restrict__ ln_out,
                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                           float* __restrict__ dact, uint32_t* __restrict__ winbits,
-                                                          const int* __restrict__ seg_order) {
+                                                          const int* __restrict__ seg_order,
+                                                          uint32_t* __restrict__ ln_out_packed) {
   const int lane = threadIdx.x & 63;
   const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (slot >= nseg) return;
@@ -270,7 +271,22 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int d = lane + 64 * j;
-      if (d < D) ln_out[(size_t)seg * D + d] = (best[j] - mean) * rstd * ln_g[d] + ln_b[d];
+      const float y = d < D ? (best[j] - mean) * rstd * ln_g[d] + ln_b[d] : 0.f;
+      if (d < D && ln_out) ln_out[(size_t)seg * D + d] = y;
+      if (ln_out_packed) {
+        // bf16x3-packed copy (the operand form of the bf16x6 dense GEMMs; D % 8 == 0): even lanes store channel pairs
+        const float y1 = __shfl_down(y, 1, 64);
+        if (d < D && !(lane & 1)) {
+          uint16_t h0, m0, l0, h1, m1, l1;
+          split3(y, h0, m0, l0);
+          split3(y1, h1, m1, l1);
+          const int halfD = D >> 1;
+          uint32_t* o = ln_out_packed + (size_t)seg * 3 * halfD + (d >> 1);
+          o[0] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+          o[halfD] = (uint32_t)m0 | ((uint32_t)m1 << 16);
+          o[2 * halfD] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+      }
     }
     if (lane == 0) { mean_out[seg] = mean; rstd_out[seg] = rstd; }
   }
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const float* __restrict__ y, int nrows, int N,
                                                       int ld, int act, bl_drop_dev drop, float* g_z,
                                                       float* __restrict__ g_bias, int tpr_log2,
-                                                      unsigned* __restrict__ order_ctr) {
+                                                      unsigned* __restrict__ order_ctr, uint2* __restrict__ g_z_packed) {
   __shared__ float4 red[256];
   const int tpr = 1 << tpr_log2;
   const int tx = threadIdx.x & (tpr - 1), ty = threadIdx.x >> tpr_log2;
@@ -449,7 +465,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* g_y, const fl
           gg[u] *= bl_act_grad_from_out(act, yu);
         }
         const float4 g = make_float4(gg[0], gg[1], gg[2], gg[3]);
-        *reinterpret_cast<float4*>(g_z + (size_t)r * ld + c) = g;
+        if (g_z) *reinterpret_cast<float4*>(g_z + (size_t)r * ld + c) = g;
+        if (g_z_packed) {  // bf16x3-packed copy, rows N wide (the operand form of the bf16x6 dense GEMMs)
+          uint16_t h[4], m[4], l[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) split3(gg[u], h[u], m[u], l[u]);
+          const int q = N >> 2;  // uint2 (4 bf16) per plane of a row
+          uint2* o = g_z_packed + (size_t)r * 3 * q + (c >> 2);
+          o[0] = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+          o[q] = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
+          o[2 * q] = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+        }
         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
       }
     }
@@ -658,17 +684,28 @@ extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* se
                                   int32_t nseg, int32_t D, int32_t act, float* out, int32_t* arg, const float* ln_g,
                                   const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, float* dact,
                                   uint32_t* winbits, const int32_t* seg_order, void* stream) {
+  return bl_segment_max_fwd_impl(x, ldx, seg_ptr, seg_items, nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits,
+                                 seg_order, nullptr, stream);
+}
+
+// + ln_out_packed: the LayerNorm output also (or only: ln_out may then be NULL) in bl_pack_bf16x3's packed form
+int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg, int32_t D,
+                            int32_t act, float* out, int32_t* arg, const float* ln_g, const float* ln_b, float eps, float* ln_out,
+                            float* mean, float* rstd, float* dact, uint32_t* winbits, const int32_t* seg_order,
+                            uint16_t* ln_out_packed, void* stream) {
   if (nseg == 0) return BL_OK;
   BL_CHECK_ARG(seg_ptr && out, "bl_segment_max_fwd: null pointer");  // arg (the winner table) is optional
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
   BL_CHECK_ARG(act == BL_ACT_NONE || act == BL_ACT_GELU, "bl_segment_max_fwd: act must be NONE or GELU");
   const bool has_ln = ln_g != nullptr;
-  BL_CHECK_ARG(!has_ln || (ln_b && ln_out && mean && rstd), "bl_segment_max_fwd: LayerNorm outputs missing");
+  BL_CHECK_ARG(!has_ln || (ln_b && (ln_out || ln_out_packed) && mean && rstd), "bl_segment_max_fwd: LayerNorm outputs missing");
+  BL_CHECK_ARG(ln_out_packed == nullptr || (has_ln && D % 8 == 0), "bl_segment_max_fwd: the packed LayerNorm output needs D %% 8 == 0");
   dim3 grid((nseg + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define SEGMAX_GO(LN_, G2_)                                                                                                  \
   DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, LN_, G2_>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, \
-                                     act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order))
+                                     act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order,                \
+                                     reinterpret_cast<uint32_t*>(ln_out_packed)))
   if (has_ln) {
     if (act == BL_ACT_GELU) SEGMAX_GO(true, true) else SEGMAX_GO(true, false)
   } else {
@@ -712,8 +749,16 @@ extern "C" int bl_layernorm_bwd(const float* g_y, const float* x, const float* m
 
 extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act,
                           bl_dropout_t drop, float* g_z, float* g_bias, void* stream) {
+  BL_CHECK_ARG(nrows == 0 || g_z, "bl_act_bwd: null pointer");
+  return bl_act_bwd_impl(g_y, y, nrows, N, ld, act, drop, g_z, g_bias, nullptr, stream);
+}
+
+// + g_z_packed: the result also (or only: g_z may then be NULL) in bl_pack_bf16x3's packed form, rows N wide
+int bl_act_bwd_impl(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act, bl_dropout_t drop,
+                    float* g_z, float* g_bias, uint16_t* g_z_packed, void* stream) {
   if (nrows == 0) return BL_OK;
-  BL_CHECK_ARG(g_y && y && g_z, "bl_act_bwd: null pointer");
+  BL_CHECK_ARG(g_y && y && (g_z || g_z_packed), "bl_act_bwd: null pointer");
+  BL_CHECK_ARG(g_z_packed == nullptr || (N % 8 == 0 && bl_aligned16(g_z_packed)), "bl_act_bwd: the packed output needs N %% 8 == 0");
   BL_CHECK_ARG(N > 0 && N % 4 == 0 && ld % 4 == 0, "bl_act_bwd: N/ld multiples of 4");
   BL_CHECK_ARG(act != BL_ACT_GELU, "bl_act_bwd: GELU needs the pre-activation (use bl_segment_max_bwd)");
   int tpr_log2 = 0;
@@ -721,7 +766,8 @@ extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32
   const int gy = (N / 4 + (1 << tpr_log2) - 1) >> tpr_log2;
   dim3 grid(min((nrows + ACT_BWD_ROWS - 1) / ACT_BWD_ROWS, max(1, ACT_BWD_MAX_BLOCKS / gy)), gy);
   hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g_y, y, nrows, N, ld, act,
-                     bl_make_drop(drop), g_z, g_bias, tpr_log2, g_bias ? bl_order_counters(gy, stream) : nullptr);
+                     bl_make_drop(drop), g_z, g_bias, tpr_log2, g_bias ? bl_order_counters(gy, stream) : nullptr,
+                     reinterpret_cast<uint2*>(g_z_packed));
   BL_LAUNCH_CHECK("bl_act_bwd");
   return BL_OK;
 }

@@ -108,7 +108,7 @@ struct Saved {  // forward -> backward
   float* agg;        // [N, Dm]
   float* mean;       // [N]
   float* rstd;       // [N]
-  float* ln_out;     // [N, Dm]
+  float* ln_out;     // [N, Dm] fp32, or (dense node update as bf16x6) the bf16x3-packed form [N, 3 Dm] in the same region
   size_t bytes;
 };
 Saved carve_saved(void* base, int N, int E, int Din, int Dm, int msg_act) {
@@ -122,12 +122,12 @@ Saved carve_saved(void* base, int N, int E, int Din, int Dm, int msg_act) {
   s.agg = (float*)take((size_t)N * Dm * 4);
   s.mean = (float*)take((size_t)N * 4);
   s.rstd = (float*)take((size_t)N * 4);
-  s.ln_out = (float*)take((size_t)N * Dm * 4);
+  s.ln_out = (float*)take((size_t)N * Dm * 6);
   s.bytes = o;
   return s;
 }
 struct WsBwd {
-  float* g_z;      // [N, Dout]
+  float* g_z;      // [N, Dout] fp32, or its bf16x3-packed form [N, 3 Dout] (same region)
   float* g_ln;     // [N, Dm]
   uint16_t* gqp;   // [N, 3 Dm]
   float* g_a;      // [E, 2 Din]
@@ -138,7 +138,7 @@ WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool with_g
   char* p = (char*)base;
   size_t o = 0;
   auto take = [&](size_t b) { char* q = p ? p + o : nullptr; o += al(b); return q; };
-  w.g_z = (float*)take((size_t)N * Dout * 4);
+  w.g_z = (float*)take((size_t)N * Dout * 6);
   w.g_ln = (float*)take((size_t)N * Dm * 4);
   w.gqp = (uint16_t*)take((size_t)N * 3 * Dm * 2);
   w.g_a = with_ga ? (float*)take((size_t)E * 2 * Din * 4) : nullptr;
@@ -214,18 +214,29 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
     ProfScope ps(1, 2.0 * E * (2.0 * Din) * Dm, st, false);
     BL_TRY(bl_gemm_rows_x6(&a, nullptr, 0, w_packed, wstride, L->type_ptr, nullptr, T, E, Dm, 2 * Din, pre, Dm, st));
   }
+  // dense node update on the bf16x6 path when the caller packed Wd (bl_pack_weights_x6(Wd, 1, Dm, Dout, w_is_kn = 1)): the
+  // LayerNorm epilogue of the segmented max then emits its result in packed form and no fp32 copy is kept
+  const bool dense_x6 = L->Wd_packed != nullptr && Dm % 32 == 0 && Dout % 32 == 0;
   {
     ProfScope ps(2, 0.0, st, false);
     // (E == 0: every segment is empty and the kernel never dereferences `pre`)
-    BL_TRY(bl_segment_max_fwd(pre, Dm, L->tgt_ptr, L->tgt_msgs, N, Dm, L->msg_act, S.agg, winner_out, L->ln_g,
-                              L->ln_b, L->ln_eps, S.ln_out, S.mean, S.rstd, S.dact, S.bits, L->node_order, st));
+    BL_TRY(bl_segment_max_fwd_impl(pre, Dm, L->tgt_ptr, L->tgt_msgs, N, Dm, L->msg_act, S.agg, winner_out, L->ln_g, L->ln_b,
+                                   L->ln_eps, dense_x6 ? nullptr : S.ln_out, S.mean, S.rstd, S.dact, S.bits, L->node_order,
+                                   dense_x6 ? (uint16_t*)S.ln_out : nullptr, st));
   }
-  bl_rows_t d;
-  d.x[0] = S.ln_out; d.idx[0] = nullptr; d.ld[0] = Dm; d.width[0] = Dm; d.nsrc = 1;
-  d.x[1] = d.x[2] = nullptr; d.idx[1] = d.idx[2] = nullptr; d.ld[1] = d.ld[2] = 0; d.width[1] = d.width[2] = 0;
   {
     ProfScope ps(3, 2.0 * N * (double)Dm * Dout, st, false);
-    BL_TRY(bl_gemm_rows(&d, L->Wd, 0, Dout, 0, L->bd, nullptr, nullptr, 1, N, Dout, Dm, BL_ACT_TANH, L->drop, h_out, Dout, st));
+    if (dense_x6) {
+      bl_rows_packed_t d;
+      d.xp[0] = (const uint16_t*)S.ln_out; d.xp[1] = d.xp[2] = nullptr; d.idx[0] = d.idx[1] = d.idx[2] = nullptr;
+      d.width[0] = Dm; d.width[1] = d.width[2] = 0; d.nsrc = 1;
+      BL_TRY(bl_gemm_rows_x6_epi(&d, L->Wd_packed, 0, nullptr, nullptr, 1, N, Dout, Dm, L->bd, BL_ACT_TANH, L->drop, h_out, Dout, st));
+    } else {
+      bl_rows_t d;
+      d.x[0] = S.ln_out; d.idx[0] = nullptr; d.ld[0] = Dm; d.width[0] = Dm; d.nsrc = 1;
+      d.x[1] = d.x[2] = nullptr; d.idx[1] = d.idx[2] = nullptr; d.ld[1] = d.ld[2] = 0; d.width[1] = d.width[2] = 0;
+      BL_TRY(bl_gemm_rows(&d, L->Wd, 0, Dout, 0, L->bd, nullptr, nullptr, 1, N, Dout, Dm, BL_ACT_TANH, L->drop, h_out, Dout, st));
+    }
   }
   return BL_OK;
 }
@@ -250,26 +261,42 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   const bool fused_sums = vec_dgrad && !bl_get_deterministic();
   WsBwd B = carve_bwd(ws, N, E, Din, Dm, Dout, !fused_sums);
 
-  {  // y = drop(tanh(z)): g_z, bias gradient
+  // dense node update on the bf16x6 path: forward must have run with Wd_packed too (it decides the form of `saved`)
+  const bool dense_x6 = L->Wd_packed != nullptr && L->Wd_packed_bwd != nullptr && Dm % 32 == 0 && Dout % 32 == 0;
+  BL_CHECK_ARG(dense_x6 || L->Wd_packed == nullptr, "bl_mp_layer_bwd: Wd_packed given without Wd_packed_bwd");
+  {  // y = drop(tanh(z)): g_z (packed for the bf16x6 GEMMs), bias gradient
     ProfScope ps(4, 0.0, st, false);
-    BL_TRY(bl_act_bwd(g_out, h_out, N, Dout, Dout, BL_ACT_TANH, L->drop, B.g_z, g_bd, st));
+    BL_TRY(bl_act_bwd_impl(g_out, h_out, N, Dout, Dout, BL_ACT_TANH, L->drop, dense_x6 ? nullptr : B.g_z, g_bd,
+                           dense_x6 ? (uint16_t*)B.g_z : nullptr, st));
   }
   bl_rows_t r1;
   r1.x[1] = r1.x[2] = nullptr; r1.idx[0] = r1.idx[1] = r1.idx[2] = nullptr; r1.ld[1] = r1.ld[2] = 0; r1.width[1] = r1.width[2] = 0; r1.nsrc = 1;
+  bl_rows_packed_t p1;
+  p1.xp[1] = p1.xp[2] = nullptr; p1.idx[0] = p1.idx[1] = p1.idx[2] = nullptr; p1.width[1] = p1.width[2] = 0; p1.nsrc = 1;
   if (two) {
     (void)hipEventRecord(g_fork1, st);
     (void)hipStreamWaitEvent(side, g_fork1, 0);
   }
   {  // dense weight gradient, next to the input-gradient chain
     ProfScope ps(5, 2.0 * N * (double)Dm * Dout, side, two);
-    r1.x[0] = S.ln_out; r1.ld[0] = Dm; r1.width[0] = Dm;
-    BL_TRY(bl_gemm_wgrad(&r1, B.g_z, Dout, nullptr, nullptr, 1, N, Dout, Dm, g_Wd, 0, Dout, side));
+    if (dense_x6) {
+      p1.xp[0] = (const uint16_t*)S.ln_out; p1.width[0] = Dm;
+      BL_TRY(bl_gemm_wgrad_x6(&p1, (const uint16_t*)B.g_z, nullptr, nullptr, nullptr, 1, N, Dout, Dm, g_Wd, 0, Dout, side));
+    } else {
+      r1.x[0] = S.ln_out; r1.ld[0] = Dm; r1.width[0] = Dm;
+      BL_TRY(bl_gemm_wgrad(&r1, B.g_z, Dout, nullptr, nullptr, 1, N, Dout, Dm, g_Wd, 0, Dout, side));
+    }
   }
   {
     ProfScope ps(6, 2.0 * N * (double)Dm * Dout, st, two);
-    r1.x[0] = B.g_z; r1.ld[0] = Dout; r1.width[0] = Dout;
-    bl_dropout_t nodrop = {0.f, 0u, 0u};
-    BL_TRY(bl_gemm_rows(&r1, L->Wd, 0, Dout, 1, nullptr, nullptr, nullptr, 1, N, Dm, Dout, BL_ACT_NONE, nodrop, B.g_ln, Dm, st));
+    if (dense_x6) {
+      p1.xp[0] = (const uint16_t*)B.g_z; p1.width[0] = Dout;
+      BL_TRY(bl_gemm_rows_x6(&p1, nullptr, 0, L->Wd_packed_bwd, 0, nullptr, nullptr, 1, N, Dm, Dout, B.g_ln, Dm, st));
+    } else {
+      r1.x[0] = B.g_z; r1.ld[0] = Dout; r1.width[0] = Dout;
+      bl_dropout_t nodrop = {0.f, 0u, 0u};
+      BL_TRY(bl_gemm_rows(&r1, L->Wd, 0, Dout, 1, nullptr, nullptr, nullptr, 1, N, Dm, Dout, BL_ACT_NONE, nodrop, B.g_ln, Dm, st));
+    }
   }
   {  // LayerNorm backward x activation derivative at the winners -> packed d loss / d (winning pre-activation)
     ProfScope ps(7, 0.0, st, two);
