@@ -32,12 +32,12 @@ HBM_PEAK_GBS = 8000.0
 
 # rocprofv3 kernel names of the timed GEMM kinds (for the committed PMC traffic file)
 _KIND_TO_KERNEL = {
-    "gemm_rows_x6_grouped": "void gemm_rows_x6_kernel<false>",
-    "gemm_rows_nk_routed_x6_grouped": "void gemm_rows_x6_kernel<true>",
-    "gemm_wgrad_routed_x6": "gemm_wgrad_x6_kernel",
-    "msg_gemm_x6": "void gemm_rows_x6_kernel<false>",
-    "msg_dgrad_x6": "void gemm_rows_x6_kernel<true>",
-    "msg_wgrad_x6": "gemm_wgrad_x6_kernel",
+    "gemm_rows_x6_grouped": "void gemm_rows_x6_kernel<false, -1>",
+    "gemm_rows_nk_routed_x6_grouped": "void gemm_rows_x6_kernel<true, -1>",
+    "gemm_wgrad_routed_x6": "void gemm_wgrad_x6_kernel<true>",
+    "msg_gemm_x6": "void gemm_rows_x6_kernel<false, -1>",
+    "msg_dgrad_x6": "void gemm_rows_x6_kernel<true, -1>",
+    "msg_wgrad_x6": "void gemm_wgrad_x6_kernel<true>",
 }
 
 
@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--serial", action="store_true", help="weight-gradient GEMMs on the main stream everywhere (no side-stream overlap): the run "
                     "whose rocprofv3 --kernel-trace --stats averages are the exclusive kernel times the roofline quotes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce per step instead of layer-wise buckets behind backward")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under `also` (configs[2] shard, seq-great)")
     ap.add_argument("--no-predict", action="store_true", help="skip the forward-only passes after the timed training steps (profiling)")
     args = ap.parse_args()
     seq = args.model == "seq-great"
@@ -197,39 +199,86 @@ def main():
     if args.serial:
         hip_ops.USE_SIDE_STREAM = False
 
-    torch.manual_seed(0)  # identical initial weights on every rank
-    if seq:
-        # BASELINE configs[4]: every sequence has --seq-len tokens (1-6 subtokens each), 2 relations per token over 8 edge
-        # kinds, 40 candidate locations and the usual rewrite candidates; laid out by the product's own padded collator
-        from buglab.models.layers.messagepassing import SubtokenEmbedder
-        from buglab.models.seqmodel import SeqBugLabModule, SeqTensorizedSample, SequenceEncoder, collate_sequences
+    def build_workload(a):
+        """(module, minibatch, optimiser) of one configuration: resident synthetic minibatch, random-init weights."""
+        torch.manual_seed(0)  # identical initial weights on every rank
+        if a.model == "seq-great":
+            # BASELINE configs[4]: every sequence has --seq-len tokens (1-6 subtokens each), 2 relations per token over 8 edge
+            # kinds, 40 candidate locations and the usual rewrite candidates; laid out by the product's own padded collator
+            from buglab.models.layers.messagepassing import SubtokenEmbedder
+            from buglab.models.seqmodel import SeqBugLabModule, SeqTensorizedSample, SequenceEncoder, collate_sequences
 
-        samples = make_samples(args.graphs, seed=1000 + rank, num_nodes=args.seq_len, num_messages=2 * args.seq_len, num_edge_types=args.types)
-        mb = to_device(collate_sequences([SeqTensorizedSample(s, {}, ()) for s in samples], args.types), device)
-        enc = SequenceEncoder(SubtokenEmbedder(15000, args.hidden, 6, args.dropout), args.hidden, args.types, args.layers, 8,
-                              4 * args.hidden, args.dropout, layer_type="great")
-        module = SeqBugLabModule(enc, 48).to(device).train()
-        module._dropout_base_seed = rank
-    else:
-        samples = make_samples(args.graphs, seed=1000 + rank, num_nodes=args.nodes, num_messages=args.messages, num_edge_types=args.types,
-                               degree=args.degree, max_degree=512)
-        mb = to_device(collate_samples(samples, args.types), device)
-        module = build_gnn_mlp_module(args.hidden, args.layers, args.types, dropout_rate=args.dropout, dropout_base_seed=rank).to(device).train()
-    opt = FlatAdam(module.parameters())
-    if world > 1:
-        opt.broadcast_parameters(0)  # what the trainer does before its first step
-
-    def step():
-        opt.zero_grad()
-        loss = module(**mb)
-        loss.backward()
-        if world > 1:
-            # the trainer's data-parallel step: ONE all-reduce of [graphs x gradient | graphs, has-batch flag], the fused
-            # clip + Adam divides by the global graph count on the device
-            opt.step_data_parallel(args.graphs)
+            samples = make_samples(a.graphs, seed=1000 + rank, num_nodes=a.seq_len, num_messages=2 * a.seq_len, num_edge_types=a.types)
+            mb_ = to_device(collate_sequences([SeqTensorizedSample(s, {}, ()) for s in samples], a.types), device)
+            enc = SequenceEncoder(SubtokenEmbedder(15000, a.hidden, 6, a.dropout), a.hidden, a.types, a.layers, 8,
+                                  4 * a.hidden, a.dropout, layer_type="great")
+            module_ = SeqBugLabModule(enc, 48).to(device).train()
+            module_._dropout_base_seed = rank
         else:
-            opt.step()
-        return loss
+            samples = make_samples(a.graphs, seed=1000 + rank, num_nodes=a.nodes, num_messages=a.messages, num_edge_types=a.types,
+                                   degree=a.degree, max_degree=512)
+            mb_ = to_device(collate_samples(samples, a.types), device)
+            module_ = build_gnn_mlp_module(a.hidden, a.layers, a.types, dropout_rate=a.dropout, dropout_base_seed=rank).to(device).train()
+        opt_ = FlatAdam(module_.parameters())
+        if world > 1:
+            opt_.broadcast_parameters(0)  # what the trainer does before its first step
+            if hasattr(module_, "overlap_parameter_groups") and not args.no_overlap:
+                opt_.set_overlap_groups(module_.overlap_parameter_groups())  # layer-wise gradient buckets behind the backward pass
+        return module_, mb_, opt_
+
+    def make_step(module_, mb_, opt_, graphs):
+        def step_():
+            opt_.zero_grad()
+            if world > 1:
+                opt_.begin_data_parallel_step(graphs)
+            loss_ = module_(**mb_)
+            loss_.backward()
+            if world > 1:
+                # the trainer's data-parallel step: ONE all-reduce of [graphs x gradient | graphs, has-batch flag], the fused
+                # clip + Adam divides by the global graph count on the device
+                opt_.step_data_parallel(graphs)
+            else:
+                opt_.step()
+            return loss_
+        return step_
+
+    def timed(step_, steps, warmup):
+        for _ in range(warmup):
+            step_()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for _ in range(steps):
+            loss_ = step_()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return D.max_over_ranks(time.perf_counter() - t0_, device), loss_
+
+    def side_config(**over):
+        """One more BASELINE configuration, timed the same way (warm-up, barrier + synchronize on both sides, max over
+        ranks) AFTER the headline run, on its own model and minibatch: reported under `also`, never as `value`."""
+        import copy
+        import gc
+
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        m_, mb2_, o_ = build_workload(a)
+        el_, _ = timed(make_step(m_, mb2_, o_, a.graphs), args.steps, args.warmup)
+        hip_ops.join_side_stream()
+        torch.cuda.synchronize()
+        del m_, mb2_, o_
+        gc.collect()
+        torch.cuda.empty_cache()
+        unit = "sequences/s" if a.model == "seq-great" else "graphs/s"
+        return {"value": round(a.graphs * world * args.steps / el_, 2), "unit": unit, "ms_per_step": round(1e3 * el_ / args.steps, 3),
+                "per_gpu": a.graphs, "n_gpus": world}
+
+    module, mb, opt = build_workload(args)
+
+    step = make_step(module, mb, opt, args.graphs)
 
     for _ in range(args.warmup):
         step()
@@ -296,6 +345,23 @@ def main():
             torch.cuda.synchronize()
             predict_elapsed = D.max_over_ranks(time.perf_counter() - tp, device)
     module.train()
+
+    # The other BASELINE configurations the driver's one command should also put a number on (every rank runs them: the
+    # optimiser all-reduces): configs[2]'s per-GPU shard (hidden 256, 32 graphs per GPU -- 256 graphs over 8 GPUs) and, on
+    # one GPU, configs[4] (seq-great).  Each on its own model / minibatch after the headline run has been measured.
+    also = {}
+    if not args.no_also and not seq and args.hidden == 128 and args.degree == "uniform":
+        hip_ops.join_side_stream()
+        torch.cuda.synchronize()
+        del module, mb, opt, step
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        also["configs[2] gnn-mlp hidden=256 layers=8 edge_types=16 batch=32 graphs/GPU"] = side_config(hidden=256, graphs=32)
+        if world == 1:
+            also["configs[4] seq-great hidden=256 layers=5 heads=8 ff=1024 batch=32 sequences x 512 tokens"] = side_config(
+                model="seq-great", hidden=256, graphs=32, layers=5, types=8, dropout=0.1)
 
     if rank == 0:
         total_graphs = args.graphs * world * args.steps
@@ -373,6 +439,7 @@ def main():
             },
             "predict_graphs_per_s": None if predict_elapsed is None else round(args.graphs * world * args.steps / predict_elapsed, 1),  # forward-only, eval mode
             "roofline": roof,
+            "also": also or None,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else (cpu_baseline_seq(args) if seq else cpu_baseline(args)),
         }
         print(json.dumps(line), flush=True)

@@ -100,6 +100,13 @@ class GnnBugLabModule(ModuleWithMetrics):
                                head_idx_references={k: local[s : s + n] for k, (s, n) in spans.items()})
         return out
 
+    def overlap_parameter_groups(self):
+        """Parameter lists, one per message-passing layer in forward order: the units whose gradient all-reduce a
+        data-parallel run starts as soon as that layer's backward has been launched (runtime/optim.py)."""
+        from buglab.models.layers.messagepassing import MlpMessagePassingLayer
+
+        return [list(l.parameters()) for l in self._gnn.message_passing_layers if isinstance(l, MlpMessagePassingLayer)]
+
     @staticmethod
     def _head_inputs(gnn_output: GnnOutput):
         if gnn_output.head_node_representations is not None:

@@ -930,6 +930,8 @@ class _MpLayerFused(torch.autograd.Function):
                                    saved.data_ptr(), ws.data_ptr() if E > 0 else None, _stream()), "bl_mp_layer_fwd")
         if winner is not None:
             WINNER_SINK.append(winner)
+        if need_bwd:
+            _note_use((W, ln_g, ln_b, Wd, bd))
         ctx.saved = (h_lo.shape[1], h_hi.shape[1] if h_hi is not None else 0, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk,
                      dense_x6, wd_kn, wd_nk)
         return out
@@ -982,7 +984,47 @@ class _MpLayerFused(torch.autograd.Function):
             _free_running = True
             _held_for_side_stream.extend((saved, ws))
         ret = [None if d is not None else t for d, t in zip(direct, tgt)]
+        if all(d is not None for d in direct):  # (gradients returned through autograd are not in place yet)
+            _notify_backward_launched((W, ln_g, ln_b, Wd, bd))
         return g_lo, g_hi, ret[4], ret[1], ret[2], ret[3], ret[0], None, None, None
+
+
+# ---- "the backward of this layer has been launched" notifications (data-parallel gradient buckets, runtime/optim.py) ----
+GRAD_READY_CALLBACK = None
+_pending_uses = {}  # id(param) -> forward uses whose backward has not been launched yet (weight sharing)
+
+
+def set_grad_ready_callback(fn) -> None:
+    """fn(list of parameters) is called from a message-passing layer's backward once every kernel that adds into those
+    parameters' gradients has been LAUNCHED (on the training stream or the side stream); None switches it off."""
+    global GRAD_READY_CALLBACK
+    GRAD_READY_CALLBACK = fn
+    _pending_uses.clear()
+
+
+def side_stream_if_any():
+    return _side_streams.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
+
+
+def _note_use(params) -> None:
+    if GRAD_READY_CALLBACK is not None:
+        for p in params:
+            _pending_uses[id(p)] = _pending_uses.get(id(p), 0) + 1
+
+
+def _notify_backward_launched(params) -> None:
+    if GRAD_READY_CALLBACK is None:
+        return
+    done = []
+    for p in params:
+        n = _pending_uses.get(id(p), 1) - 1
+        if n <= 0:
+            _pending_uses.pop(id(p), None)
+            done.append(p)
+        else:
+            _pending_uses[id(p)] = n
+    if done:
+        GRAD_READY_CALLBACK(done)
 
 
 def fused_layer_ok(Din: int, Dm: int) -> bool:

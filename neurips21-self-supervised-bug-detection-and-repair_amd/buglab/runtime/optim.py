@@ -37,7 +37,9 @@ class FlatAdam:
         self._tail_slot = 0
         self._last_dp_step_counted = False
         off = 0
+        self._span = {}  # id(param) -> (offset, padded size) in the flat buffers
         for p, n in zip(self.params, sizes):
+            self._span[id(p)] = (off, n)
             view = self.flat_param[off : off + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
@@ -54,6 +56,14 @@ class FlatAdam:
         self.eps = eps
         self.step_count = 0
         self.process_group = process_group
+        # layer-wise buckets of the data-parallel gradient reduction (set_overlap_groups); None: one all-reduce per step
+        self._buckets = None
+        self._rest = None
+        self._armed_B = None
+        self._issued = 0
+        self._bucket_left = None
+        self._works = []
+        self._comm_stream = None
 
     def zero_grad(self):
         hip_ops.join_side_stream()
@@ -103,6 +113,102 @@ class FlatAdam:
                 dist.broadcast(t, src=src, group=self.process_group)
             hip_ops.invalidate_weight_packs()
 
+    # ---- layer-wise buckets: the reduction of layer k's gradients runs while layers k-1 .. 1 are still in backward ------
+    def set_overlap_groups(self, groups) -> bool:
+        """`groups`: parameter lists in FORWARD order (one per message-passing layer), each contiguous in the flat buffer.
+        With them, `begin_data_parallel_step` + the kernels' "backward of this layer has been launched" notifications
+        (hip_ops.GRAD_READY_CALLBACK) start one all-reduce per group as soon as its gradients are complete -- in a FIXED
+        order (last group first), on a communication stream of its own; `step_data_parallel` reduces what is left (the
+        parameters outside the groups and the 4-float tail) and waits.  The plan depends on the model only, so every
+        rank -- also one that has no minibatch and never runs backward -- issues the same collectives in the same order.
+        Returns False (and keeps the single all-reduce) when a group is not contiguous."""
+        buckets = []
+        for g in groups:
+            spans = sorted(self._span[id(p)] for p in g if id(p) in self._span)
+            if not spans:
+                continue
+            for (o0, n0), (o1, _) in zip(spans, spans[1:]):
+                if o0 + n0 != o1:
+                    return False
+            buckets.append((spans[0][0], spans[-1][0] + spans[-1][1], [id(p) for p in g if id(p) in self._span]))
+        buckets.sort(key=lambda b: b[0])
+        for (_, hi, _), (lo, _, _) in zip(buckets, buckets[1:]):
+            if hi > lo:
+                return False
+        rest, pos = [], 0
+        for lo, hi, _ in buckets:
+            if lo > pos:
+                rest.append((pos, lo))
+            pos = hi
+        rest.append((pos, self.numel + self.TAIL))  # never empty: the tail rides on the last range
+        self._buckets, self._rest = buckets, rest
+        self._bucket_of = {pid: i for i, (_, _, ids) in enumerate(buckets) for pid in ids}
+        return True
+
+    def _dp_active(self) -> bool:
+        import torch.distributed as dist
+
+        return bool(self.distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1)
+
+    def begin_data_parallel_step(self, local_graphs: int) -> None:
+        """Call after zero_grad() and BEFORE the forward pass of a data-parallel step (optional: without it, or without
+        overlap groups, step_data_parallel does one all-reduce of the whole buffer)."""
+        self._armed_B = None
+        if self._buckets is None or not self._dp_active():
+            return
+        self._armed_B = int(local_graphs)
+        self._issued = 0
+        self._bucket_left = [len(ids) for _, _, ids in self._buckets]
+        self._works = []
+        if self._armed_B > 0:
+            hip_ops.set_grad_ready_callback(self._on_layer_backward_launched)
+
+    def _on_layer_backward_launched(self, params) -> None:
+        for p in params:
+            b = self._bucket_of.get(id(p))
+            if b is not None:
+                self._bucket_left[b] -= 1
+        self._issue_ready()
+
+    def _issue_ready(self, everything: bool = False) -> None:
+        # canonical order: last group first; a group is issued only after every later group has been
+        n = len(self._buckets)
+        while self._issued < n:
+            b = n - 1 - self._issued
+            if not everything and self._bucket_left[b] > 0:
+                return
+            lo, hi, _ = self._buckets[b]
+            self._all_reduce_range(lo, hi)
+            self._issued += 1
+
+    def _all_reduce_range(self, lo: int, hi: int) -> None:
+        import torch.distributed as dist
+
+        seg = self._grad_and_tail[lo:hi]
+        B = self._armed_B
+        if seg.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            # the gradients of this range are complete once everything launched so far on the training stream AND on the
+            # free-running side stream (weight-gradient GEMMs) has finished
+            comm = self._comm_stream
+            ev = torch.cuda.Event()
+            ev.record()
+            comm.wait_event(ev)
+            side = hip_ops.side_stream_if_any()
+            if side is not None:
+                ev2 = torch.cuda.Event()
+                ev2.record(side)
+                comm.wait_event(ev2)
+            with torch.cuda.stream(comm):
+                if B > 0 and lo < self.numel:
+                    self._grad_and_tail[lo:min(hi, self.numel)].mul_(float(B))
+                self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+        else:
+            if B > 0 and lo < self.numel:
+                self._grad_and_tail[lo:min(hi, self.numel)].mul_(float(B))
+            self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+
     def step_data_parallel(self, local_graphs: int) -> None:
         """One optimiser step of a data-parallel run.  Each rank calls it EVERY step, with the number of graphs of the
         minibatch it just back-propagated (0, with an untouched zero gradient buffer, when its loader is exhausted).
@@ -117,9 +223,23 @@ class FlatAdam:
         if B > 0:
             self.tail[0].fill_(float(B))  # fill kernels: a host tensor would have to be copied from pageable memory (blocking)
             self.tail[1].fill_(1.0)
-            self.flat_grad.mul_(float(B))
-        if self.distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
-            dist.all_reduce(self._grad_and_tail, op=dist.ReduceOp.SUM, group=self.process_group)
+        if self._armed_B is not None:
+            # bucketed form: the layer groups not reduced during backward (none, on a rank without a minibatch) in the same
+            # fixed order, then the ranges outside the groups with the tail; then wait for all of them
+            assert self._armed_B == B, "begin_data_parallel_step / step_data_parallel disagree on the number of graphs"
+            hip_ops.set_grad_ready_callback(None)
+            self._issue_ready(everything=True)
+            for lo, hi in self._rest:
+                self._all_reduce_range(lo, hi)
+            for w in self._works:
+                w.wait()
+            self._works = []
+            self._armed_B = None
+        else:
+            if B > 0:
+                self.flat_grad.mul_(float(B))
+            if self._dp_active():
+                dist.all_reduce(self._grad_and_tail, op=dist.ReduceOp.SUM, group=self.process_group)
         self.step_count += 1
         self._last_dp_step_counted = True
         self._apply_update_data_parallel()

@@ -267,11 +267,12 @@ class ModelTrainer:
                     if step > 0 and B == 0 and optimizer.previous_step_was_idle():
                         break
                     optimizer.zero_grad()
-                    B = 0
+                    B = int(mb["has_bug"].shape[0]) if mb is not None else 0
+                    if hasattr(optimizer, "begin_data_parallel_step"):
+                        optimizer.begin_data_parallel_step(B)  # layer-wise gradient buckets reduce during backward
                     if mb is not None:
                         loss = nn(**mb)
                         loss.backward()
-                        B = int(mb["has_bug"].shape[0])
                     optimizer.step_data_parallel(B)
                 else:
                     if not self._all_ranks_have(mb is not None, device):
@@ -384,6 +385,9 @@ class ModelTrainer:
                                "gradients are NOT clipped", self._clip, type(optimizer).__name__)
         self._restore_optimizer_state(optimizer, device)
         _, world = self._world()
+        if world > 1 and hasattr(optimizer, "set_overlap_groups") and hasattr(self._nn, "overlap_parameter_groups"):
+            # the gradient all-reduce goes layer by layer, behind the backward pass (runtime/optim.py::set_overlap_groups)
+            optimizer.set_overlap_groups(self._nn.overlap_parameter_groups())
         if world > 1:
             # replicas must be identical before the first step: rank 0's parameters (and moments) win
             if hasattr(optimizer, "broadcast_parameters"):

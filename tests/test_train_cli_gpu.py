@@ -137,3 +137,15 @@ def test_epoch_loop_with_loader_processes_under_fine_thread_interleaving(tmp_pat
     finally:
         sys.setswitchinterval(previous)
     assert all(bool(torch.isfinite(p).all()) for p in trainer.neural_module.parameters())
+
+
+def test_rccl_code_path_world_size_one():
+    """The `nccl` (= RCCL) backend's init / broadcast / gradient all-reduce / teardown of the data-parallel step, world size 1,
+    in a process of its own (tools/nccl_selftest.py): the only multi-GPU code the 1-GPU box can execute for real."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(29000 + os.getpid() % 2000))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_selftest.py")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "NCCL_SELFTEST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

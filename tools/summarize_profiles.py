@@ -36,7 +36,7 @@ for name in ("bench_serial", "bench", "bench_seq"):
     rows = list(csv.DictReader(open(path)))
     tot = sum(int(x["TotalDurationNs"]) for x in rows)
     # steps the process ran (warm-up + timed + bench.py's two profiling passes): one dropout-free marker per model
-    marker = "gemm_rows_x6_kernel<false>" if name != "bench_seq" else "masked_softmax_fwd_kernel"
+    marker = "gemm_rows_x6_kernel<false, -1>" if name != "bench_seq" else "masked_softmax_fwd_kernel"
     per_step = 8 if name != "bench_seq" else 5
     steps = next(int(x["Calls"]) for x in rows if marker in x["Name"]) / per_step
     print(f"--- {name}: kernel ms per step {tot / steps / 1e6:.3f}, {sum(int(x['Calls']) for x in rows) / steps:.0f} launches per step")
