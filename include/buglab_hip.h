@@ -280,6 +280,8 @@ typedef struct {
                                    * weight gradient; the same layer's backward call must then also carry ... */
   const uint16_t* Wd_packed_bwd;  /* ... bl_pack_weights_x6(Wd, 1, Dout, Dm, w_is_kn = 0), the form of g_ln = g_z . Wd^T.
                                    * NULL / NULL: exact-fp32 MFMA GEMMs (bl_gemm_rows / bl_gemm_wgrad) */
+  int32_t num_hub_slots;          /* how many leading entries of node_order may be hubs (nodes with very long target segments get
+                                   * a whole workgroup in the segmented max); < 0: unknown -- the first 4096 are looked at */
 } bl_mp_layer_t;
 
 /* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call.

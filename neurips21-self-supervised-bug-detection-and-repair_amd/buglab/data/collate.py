@@ -96,7 +96,7 @@ def segments_from_index(index: np.ndarray, num_segments: int):
 # reference-node families the scoring heads gather (localizationmodule.py:54-60, fixermodules.py:31-39, 65-73, 110-124)
 HEAD_REFERENCE_KEYS = ("candidate_nodes", "target_rewrite_nodes", "varmisused_node_ids", "candidate_symbol_node_ids",
                        "call_node_ids", "candidate_swapped_a", "candidate_swapped_b")
-HUB_DEGREE = 64  # nodes with more incident messages than this are processed first by the per-node kernels
+HUB_DEGREE = 32  # nodes with more incident messages than this are processed first by the per-node kernels
 TOKEN_CHUNK = 256  # occurrences of one token summed by one wave of the embedding-gradient kernel
 
 
@@ -268,6 +268,9 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
         "node_to_graph": node_to_graph,
         "num_nodes_per_graph": n_per_graph.astype(I32),
         "num_graphs": B,
+        # how many leading entries of node_order are hubs (more than HUB_DEGREE incident messages): the segmented max gives
+        # each of those with a long target segment a whole workgroup (csrc/bl_graph_ops.hip::segment_max_hub_kernel)
+        "num_hub_nodes": int(np.count_nonzero(np.diff(tgt_ptr).astype(np.int64) + np.diff(src_ptr) > HUB_DEGREE)),
         "candidate_ptr": cand_ptr.astype(I32),
         "reference_node_ids": ref_ids,
         "reference_node_graph_idx": ref_graph,
@@ -400,7 +403,7 @@ def pack_minibatch(mb: Dict[str, Any], out: Optional[np.ndarray] = None):
         "layout": layout, "total": total, "head_spans": dict(gd["head_spans"]), "num_graphs": int(gd["num_graphs"]),
         "num_nodes": int(gd["token_ids"].shape[0]), "num_messages": int(gd["msg_src"].shape[0]),
         "type_ptr_host": np.asarray(gd["type_ptr"], dtype=np.int64), "num_nodes_per_graph": np.asarray(gd["num_nodes_per_graph"]),
-        "num_repair_groups": int(mb["num_repair_groups"]),
+        "num_repair_groups": int(mb["num_repair_groups"]), "num_hub_nodes": int(gd.get("num_hub_nodes", -1)),
         "original_idxs": {k: mb[k] for k in ("text_rewrite_original_idxs", "candidate_rewrite_original_idxs", "pair_rewrite_original_idx")},
     }
     if "rewrite_logprobs" in mb:
@@ -451,6 +454,7 @@ def upload_packed(blob: np.ndarray, meta: Dict[str, Any], device) -> Dict[str, A
     out_gd["head_spans"] = dict(meta["head_spans"])
     for k in ("num_graphs", "num_nodes", "num_messages", "type_ptr_host", "num_nodes_per_graph"):
         out_gd[k] = meta[k]
+    out_gd["num_hub_nodes"] = meta.get("num_hub_nodes", -1)
     out_gd["_blob"] = dblob  # keeps the single allocation alive
     out["num_repair_groups"] = meta["num_repair_groups"]
     out.update(meta["original_idxs"])

@@ -44,7 +44,7 @@ class bl_mp_layer_t(Structure):
                 ("src_ptr", c_void_p), ("src_msgs", c_void_p), ("node_order", c_void_p),
                 ("W", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p), ("Wd", c_void_p), ("bd", c_void_p),
                 ("msg_act", c_int32), ("ln_eps", c_float), ("drop", bl_dropout_t), ("Wt", c_void_p),
-                ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p)]
+                ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p), ("num_hub_slots", c_int32)]
 
 
 _SIGNATURES = {
@@ -631,6 +631,7 @@ class GraphIndex(NamedTuple):
     num_messages: int
     num_types: int
     node_order: Optional[torch.Tensor] = None  # processing order of the per-node kernels: high-degree nodes first
+    num_hubs: int = -1  # leading entries of node_order that are hubs (-1: unknown, the kernels look at the first 4096)
 
 
 class _EmbedSubtokenMax(torch.autograd.Function):
@@ -890,6 +891,7 @@ def _layer_desc(g: "GraphIndex", W, ln_g, ln_b, Wd, bd, Din, msg_act, drop: Drop
     L.msg_src, L.msg_tgt, L.type_ptr = g.msg_src.data_ptr(), g.msg_tgt.data_ptr(), g.type_ptr.data_ptr()
     L.tgt_ptr, L.tgt_msgs, L.src_ptr, L.src_msgs = g.tgt_ptr.data_ptr(), g.tgt_msgs.data_ptr(), g.src_ptr.data_ptr(), g.src_msgs.data_ptr()
     L.node_order = _p(g.node_order)
+    L.num_hub_slots = int(g.num_hubs)
     L.W, L.ln_g, L.ln_b, L.Wd, L.bd = W.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), Wd.data_ptr(), bd.data_ptr()
     L.msg_act, L.ln_eps, L.drop = int(msg_act), 1e-5, drop.c()
     return L

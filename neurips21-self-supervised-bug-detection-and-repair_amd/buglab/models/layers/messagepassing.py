@@ -145,9 +145,9 @@ class GraphNeuralNetwork(nn.Module):
     def forward(self, *, token_ids, token_lens, msg_src, msg_tgt, type_ptr, tgt_ptr, tgt_msgs, src_ptr, src_msgs,
                 node_to_graph, reference_node_ids, reference_node_graph_idx, num_graphs, num_nodes, num_messages,
                 return_all_states: bool = False, dropout_seed: Optional[int] = None, tok_occ=None, tok_chunk_ptr=None,
-                tok_chunk_id=None, node_order=None, **_unused) -> GnnOutput:
+                tok_chunk_id=None, node_order=None, num_hub_nodes: int = -1, **_unused) -> GnnOutput:
         graph = GraphIndex(msg_src, msg_tgt, type_ptr, tgt_ptr, tgt_msgs, src_ptr, src_msgs, int(num_nodes),
-                           int(num_messages), int(type_ptr.shape[0]) - 1, node_order)
+                           int(num_messages), int(type_ptr.shape[0]) - 1, node_order, int(num_hub_nodes))
         training = self.training and dropout_seed is not None
         seed = int(dropout_seed or 0)
         mk = lambda rate, stream: Dropout(rate if training else 0.0, seed, stream)

@@ -138,40 +138,35 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
 // gelu(largest x) or gelu(smallest x).  The GELU form therefore tracks both extremes of the RAW messages and evaluates
 // two erf per (segment, channel) instead of one per (message, channel), and it has the winner's raw message at hand for
 // the derivative.  (A -inf message still gives gelu(-inf) = NaN, like the eager op.)
-template <int NV, bool HAS_LN, bool GELU2>
-__global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ x, int ldx,
-                                                          const int* __restrict__ seg_ptr,
-                                                          const int* __restrict__ seg_items, int nseg, int D, int act,
-                                                          float* __restrict__ out, int* __restrict__ arg,
-                                                          const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                          float eps, float* __restrict__ ln_out,
-                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                          float* __restrict__ dact, uint32_t* __restrict__ winbits,
-                                                          const int* __restrict__ seg_order,
-                                                          uint32_t* __restrict__ ln_out_packed) {
-  const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (slot >= nseg) return;
-  // seg_order (optional): processing order, long segments first -- a 512-item hub takes one wave about as
-  // long as the whole launch, so it must start at t = 0 instead of wherever its node id falls
-  const int seg = seg_order ? seg_order[slot] : slot;
-  const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
-  float best[NV], low[NV];
-  int barg[NV], larg[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; }
+// Segments longer than SEGMAX_HUB items among the first hub_slots entries of seg_order are "hubs": a whole workgroup
+// each (segment_max_hub_kernel: the waves scan contiguous shares); the wave-per-segment kernel skips exactly those.
+#define SEGMAX_HUB 40  // longer segments (among the hub candidates) get a 4-wave workgroup
+// (measured at BASELINE config c4, hidden 256: one wave per segment 3.06 ms per step; 4-wave hubs 2.39; 16-wave hubs 2.75;
+// 16 waves above 128 items + 4 waves below 2.76 -- the 1024-thread workgroups cost more to dispatch than their shorter
+// chains save)
+#define SEGMAX_HUB_SLOTS 4096  // hub_slots unknown to the caller: the first so many slots of seg_order are looked at
 
+__device__ __forceinline__ bool segmax_is_hub(const int* __restrict__ seg_ptr, int hub_slots, int slot, int seg) {
+  return slot < hub_slots && seg_ptr[seg + 1] - seg_ptr[seg] > SEGMAX_HUB;
+}
+
+// extremes of the items [beg, end) of one segment: best = largest (activated, unless GELU2) value and its item, low = smallest raw value
+template <int NV, bool GELU2>
+__device__ __forceinline__ void segmax_scan(const float* __restrict__ x, int ldx, const int* __restrict__ seg_items, int beg, int end, int D,
+                                            int act, float (&best)[NV], int (&barg)[NV], float (&low)[NV], int (&larg)[NV]) {
+  constexpr int U = NV <= 4 ? 8 : 4;  // rows in flight per step
+  const int lane = threadIdx.x & 63;
   for (int base = beg; base < end; base += 64) {
     const int cnt = min(64, end - base);
     const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
-    int i = 0;
-    // four rows in flight per step (independent loads), compared in item order (ties -> first item)
-    for (; i + 4 <= cnt; i += 4) {
-      int e[4];
-      float v[4][NV];
+    // U rows in flight per step (independent loads; a short last step re-reads the last row and ignores it, so that a
+    // segment of up to U items is ONE round trip), compared in item order (ties -> first item)
+    for (int i = 0; i < cnt; i += U) {
+      int e[U];
+      float v[U][NV];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        e[u] = __shfl(mine, i + u, 64);
+      for (int u = 0; u < U; ++u) {
+        e[u] = __shfl(mine, min(i + u, cnt - 1), 64);
         const float* __restrict__ row = x + (size_t)e[u] * ldx;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -180,9 +175,11 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u) {
+        if (i + u >= cnt) break;  // wave-uniform
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
+          if (lane + 64 * j >= D) continue;  // padding lanes keep barg = -1
           float t = v[u][j];
           if (GELU2) {
             if (t < low[j]) { low[j] = t; larg[j] = e[u]; }
@@ -191,26 +188,14 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
           }
           if (BL_MAX_WINS(t, best[j])) { best[j] = t; barg[j] = e[u]; }
         }
-    }
-    for (; i < cnt; ++i) {
-      const int e = __shfl(mine, i, 64);
-      const float* __restrict__ row = x + (size_t)e * ldx;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int d = lane + 64 * j;
-        if (d < D) {
-          float t = row[d];
-          if (GELU2) {
-            if (t < low[j]) { low[j] = t; larg[j] = e; }
-          } else if (act == BL_ACT_GELU) {
-            t = bl_gelu(t);
-          }
-          if (BL_MAX_WINS(t, best[j])) { best[j] = t; barg[j] = e; }
-        }
       }
     }
   }
-  float raw[NV];  // GELU form: the winner's message before the activation (its derivative is needed below)
+}
+
+// GELU form: decide between the two extremes; raw = the winner's message before the activation
+template <int NV, bool GELU2>
+__device__ __forceinline__ void segmax_pick(float (&best)[NV], int (&barg)[NV], const float (&low)[NV], const int (&larg)[NV], float (&raw)[NV]) {
   if (GELU2) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -221,26 +206,41 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
       if (gl > gh || gl != gl) { best[j] = gl; barg[j] = larg[j]; raw[j] = low[j]; }
     }
   }
-  if (winbits) {
-    // per ITEM bitmask of the channels it won (bit d of row `item`): the routed bf16x6 GEMMs of the
-    // backward pass read these 4 bytes per 32 channels instead of 128 bytes of the arg table
-    const int wpr = (D + 31) >> 5;
-    for (int base = beg; base < end; base += 64) {
-      const int cnt = min(64, end - base);
-      const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
-      for (int i = 0; i < cnt; ++i) {
-        const int e = __shfl(mine, i, 64);
-        uint32_t word = 0;  // lane w ends up holding word w of the item's mask: one store per item
+}
+
+// per ITEM bitmask of the channels it won (bit d of row `item`) for the items [beg, end): the routed bf16x6 GEMMs of the
+// backward pass read these 4 bytes per 32 channels instead of 128 bytes of the arg table
+template <int NV>
+__device__ __forceinline__ void segmax_winbits(const int* __restrict__ seg_items, int beg, int end, int D, const int (&barg)[NV],
+                                               uint32_t* __restrict__ winbits) {
+  const int lane = threadIdx.x & 63;
+  const int wpr = (D + 31) >> 5;
+  for (int base = beg; base < end; base += 64) {
+    const int cnt = min(64, end - base);
+    const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
+    for (int i = 0; i < cnt; ++i) {
+      const int e = __shfl(mine, i, 64);
+      uint32_t word = 0;  // lane w ends up holding word w of the item's mask: one store per item
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const unsigned long long b = __ballot(barg[j] == e);  // padding lanes hold -1
-          if (lane == 2 * j) word = (uint32_t)b;
-          if (lane == 2 * j + 1) word = (uint32_t)(b >> 32);
-        }
-        if (lane < wpr) winbits[(size_t)e * wpr + lane] = word;
+      for (int j = 0; j < NV; ++j) {
+        const unsigned long long b = __ballot(barg[j] == e);  // padding lanes hold -1
+        if (lane == 2 * j) word = (uint32_t)b;
+        if (lane == 2 * j + 1) word = (uint32_t)(b >> 32);
       }
+      if (lane < wpr) winbits[(size_t)e * wpr + lane] = word;
     }
   }
+}
+
+// outputs of one segment from its winners (one wave): aggregate, arg table, activation derivative, LayerNorm (+ packed copy)
+template <int NV, bool HAS_LN, bool GELU2>
+__device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int ldx, int seg, int D, int act, float (&best)[NV],
+                                              const int (&barg)[NV], const float (&raw)[NV], float* __restrict__ out,
+                                              int* __restrict__ arg, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                              float eps, float* __restrict__ ln_out, float* __restrict__ mean_out,
+                                              float* __restrict__ rstd_out, float* __restrict__ dact,
+                                              uint32_t* __restrict__ ln_out_packed) {
+  const int lane = threadIdx.x & 63;
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -290,6 +290,91 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
     }
     if (lane == 0) { mean_out[seg] = mean; rstd_out[seg] = rstd; }
   }
+}
+
+#define SEGMAX_PARAMS                                                                                                             \
+  const float *__restrict__ x, int ldx, const int *__restrict__ seg_ptr, const int *__restrict__ seg_items, int nseg, int D,     \
+      int act, float *__restrict__ out, int *__restrict__ arg, const float *__restrict__ ln_g, const float *__restrict__ ln_b,   \
+      float eps, float *__restrict__ ln_out, float *__restrict__ mean_out, float *__restrict__ rstd_out,                         \
+      float *__restrict__ dact, uint32_t *__restrict__ winbits, const int *__restrict__ seg_order,                               \
+      uint32_t *__restrict__ ln_out_packed, int hub_slots
+
+// Wave-per-segment kernel (skips the hubs) ...
+template <int NV, bool HAS_LN, bool GELU2>
+__global__ __launch_bounds__(256) void segment_max_kernel(SEGMAX_PARAMS) {
+  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= nseg) return;
+  // seg_order (optional): processing order, long segments first
+  const int seg = seg_order ? seg_order[slot] : slot;
+  if (segmax_is_hub(seg_ptr, hub_slots, slot, seg)) return;  // segment_max_hub_kernel's
+  const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
+  float best[NV], low[NV], raw[NV];
+  int barg[NV], larg[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; raw[j] = 0.f; }
+  segmax_scan<NV, GELU2>(x, ldx, seg_items, beg, end, D, act, best, barg, low, larg);
+  segmax_pick<NV, GELU2>(best, barg, low, larg, raw);
+  if (winbits) segmax_winbits<NV>(seg_items, beg, end, D, barg, winbits);
+  segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
+                                   ln_out_packed);
+}
+
+// ... and the hub kernel, launched in front of it: workgroup b looks at entry b of seg_order and, if that segment is a hub,
+// takes it with all four waves -- wave w scans the w-th contiguous share of the items, the partial extremes go through LDS
+// and wave 0 merges them in share order with the same strict comparisons (so the first of equal values still wins, and a
+// NaN sticks); the final winners come back through LDS for the routing bitmask, which every wave writes for its own share.
+template <int NV, bool HAS_LN, bool GELU2, int SEGMAX_HUB_WAVES>
+__global__ __launch_bounds__(64 * SEGMAX_HUB_WAVES) void segment_max_hub_kernel(SEGMAX_PARAMS, int len_lo, int len_hi) {
+  constexpr int W = 64 * NV;
+  __shared__ float hub_f[2][SEGMAX_HUB_WAVES][W];
+  __shared__ int hub_i[2][SEGMAX_HUB_WAVES][W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = blockIdx.x;
+  if (slot >= nseg || slot >= hub_slots) return;
+  const int seg = seg_order[slot];
+  {  // this kernel's share of the hubs: len_lo < length <= len_hi (uniform over the workgroup: nobody reaches a barrier)
+    const int len = seg_ptr[seg + 1] - seg_ptr[seg];
+    if (len <= len_lo || len > len_hi) return;
+  }
+  float best[NV], low[NV], raw[NV];
+  int barg[NV], larg[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; raw[j] = 0.f; }
+  const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
+  const int share = (end - beg + SEGMAX_HUB_WAVES - 1) / SEGMAX_HUB_WAVES;
+  const int wb = min(end, beg + wave * share), we = min(end, wb + share);
+  segmax_scan<NV, GELU2>(x, ldx, seg_items, wb, we, D, act, best, barg, low, larg);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int o = lane + 64 * j;
+    hub_f[0][wave][o] = best[j]; hub_i[0][wave][o] = barg[j]; hub_f[1][wave][o] = low[j]; hub_i[1][wave][o] = larg[j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < SEGMAX_HUB_WAVES; ++w) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int o = lane + 64 * j;
+        const float tb = hub_f[0][w][o], tl = hub_f[1][w][o];
+        const int ab = hub_i[0][w][o], al = hub_i[1][w][o];
+        if (ab >= 0 && BL_MAX_WINS(tb, best[j])) { best[j] = tb; barg[j] = ab; }
+        if (GELU2 && al >= 0 && tl < low[j]) { low[j] = tl; larg[j] = al; }
+      }
+    }
+    segmax_pick<NV, GELU2>(best, barg, low, larg, raw);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) hub_i[0][0][lane + 64 * j] = barg[j];  // the final winners
+  }
+  __syncthreads();
+  if (winbits) {
+    int fin[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) fin[j] = hub_i[0][0][lane + 64 * j];
+    segmax_winbits<NV>(seg_items, wb, we, D, fin, winbits);
+  }
+  if (wave == 0)
+    segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
+                                     ln_out_packed);
 }
 
 // backward of the segmented max in gather form: each item row looks up its segment's argmax
@@ -685,14 +770,14 @@ extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* se
                                   const float* ln_b, float eps, float* ln_out, float* mean, float* rstd, float* dact,
                                   uint32_t* winbits, const int32_t* seg_order, void* stream) {
   return bl_segment_max_fwd_impl(x, ldx, seg_ptr, seg_items, nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits,
-                                 seg_order, nullptr, stream);
+                                 seg_order, nullptr, -1, stream);
 }
 
 // + ln_out_packed: the LayerNorm output also (or only: ln_out may then be NULL) in bl_pack_bf16x3's packed form
 int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg, int32_t D,
                             int32_t act, float* out, int32_t* arg, const float* ln_g, const float* ln_b, float eps, float* ln_out,
                             float* mean, float* rstd, float* dact, uint32_t* winbits, const int32_t* seg_order,
-                            uint16_t* ln_out_packed, void* stream) {
+                            uint16_t* ln_out_packed, int32_t num_hub_slots, void* stream) {
   if (nseg == 0) return BL_OK;
   BL_CHECK_ARG(seg_ptr && out, "bl_segment_max_fwd: null pointer");  // arg (the winner table) is optional
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
@@ -702,10 +787,19 @@ int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr,
   BL_CHECK_ARG(ln_out_packed == nullptr || (has_ln && D % 8 == 0), "bl_segment_max_fwd: the packed LayerNorm output needs D %% 8 == 0");
   dim3 grid((nseg + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define SEGMAX_GO(LN_, G2_)                                                                                                  \
-  DISPATCH_NV(D, hipLaunchKernelGGL((segment_max_kernel<NV, LN_, G2_>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, \
-                                     act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order,                \
-                                     reinterpret_cast<uint32_t*>(ln_out_packed)))
+  uint32_t* lnp = reinterpret_cast<uint32_t*>(ln_out_packed);
+  // hub candidates: the first hub_slots entries of seg_order (the collator sorts high-degree nodes to the front); their
+  // kernel goes first so that the longest segments start at t = 0
+  const int hub_slots = seg_order ? (num_hub_slots < 0 ? min(nseg, SEGMAX_HUB_SLOTS) : min(nseg, num_hub_slots)) : 0;
+#define SEGMAX_GO(LN_, G2_)                                                                                                          \
+  DISPATCH_NV(D, {                                                                                                                   \
+    if (hub_slots > 0)                                                                                                               \
+      hipLaunchKernelGGL((segment_max_hub_kernel<NV, LN_, G2_, 4>), dim3(hub_slots), dim3(256), 0, st, x, ldx, seg_ptr, seg_items,    \
+                         nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order, lnp, hub_slots,      \
+                         SEGMAX_HUB, 0x7fffffff);                                                                                    \
+    hipLaunchKernelGGL((segment_max_kernel<NV, LN_, G2_>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, act, out, arg,   \
+                       ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order, lnp, hub_slots);                              \
+  })
   if (has_ln) {
     if (act == BL_ACT_GELU) SEGMAX_GO(true, true) else SEGMAX_GO(true, false)
   } else {

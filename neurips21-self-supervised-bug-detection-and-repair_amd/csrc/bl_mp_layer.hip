@@ -222,7 +222,7 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
     // (E == 0: every segment is empty and the kernel never dereferences `pre`)
     BL_TRY(bl_segment_max_fwd_impl(pre, Dm, L->tgt_ptr, L->tgt_msgs, N, Dm, L->msg_act, S.agg, winner_out, L->ln_g, L->ln_b,
                                    L->ln_eps, dense_x6 ? nullptr : S.ln_out, S.mean, S.rstd, S.dact, S.bits, L->node_order,
-                                   dense_x6 ? (uint16_t*)S.ln_out : nullptr, st));
+                                   dense_x6 ? (uint16_t*)S.ln_out : nullptr, L->num_hub_slots, st));
   }
   {
     ProfScope ps(3, 2.0 * N * (double)Dm * Dout, st, false);

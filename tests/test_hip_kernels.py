@@ -111,6 +111,8 @@ def test_segment_max_layernorm_fwd_bwd(ops, D, act):
     x = torch.randn(E, D)
     x[3] = x[1]  # exact tie inside a segment? force same segment
     seg[3] = seg[1]
+    x[150] = x[1]  # and one more copy far down the hub segment: with the multi-wave hub kernel (seg_order given, below) the
+    # tie spans two waves' shares and the FIRST item must still win
     order = np.argsort(seg, kind="stable").astype(np.int32)
     ptr[1:] = np.cumsum(np.bincount(seg, minlength=nseg))
     g, b = torch.randn(D), torch.randn(D)
