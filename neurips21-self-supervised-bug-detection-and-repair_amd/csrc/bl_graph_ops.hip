@@ -617,12 +617,14 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
     for (int base = beg; base < end; base += 64) {
       const int cnt = min(64, end - base);
       const int mine = lane < cnt ? items[base + lane] : 0;
-      int i = 0;
-      for (; i + 4 <= cnt; i += 4) {  // four independent row loads in flight, summed in item order
-        float v[4][NV];
+      // U independent row loads in flight per step, summed in item order; a short last step re-reads the last row and
+      // drops it, so that up to U items are ONE round trip
+      constexpr int U = NV <= 4 ? 8 : 4;
+      for (int i = 0; i < cnt; i += U) {
+        float v[U][NV];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = __shfl(mine, i + u, 64);
+        for (int u = 0; u < U; ++u) {
+          const int e = __shfl(mine, min(i + u, cnt - 1), 64);
           const float* __restrict__ row = g_a + (size_t)e * ld_ga + coff;
 #pragma unroll
           for (int j = 0; j < NV; ++j) {
@@ -631,17 +633,10 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < U; ++u) {
+          if (i + u >= cnt) break;  // wave-uniform
 #pragma unroll
           for (int j = 0; j < NV; ++j) acc[j] += v[u][j];
-      }
-      for (; i < cnt; ++i) {
-        const int e = __shfl(mine, i, 64);
-        const float* __restrict__ row = g_a + (size_t)e * ld_ga + coff;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const int d = lane + 64 * j;
-          if (d < Din) acc[j] += row[d];
         }
       }
     }
