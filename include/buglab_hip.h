@@ -373,6 +373,36 @@ int bl_localization_scores_bwd(const float* x, int32_t ld_x, const int32_t* cand
                                int32_t ld_gx, float* g_Ws, float* g_bs, float* g_W1, float* g_b1, float* g_w, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * H2 + H6 + H7 + H8 on the training path: everything between the scorers' logits and the scalar loss in one kernel per
+ * direction.  Replaces LocalizationModule.forward's NO_BUG logit / log-softmax / torch.where pick / clamp at log 0.995 /
+ * abstain term / (weighted) mean and accuracy counters (buglab/models/layers/localizationmodule.py:63-124), the joint
+ * log-softmax of the three repair scorers' logits over the location groups and the arg-max flags
+ * (buglab/models/gnn.py:295-311, utils.py:15-28), the fixers' -logprob[target] and counters (fixermodules.py:41-53, 86-98,
+ * 134-147) and the loss assembly loc + w_buggy * (text + var + swap) / B (gnn.py:221-251).
+ * Items of the localization log-softmax are the C candidate rows followed by one NO_BUG slot per graph (value 1.0). */
+typedef struct {
+  int32_t B, C, Rt, Rv, Rs, G;                 /* graphs, candidate rows, text / var / swap logits, repair location groups */
+  const float* loc_scores;                     /* [C] candidate scores (bl_localization_scores_fwd) */
+  const float* repair_logits;                  /* [Rt + Rv + Rs]: text | var | swap */
+  const int32_t *loc_group_ptr, *loc_group_items;        /* CSR graph -> its items among 0 .. C + B - 1 */
+  const int32_t* candidate_ptr;                /* [B + 1]: the candidate rows of graph b are candidate_ptr[b] .. candidate_ptr[b+1] */
+  const uint8_t* has_bug;                      /* [B] */
+  const int32_t* correct_candidate_idxs;       /* [B] row of the buggy location (read where has_bug) */
+  const int32_t *repair_group_ptr, *repair_group_items;  /* CSR location group -> its logits */
+  const int32_t* logit_group[3];               /* location group of every text / var / swap logit */
+  const int32_t* target[3];                    /* indices (into their slice) of the correct text / var / swap rewrites */
+  int32_t ntarget[3];
+  float w_buggy, abstain_weight;
+} bl_bug_loss_t;
+/* stats[16]: B, graphs localized correctly, NO_BUG graphs, NO_BUG graphs predicted so, -sum of the location logprobs, then
+ * (arg-max hits, count) for text / var / swap rewrites, loss, repair loss (times w_buggy), buggy graphs, 1, 0. */
+int bl_bug_loss_fwd(const bl_bug_loss_t* d, float* loc_logprobs, float* repair_logprobs, float* group_max, float* loss,
+                    float* stats, void* stream);
+/* g_loss: device scalar; scratch: C + B + Rt + Rv + Rs floats; writes every entry of g_loc_scores [C] and g_repair_logits */
+int bl_bug_loss_bwd(const bl_bug_loss_t* d, const float* loc_logprobs, const float* repair_logprobs, const float* g_loss,
+                    float* scratch, float* g_loc_scores, float* g_repair_logits, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * `seq-great` / `seq-rat` relational-transformer block (reference buglab/models/layers/relational_transformer.py,
  * relational_multihead_attention.py, multihead_attention.py): the row-wise kernels around the MFMA GEMMs.
  * q (pre-scaled by dk^-0.5), k, v, the attention context and their gradients are [B, H, L, dk] (one [L, dk] matrix per

@@ -28,6 +28,17 @@ from buglab.runtime.module import ModuleWithMetrics
 LOGGER = logging.getLogger(__name__)
 
 
+class _FusedStatsSlice:
+    """Picklable "read my slice of the owner's fused-loss counters" callable handed to the sub-modules."""
+
+    def __init__(self, owner, lo: int, hi: int):
+        self.owner, self.lo, self.hi = owner, lo, hi
+
+    def __call__(self):
+        st = self.owner._fused_stats
+        return None if st is None else st[self.lo:self.hi]
+
+
 class GnnBugLabModule(ModuleWithMetrics):
     """reference gnn.py:55-322."""
 
@@ -51,6 +62,13 @@ class GnnBugLabModule(ModuleWithMetrics):
         self._argswap_module = CandidatePairSelectorModule(H)
         self._epoch_idx = 0
         self._acc = None
+        # counters of the fused loss assembly (hip_ops.bug_loss: one kernel for everything between the logits and the loss);
+        # the sub-modules read their slices when metrics are reported
+        self._fused_stats = None
+        self._localization_module._stats_source = _FusedStatsSlice(self, 0, 5)
+        self._text_repair_module._counts_source = _FusedStatsSlice(self, 5, 7)
+        self._varmisuse_module._counts_source = _FusedStatsSlice(self, 7, 9)
+        self._argswap_module._counts_source = _FusedStatsSlice(self, 9, 11)
         self._dropout_base_seed = int(dropout_base_seed)
         self._dropout_step = 0
 
@@ -63,15 +81,27 @@ class GnnBugLabModule(ModuleWithMetrics):
         return self._gnn
 
     # ---- metrics (reference :95-114) ----------------------------------------------------------
+    def _all_acc(self):
+        ext = None if self._fused_stats is None else self._fused_stats[11:15]
+        if ext is None:
+            return self._acc
+        return ext if self._acc is None else self._acc + ext
+
     def _reset_module_metrics(self) -> None:
-        if self._acc is not None and self.training and float(self._acc[3]) > 0:
+        acc = self._all_acc()
+        if acc is not None and self.training and float(acc[3]) > 0:
             self._epoch_idx += 1
         self._acc = None  # [loss sum, repair loss sum, total buggy samples, num batches]
+        # nn.Module.modules() yields this module BEFORE its children: let the localization head see its counters (it advances
+        # its own epoch index on reset) before they are dropped; its own turn then finds nothing and does nothing
+        self._localization_module._reset_module_metrics()
+        self._fused_stats = None
 
     def _module_metrics(self) -> Dict[str, Any]:
-        if self._acc is None:
+        acc = self._all_acc()
+        if acc is None:
             return {}
-        loss, repair, samples, batches = (float(x) for x in self._acc.tolist())
+        loss, repair, samples, batches = (float(x) for x in acc.tolist())
         m = {}
         if samples > 0:
             m["Repair Loss"] = repair / samples
@@ -124,6 +154,45 @@ class GnnBugLabModule(ModuleWithMetrics):
             gnn_output.num_graphs,
             graph_data["candidate_ptr"], graph_data["loc_group_ptr"], graph_data["loc_group_items"])
         return ids, logprobs, gnn_output, arange
+
+    def _repair_logits(self, gnn_output: GnnOutput, target_rewrites):
+        """The three scorers' logits (reference :261-293), each a [0] tensor when its head has no candidates."""
+        h, refs = self._head_inputs(gnn_output)
+        zeros = lambda: torch.zeros(0, dtype=torch.float32, device=h.device)
+        text = (self._text_repair_module.compute_rewrite_logits(h, refs["target_rewrite_nodes"], target_rewrites)
+                if target_rewrites.shape[0] > 0 else zeros())
+        var = (self._varmisuse_module.compute_per_slot_log_probability(h, refs["varmisused_node_ids"], refs["candidate_symbol_node_ids"])
+               if refs["varmisused_node_ids"].shape[0] > 0 else zeros())
+        swap = (self._argswap_module.compute_per_pair_logits(h, refs["call_node_ids"], refs["candidate_swapped_a"], refs["candidate_swapped_b"])
+                if refs["call_node_ids"].shape[0] > 0 else zeros())
+        return text, var, swap
+
+    def _fused_loss_applicable(self) -> bool:
+        # one buggy-sample weight for the localization and the repair part (the two schedules are the same object in every
+        # constructor of this repository; they could only differ if someone re-wired a sub-module by hand)
+        loc = self._localization_module
+        return loc._buggy_samples_weight_schedule(loc._epoch_idx) == self._buggy_samples_weight_schedule(self._epoch_idx)
+
+    def _forward_fused_loss(self, gnn_output, graph_data, has_bug, correct_candidate_node_idxs, target_rewrites,
+                            rewrite_to_location_group, candidate_symbol_to_location_group, swapped_pair_to_call_location_group,
+                            correct_rewrite_idxs, correct_candidate_symbols, correct_swapped_pair, repair_group_ptr, repair_group_items):
+        """reference :221-251 with localizationmodule.py:63-124 and fixermodules' forward()s folded in (hip_ops.bug_loss)."""
+        h, refs = self._head_inputs(gnn_output)
+        B = has_bug.shape[0]
+        scores = self._localization_module.compute_localization_scores(
+            h, refs["candidate_nodes"], gnn_output.node_graph_idx_reference["candidate_nodes"], B, graph_data["candidate_ptr"])
+        text, var, swap = self._repair_logits(gnn_output, target_rewrites)
+        logits = torch.cat((text, var, swap))  # :295
+        ix = hip_ops.BugLossIndex(graph_data["loc_group_ptr"], graph_data["loc_group_items"], graph_data["candidate_ptr"], has_bug,
+                                  correct_candidate_node_idxs, repair_group_ptr, repair_group_items,
+                                  (rewrite_to_location_group, candidate_symbol_to_location_group, swapped_pair_to_call_location_group),
+                                  (correct_rewrite_idxs, correct_candidate_symbols, correct_swapped_pair),
+                                  int(repair_group_ptr.shape[0]) - 1)
+        loss, stats = hip_ops.bug_loss(scores, logits, (text.shape[0], var.shape[0], swap.shape[0]), ix,
+                                       self._buggy_samples_weight_schedule(self._epoch_idx), self._localization_module._abstain_weight)
+        with torch.no_grad():  # :244-249 and the sub-modules' counters, without host syncs
+            self._fused_stats = stats if self._fused_stats is None else self._fused_stats + stats
+        return loss
 
     def _compute_repair_logprobs(self, gnn_output: GnnOutput, target_rewrites, rewrite_to_location_group,
                                  candidate_symbol_to_location_group, swapped_pair_to_call_location_group,
@@ -182,6 +251,12 @@ class GnnBugLabModule(ModuleWithMetrics):
         if dropout_seed is None:
             dropout_seed = self._next_dropout_seed()
         gnn_output = self._compute_gnn_output(graph_data, dropout_seed)
+        if rewrite_logprobs is None and hip_ops.FUSED_LOSS and repair_group_ptr is not None and self._fused_loss_applicable():
+            # detector training: everything between the scorers' logits and the loss in one kernel per direction
+            return self._forward_fused_loss(gnn_output, graph_data, has_bug, correct_candidate_node_idxs, target_rewrites,
+                                            rewrite_to_location_group, candidate_symbol_to_location_group,
+                                            swapped_pair_to_call_location_group, correct_rewrite_idxs, correct_candidate_symbols,
+                                            correct_swapped_pair, repair_group_ptr, repair_group_items)
         swap_lp, text_lp, var_lp, (swap_sel, text_sel, var_sel) = self._compute_repair_logprobs(
             gnn_output, target_rewrites, rewrite_to_location_group, candidate_symbol_to_location_group,
             swapped_pair_to_call_location_group, repair_group_ptr, repair_group_items, num_repair_groups)

@@ -47,6 +47,14 @@ class bl_mp_layer_t(Structure):
                 ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p), ("num_hub_slots", c_int32)]
 
 
+class bl_bug_loss_t(Structure):
+    _fields_ = [("B", c_int32), ("C", c_int32), ("Rt", c_int32), ("Rv", c_int32), ("Rs", c_int32), ("G", c_int32),
+                ("loc_scores", c_void_p), ("repair_logits", c_void_p), ("loc_group_ptr", c_void_p), ("loc_group_items", c_void_p),
+                ("candidate_ptr", c_void_p), ("has_bug", c_void_p), ("correct_candidate_idxs", c_void_p),
+                ("repair_group_ptr", c_void_p), ("repair_group_items", c_void_p), ("logit_group", c_void_p * 3),
+                ("target", c_void_p * 3), ("ntarget", c_int32 * 3), ("w_buggy", c_float), ("abstain_weight", c_float)]
+
+
 _SIGNATURES = {
     "bl_version": ([], ctypes.c_int),
     "bl_set_deterministic": ([c_int32], None),
@@ -89,6 +97,8 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_localization_scores_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_bug_loss_fwd": ([POINTER(bl_bug_loss_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_bug_loss_bwd": ([POINTER(bl_bug_loss_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_add_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_rel_attn_bias_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_rel_attn_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -1363,6 +1373,84 @@ def localization_scores(x, cand, cand_graph, cand_ptr, num_graphs: int, Ws, bs, 
     if cand.shape[0] == 0:
         return torch.zeros((0,), dtype=torch.float32, device=x.device)
     return _LocalizationScores.apply(x.contiguous(), cand, cand_graph, cand_ptr, int(num_graphs), Ws, bs, W1, b1, w)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss assembly (csrc/bl_loss.hip): everything between the scorers' logits and the scalar loss in one kernel per direction
+FUSED_LOSS = os.environ.get("BL_FUSED_LOSS", "1") != "0"
+BUG_LOSS_STATS = 16
+
+
+class BugLossIndex(NamedTuple):
+    """Index tensors of one minibatch the loss assembly reads (all int32 on the device, has_bug bool)."""
+
+    loc_group_ptr: torch.Tensor
+    loc_group_items: torch.Tensor
+    candidate_ptr: torch.Tensor
+    has_bug: torch.Tensor
+    correct_candidate_idxs: torch.Tensor
+    repair_group_ptr: torch.Tensor
+    repair_group_items: torch.Tensor
+    logit_groups: tuple   # (text, var, swap): location group of every logit
+    targets: tuple        # (text, var, swap): indices of the correct rewrites inside their slice
+    num_groups: int
+
+
+def _bug_loss_desc(loc_scores, logits, sizes, ix: BugLossIndex, w_buggy: float, abstain: float) -> bl_bug_loss_t:
+    d = bl_bug_loss_t()
+    d.B, d.C = int(ix.has_bug.shape[0]), int(loc_scores.shape[0])
+    d.Rt, d.Rv, d.Rs = (int(n) for n in sizes)
+    d.G = int(ix.num_groups)
+    d.loc_scores, d.repair_logits = _p(loc_scores), _p(logits)
+    d.loc_group_ptr, d.loc_group_items = _i32(ix.loc_group_ptr).data_ptr(), _i32(ix.loc_group_items).data_ptr()
+    d.candidate_ptr = _i32(ix.candidate_ptr).data_ptr()
+    d.has_bug = _req(ix.has_bug, torch.bool, "has_bug").data_ptr()
+    d.correct_candidate_idxs = _i32(ix.correct_candidate_idxs).data_ptr()
+    d.repair_group_ptr, d.repair_group_items = _p(ix.repair_group_ptr), _p(ix.repair_group_items)
+    for k in range(3):
+        d.logit_group[k] = _i32(ix.logit_groups[k]).data_ptr() if ix.logit_groups[k].numel() else None
+        d.target[k] = _i32(ix.targets[k]).data_ptr() if ix.targets[k].numel() else None
+        d.ntarget[k] = int(ix.targets[k].shape[0])
+    d.w_buggy, d.abstain_weight = float(w_buggy), float(abstain)
+    return d
+
+
+class _BugLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loc_scores, logits, sizes, ix: BugLossIndex, w_buggy: float, abstain: float):
+        _f32(loc_scores, "loc_scores")
+        _f32(logits, "repair logits")
+        dev = loc_scores.device
+        d = _bug_loss_desc(loc_scores, logits, sizes, ix, w_buggy, abstain)
+        loc_lp = torch.empty((d.C + d.B,), dtype=torch.float32, device=dev)
+        rep_lp = torch.empty((max(1, logits.shape[0]),), dtype=torch.float32, device=dev)
+        gmax = torch.empty((max(1, d.G),), dtype=torch.float32, device=dev)
+        out = torch.empty((1 + BUG_LOSS_STATS,), dtype=torch.float32, device=dev)  # [loss | stats]
+        _check(load_library().bl_bug_loss_fwd(ctypes.byref(d), loc_lp.data_ptr(), rep_lp.data_ptr(), gmax.data_ptr(), out.data_ptr(),
+                                              out[1:].data_ptr(), _stream()), "bl_bug_loss_fwd")
+        ctx.saved = (loc_scores, logits, sizes, ix, w_buggy, abstain, loc_lp, rep_lp)
+        loss, stats = out[0], out[1:]
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        loc_scores, logits, sizes, ix, w_buggy, abstain, loc_lp, rep_lp = ctx.saved
+        ctx.saved = None
+        dev = loc_scores.device
+        d = _bug_loss_desc(loc_scores, logits, sizes, ix, w_buggy, abstain)
+        scratch = torch.empty((d.C + d.B + logits.shape[0] + 1,), dtype=torch.float32, device=dev)
+        g_scores = torch.empty_like(loc_scores)
+        g_logits = torch.empty_like(logits)
+        g = g_loss.contiguous().reshape(1)
+        _check(load_library().bl_bug_loss_bwd(ctypes.byref(d), loc_lp.data_ptr(), rep_lp.data_ptr(), _f32(g).data_ptr(), scratch.data_ptr(),
+                                              _p(g_scores), _p(g_logits), _stream()), "bl_bug_loss_bwd")
+        return g_scores, g_logits, None, None, None, None
+
+
+def bug_loss(loc_scores, logits, sizes, ix: BugLossIndex, w_buggy: float = 1.0, abstain_weight: float = 0.0):
+    """-> (loss scalar, stats [16]); see include/buglab_hip.h::bl_bug_loss_t.  logits = cat(text, var, swap) with `sizes` rows each."""
+    return _BugLoss.apply(loc_scores.contiguous(), logits.contiguous(), tuple(int(n) for n in sizes), ix, float(w_buggy), float(abstain_weight))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -29,6 +29,7 @@ class _ScorerBase(ModuleWithMetrics):
         self.w2 = nn.Parameter(torch.empty(hidden).uniform_(-b2, b2))
         self.b2 = nn.Parameter(torch.empty(1).uniform_(-b2, b2))
         self._counts = None
+        self._counts_source = None  # the owning module's fused loss assembly keeps the counters: () -> [2] (hits, total) or None
 
     def _score(self, sources):
         return hip_ops.mlp_score(sources, self.W1, self.b1, self.w2, self.b2)  # one C call forward, one backward
@@ -37,9 +38,11 @@ class _ScorerBase(ModuleWithMetrics):
         self._counts = None
 
     def _module_metrics(self) -> Dict[str, Any]:
-        if self._counts is None:
+        ext = self._counts_source() if self._counts_source is not None else None
+        if self._counts is None and ext is None:
             return {}
-        correct, total = (int(x) for x in self._counts.tolist())
+        correct, total = (int(a) + int(b) for a, b in zip(self._counts.tolist() if self._counts is not None else (0, 0),
+                                                           ext.tolist() if ext is not None else (0, 0)))
         if total == 0:
             return {}
         return {self._metric_name: correct / total, self._stats_name: f"{correct / total:.2%} ({correct}/{total})"}

@@ -32,16 +32,25 @@ class LocalizationModule(ModuleWithMetrics):
         self._abstain_weight = abstain_weight
         self._epoch_idx = 0
         self._stats = None
+        self._stats_source = None  # the owning module's fused loss assembly keeps the counters (hip_ops.bug_loss): () -> [5] or None
+
+    def _all_stats(self):
+        ext = self._stats_source() if self._stats_source is not None else None
+        if ext is None:
+            return self._stats
+        return ext if self._stats is None else self._stats + ext
 
     def _reset_module_metrics(self) -> None:
-        if self._stats is not None and self.training and float(self._stats[0]) > 0:
+        st = self._all_stats()
+        if st is not None and self.training and float(st[0]) > 0:
             self._epoch_idx += 1  # "Assumes that module metrics are reset once per epoch" (:32-36)
         self._stats = None
 
     def _module_metrics(self) -> Dict[str, Any]:
-        if self._stats is None:
+        st = self._all_stats()
+        if st is None:
             return {}
-        total, correct, no_bug, no_bug_correct, loss = (float(x) for x in self._stats.tolist())
+        total, correct, no_bug, no_bug_correct, loss = (float(x) for x in st.tolist())
         if total == 0:
             return {}
         return {
@@ -50,6 +59,11 @@ class LocalizationModule(ModuleWithMetrics):
             "Localization Loss": loss / total,
             "Weight of Buggy Samples": self._buggy_samples_weight_schedule(self._epoch_idx),
         }
+
+    def compute_localization_scores(self, node_reprs, candidate_nodes, candidate_to_sample_idx, num_samples, candidate_ptr):
+        """reference :56-60: the candidates' scores before the NO_BUG logit and the log-softmax (one C call)."""
+        return hip_ops.localization_scores(node_reprs, candidate_nodes, candidate_to_sample_idx, candidate_ptr, num_samples,
+                                           self.Ws, self.bs, self.W1, self.b1, self.w)
 
     def compute_localization_logprobs(self, node_reprs, candidate_nodes, candidate_to_sample_idx, num_samples,
                                       candidate_ptr, loc_group_ptr, loc_group_items):

@@ -514,3 +514,49 @@ def test_fused_layer_call_equals_kernel_by_kernel_path():
     for k, g in res[True][1].items():
         ref = res[False][1][k]
         assert float((g - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-7, k  # atomics reorder sums
+
+
+@pytest.mark.parametrize("w_buggy,abstain", [(1.0, 0.0), (2.5, 0.0), (1.0, 0.35), (0.4, 0.2)])
+def test_fused_loss_assembly_equals_the_op_by_op_path(w_buggy, abstain):
+    """hip_ops.bug_loss (one kernel per direction for localizationmodule.py:63-124 + gnn.py:221-251,295-311 + the fixers'
+    forward()s) against the same arithmetic done op by op (which the reference-generated goldens pin): loss, every
+    parameter gradient, and every metric -- for a buggy-sample weight != 1 and an abstain weight too."""
+    from functools import partial
+
+    from buglab.data.collate import collate_samples, to_device
+    from buglab.data.synthetic import make_samples
+    from buglab.models import hip_ops
+    from buglab.models.gnn import build_gnn_mlp_module, const_weight_schedule
+
+    mb = to_device(collate_samples(make_samples(7, seed=21, num_nodes=90, num_messages=400, num_edge_types=5, vocab_size=300, num_candidates=9), 5), "cuda")
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(4)
+        module = build_gnn_mlp_module(64, 4, 5, vocabulary_size=300, dropout_rate=0.0, buggy_samples_weight=w_buggy).cuda().train()
+        module._localization_module._abstain_weight = abstain
+        hip_ops.FUSED_LOSS = fused
+        try:
+            losses = []
+            for _ in range(2):  # two steps: the counters accumulate
+                module.zero_grad(set_to_none=True)
+                loss = module(**mb, dropout_seed=3)
+                loss.backward()
+                losses.append(float(loss.detach()))
+            hip_ops.join_side_stream()
+            torch.cuda.synchronize()
+            res[fused] = (losses, {k: p.grad.clone() for k, p in module.named_parameters()}, module.report_metrics())
+            module.reset_metrics()
+            assert module.report_metrics() == {}
+        finally:
+            hip_ops.FUSED_LOSS = True
+    assert max(abs(a - b) for a, b in zip(res[True][0], res[False][0])) < 2e-6
+    for k, g in res[True][1].items():
+        ref = res[False][1][k]
+        assert float((g - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-8, k
+    m1, m0 = res[True][2], res[False][2]
+    assert set(m1) == set(m0)
+    for k in m0:
+        if isinstance(m0[k], str):
+            assert m1[k] == m0[k], k
+        else:
+            assert abs(m1[k] - m0[k]) < 1e-5 or (m1[k] != m1[k] and m0[k] != m0[k]), (k, m1[k], m0[k])
