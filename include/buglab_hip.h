@@ -131,6 +131,18 @@ int bl_pack_bf16x3_cols(const float* x, int32_t ld, int64_t R, int32_t D, int32_
  * n = 128 tile + 64 i + row_lo and k = 32 stage + 8 k-group + 0..7; columns past N are zero.
  * w is [G][K][N] if w_is_kn (forward weights W[t]: C = A . W) or [G][N][K] (C = A . w^T). */
 int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t N, int32_t w_is_kn, uint16_t* out, void* stream);
+/* All the operand copies of the weights a training step needs, in ONE launch (they are re-made after every optimiser
+ * step): a table of jobs in DEVICE memory, built once per model.  kind 0 / 1 = bl_pack_weights_x6 with w_is_kn = kind
+ * (w [G][N][K] / [G][K][N]); kind 2 = the fp32 transpose out[g][n][k] = w[g][k][n] (the W^T of bl_routed_dgrad_nodes).
+ * first_block = sum of bl_pack_job_blocks(...) of the jobs before; total_blocks = that sum over all jobs. */
+typedef struct {
+  const float* w;
+  void* out;
+  int32_t kind, G, K, N;
+  int32_t first_block, pad_;
+} bl_pack_job_t;
+int64_t bl_pack_job_blocks(int32_t kind, int32_t G, int32_t K, int32_t N);
+int bl_pack_weights_multi(const bl_pack_job_t* jobs_device, int32_t njobs, int32_t total_blocks, void* stream);
 int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                     int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
                     int32_t N, int32_t K, float* c, int32_t ldc, void* stream);

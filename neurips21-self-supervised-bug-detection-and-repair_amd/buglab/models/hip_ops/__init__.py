@@ -47,6 +47,11 @@ class bl_mp_layer_t(Structure):
                 ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p), ("num_hub_slots", c_int32)]
 
 
+class bl_pack_job_t(Structure):
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", c_int32), ("G", c_int32), ("K", c_int32), ("N", c_int32),
+                ("first_block", c_int32), ("pad_", c_int32)]
+
+
 class bl_bug_loss_t(Structure):
     _fields_ = [("B", c_int32), ("C", c_int32), ("Rt", c_int32), ("Rv", c_int32), ("Rs", c_int32), ("G", c_int32),
                 ("loc_scores", c_void_p), ("repair_logits", c_void_p), ("loc_group_ptr", c_void_p), ("loc_group_items", c_void_p),
@@ -67,6 +72,8 @@ _SIGNATURES = {
     "bl_gemm_rows_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_pack_weights_x6": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_pack_job_blocks": ([c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_pack_weights_multi": ([c_void_p, c_int32, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6_epi": ([POINTER(bl_rows_packed_t), c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32,
                              bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
@@ -818,7 +825,6 @@ class _MpLayer(torch.autograd.Function):
 # One C call per message-passing layer and direction (bl_mp_layer_fwd / bl_mp_layer_bwd).
 FUSED_LAYER = os.environ.get("BL_FUSED_LAYER", "1") != "0"
 _weights_epoch = 0          # bumped by whoever changes parameters behind autograd's back (FlatAdam's kernel)
-_pack_cache = {}            # id(W) -> (weakref(W), version, epoch, packed [T, *] forward form, packed backward form | None)
 
 
 def set_deterministic(on: bool = True) -> None:
@@ -848,51 +854,97 @@ def _as_groups(w: torch.Tensor) -> torch.Tensor:
     return w if w.dim() == 3 else w.unsqueeze(0)
 
 
-def _packed_layer_weights(W: torch.Tensor, need_bwd: bool):
-    """bf16x3-packed, tiled copies of a layer's per-type weights: the forward form (C = A . W[t]) and, when a
-    backward pass will follow, the form of the routed input-gradient GEMM (C = G . W[t]^T).  Packed once per
-    parameter value: eval / predict passes re-use them, a training step packs each form once.  A 2-D weight
-    (the dense node update's Wd [Dm, Dout]) is packed as one group."""
-    import weakref
+# Operand copies of the weights (bf16x3-packed tiled forms for the bf16x6 GEMMs, fp32 transposes for the vector input
+# gradient).  They are functions of the parameter values, so a training step re-makes all of them once after the optimiser
+# step -- in ONE launch (bl_pack_weights_multi) over a table of every copy any layer has asked for so far, instead of one
+# launch per layer and form.  Validity = (parameter object, its autograd version, the epoch bumped by whoever writes
+# parameters behind autograd's back, its storage address).
+_KIND = {"nk": 0, "kn": 1, "t": 2}
 
-    key = id(W)
-    ent = _pack_cache.get(key)
-    if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == _weights_epoch and ent[5] == W.data_ptr():
-        if not need_bwd or ent[4] is not None:
-            return ent[3], ent[4]
-        ent = (ent[0], ent[1], ent[2], ent[3], pack_weights_x6(_as_groups(W.detach()), False), ent[5])
-        _pack_cache[key] = ent
-        return ent[3], ent[4]
-    if len(_pack_cache) > 256:
-        for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
-            del _pack_cache[k]
-    wd = _as_groups(W.detach())
-    ent = (weakref.ref(W), W._version, _weights_epoch, pack_weights_x6(wd, True), pack_weights_x6(wd, False) if need_bwd else None,
-           W.data_ptr())
-    _pack_cache[key] = ent
-    return ent[3], ent[4]
+
+class _WeightCopies:
+    def __init__(self):
+        self.entries = {}   # id(W) -> {"ref", "ptr", "shape", "forms": {name: tensor}, "version", "epoch"}
+        self.plan = None    # (device job table, njobs, total_blocks, [entries in table order])
+
+    def _fresh(self, ent, W) -> bool:
+        return ent["version"] == W._version and ent["epoch"] == _weights_epoch
+
+    def get(self, W: torch.Tensor, names):
+        import weakref
+
+        ent = self.entries.get(id(W))
+        if ent is not None and (ent["ref"]() is not W or ent["ptr"] != W.data_ptr() or ent["shape"] != tuple(W.shape)):
+            ent = None
+        if ent is None:
+            if len(self.entries) > 256:
+                self.entries = {k: v for k, v in self.entries.items() if v["ref"]() is not None}
+            ent = {"ref": weakref.ref(W), "ptr": W.data_ptr(), "shape": tuple(W.shape), "forms": {}, "version": -1, "epoch": -1}
+            self.entries[id(W)] = ent
+            self.plan = None
+        G, K, N = _as_groups(W).shape  # the parameter is [G][K][N] (forward form: C = A . W[g])
+        for nm in names:
+            if nm not in ent["forms"]:
+                if nm == "t":
+                    ent["forms"][nm] = torch.empty((G, N, K), dtype=torch.float32, device=W.device)
+                else:  # "kn": C = A . W (K x N) ; "nk": C = G . W^T, i.e. bl_pack_weights_x6 of [G][N'][K'] with N' = K, K' = N
+                    n_out, k_in = (N, K) if nm == "kn" else (K, N)
+                    ent["forms"][nm] = torch.empty((G, ((n_out + 127) // 128) * (k_in // 32) * 12288), dtype=torch.int16, device=W.device)
+                ent["version"] = -1  # (a new form has to be filled)
+                self.plan = None
+        if not self._fresh(ent, W):
+            self.refresh(W.device)
+        return [ent["forms"][nm] for nm in names]
+
+    def refresh(self, device) -> None:
+        """Re-make every registered copy on `device` whose parameter changed: one launch."""
+        lib = load_library()
+        # (strong references for the duration: a parameter that is only kept alive by a reference cycle can be collected by
+        # the cyclic GC at any allocation below)
+        alive = [(e, e["ref"]()) for e in self.entries.values()]
+        alive = [(e, W) for e, W in alive if W is not None and W.device == device]
+        live = [e for e, _ in alive]
+        if self.plan is None or self.plan[4] != device or len(self.plan[3]) != len(live) or any(a is not b for a, b in zip(self.plan[3], live)):
+            jobs, blocks = [], 0
+            for e, W in alive:
+                G, K, N = _as_groups(W).shape
+                for nm, out in e["forms"].items():
+                    j = bl_pack_job_t()
+                    j.w, j.out, j.kind = W.data_ptr(), out.data_ptr(), _KIND[nm]
+                    # kind 1 (kn): w [G][K][N]; kind 0 (nk): bl_pack_weights_x6(w_is_kn = 0) reads w as [G][N'][K'] = [G][K][N]
+                    # with output columns N' = K and contraction K' = N; kind 2: transpose of [G][K][N]
+                    j.G, j.K, j.N = (G, K, N) if nm != "nk" else (G, N, K)
+                    j.first_block = blocks
+                    blocks += int(lib.bl_pack_job_blocks(j.kind, j.G, j.K, j.N))
+                    jobs.append(j)
+            raw = b"".join(bytes(j) for j in jobs)
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device) if jobs else None
+            self.plan = (table, len(jobs), blocks, live, device)
+        table, njobs, blocks, _, _ = self.plan
+        if njobs:
+            _check(lib.bl_pack_weights_multi(table.data_ptr(), njobs, blocks, _stream()), "bl_pack_weights_multi")
+        for e, W in alive:
+            e["version"], e["epoch"] = W._version, _weights_epoch
+
+
+_weight_copies = _WeightCopies()
+
+
+def _packed_layer_weights(W: torch.Tensor, need_bwd: bool):
+    """bf16x3-packed, tiled copies of a layer's weights: the forward form (C = A . W[t]) and, when asked for, the form of the
+    input-gradient GEMM (C = G . W[t]^T).  A 2-D weight (the dense node update's Wd [Dm, Dout]) is one group."""
+    got = _weight_copies.get(W, ("kn", "nk") if need_bwd else ("kn",))
+    return got[0], (got[1] if need_bwd else None)
 
 
 # The routed input gradient of a message-passing layer from the NON-ZEROS of the message gradient, on the vector units, node
 # sums fused in (csrc/bl_routed_dgrad.hip), instead of the matrix-core GEMM over all E x Dm entries + bl_mp_scatter_grad.
 # BL_DGRAD_VEC=0: matrix cores.  Needs W transposed ([T, Dm, 2 Din]); cached per parameter value like the packed forms.
 DGRAD_VEC = os.environ.get("BL_DGRAD_VEC", "1") != "0"
-_wt_cache = {}  # id(W) -> (weakref(W), version, epoch, data_ptr, W transposed)
 
 
 def _transposed_layer_weights(W: torch.Tensor) -> torch.Tensor:
-    import weakref
-
-    key = id(W)
-    ent = _wt_cache.get(key)
-    if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == _weights_epoch and ent[3] == W.data_ptr():
-        return ent[4]
-    if len(_wt_cache) > 256:
-        for k in [k for k, v in _wt_cache.items() if v[0]() is None]:
-            del _wt_cache[k]
-    wt = W.detach().transpose(1, 2).contiguous()
-    _wt_cache[key] = (weakref.ref(W), W._version, _weights_epoch, W.data_ptr(), wt)
-    return wt
+    return _weight_copies.get(W, ("t",))[0]
 
 
 def _layer_desc(g: "GraphIndex", W, ln_g, ln_b, Wd, bd, Din, msg_act, drop: Dropout) -> bl_mp_layer_t:
@@ -925,7 +977,10 @@ class _MpLayerFused(torch.autograd.Function):
         for t, nm in ((W, "W"), (ln_g, "ln_g"), (ln_b, "ln_b"), (Wd, "Wd"), (bd, "bd")):
             _f32(t, nm)
         need_bwd = torch.is_grad_enabled() and any(t.requires_grad for t in (h_lo, W, Wd) if t is not None)
-        wkn, wnk = _packed_layer_weights(W, need_bwd)
+        # which form of W the input gradient will read: its fp32 transpose (vector-unit path) or the packed C = G . W^T form
+        use_vec = DGRAD_VEC and E > 0 and bool(lib.bl_routed_dgrad_vec_ok(Dm, K2))
+        wkn, wnk = _packed_layer_weights(W, need_bwd and not use_vec)
+        wt = _transposed_layer_weights(W) if (need_bwd and use_vec) else None
         dev = h_lo.device
         L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
         dense_x6 = DENSE_X6 and Dm % 32 == 0 and Dout % 32 == 0
@@ -945,12 +1000,12 @@ class _MpLayerFused(torch.autograd.Function):
         if need_bwd:
             _note_use((W, ln_g, ln_b, Wd, bd))
         ctx.saved = (h_lo.shape[1], h_hi.shape[1] if h_hi is not None else 0, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk,
-                     dense_x6, wd_kn, wd_nk)
+                     dense_x6, wd_kn, wd_nk, wt)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk, dense_x6, wd_kn, wd_nk = ctx.saved
+        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk, dense_x6, wd_kn, wd_nk, wt = ctx.saved
         ctx.saved = None
         lib = load_library()
         N, E = g.num_nodes, g.num_messages
@@ -958,7 +1013,10 @@ class _MpLayerFused(torch.autograd.Function):
         Din, Dout = w_lo + w_hi, Wd.shape[1]
         dev = out.device
         g_out = g_out.contiguous()
-        if wnk is None:  # forward ran without grad mode knowing a backward would follow
+        use_vec = DGRAD_VEC and E > 0 and bool(lib.bl_routed_dgrad_vec_ok(Dm, 2 * Din))
+        if use_vec and wt is None:
+            wt = _transposed_layer_weights(W)
+        if wnk is None and not use_vec:  # forward ran without grad mode knowing a backward would follow
             wnk = _packed_layer_weights(W, True)[1]
         direct = [_direct_small(bd), _direct_small(ln_g), _direct_small(ln_b), _direct_grad_target(Wd), _direct_grad_target(W)]
         tgt = [d if d is not None else torch.zeros_like(p) for d, p in zip(direct, (bd, ln_g, ln_b, Wd, W))]
@@ -969,9 +1027,7 @@ class _MpLayerFused(torch.autograd.Function):
                 wd_nk = pack_weights_x6(_as_groups(Wd.detach()), False)
             L.Wd_packed, L.Wd_packed_bwd = wd_kn.data_ptr(), wd_nk.data_ptr()
         ws_mode = 1
-        wt = None
-        if DGRAD_VEC and E > 0 and lib.bl_routed_dgrad_vec_ok(Dm, 2 * Din):
-            wt = _transposed_layer_weights(W)  # (kept alive by this frame until the call below has been enqueued; cached beyond)
+        if use_vec:
             L.Wt = wt.data_ptr()
             if not lib.bl_get_deterministic():
                 ws_mode = 2  # node sums fused into the input-gradient kernel: no [E, 2 Din] scratch
@@ -985,7 +1041,7 @@ class _MpLayerFused(torch.autograd.Function):
                 _side_streams[key] = torch.cuda.Stream()
             side = _side_streams[key]
         free_running = side is not None and direct[3] is not None and direct[4] is not None
-        _check(lib.bl_mp_layer_bwd(ctypes.byref(L), out.data_ptr(), g_out.data_ptr(), wnk.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+        _check(lib.bl_mp_layer_bwd(ctypes.byref(L), out.data_ptr(), g_out.data_ptr(), _p(wnk), saved.data_ptr(), ws.data_ptr(),
                                    g_lo.data_ptr(), g_lo.stride(0), w_lo, _p(g_hi), g_hi.stride(0) if g_hi is not None else 0,
                                    g_W.data_ptr(), g_lng.data_ptr(), g_lnb.data_ptr(), g_Wd.data_ptr(), g_bd.data_ptr(), _stream(),
                                    side.cuda_stream if side is not None else None, 0 if free_running else 1), "bl_mp_layer_bwd")

@@ -68,10 +68,9 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
 // workgroup of an edge type at once) the B loads cost 1.8x more (load-only microbenchmark, c2 shapes:
 // 0.082 -> 0.045 ms per GEMM).  Columns past N are zero.
 // w is [G][K][N] (w_is_kn = 1: the forward weights, transposed on the fly) or [G][N][K] (w_is_kn = 0).
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int G, int K, int N, int w_is_kn,
-                                                           uint4* __restrict__ out) {
-  const int nst = K >> 5, ntn = (N + 127) >> 7;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one (g, tile, stage, i, row_lo, kg)
+__device__ __forceinline__ void pack_weights_thread(const float* __restrict__ w, int G, int K, int N, int w_is_kn,
+                                                    uint4* __restrict__ out, long long t) {
+  const int nst = K >> 5, ntn = (N + 127) >> 7;  // t = one (g, tile, stage, i, row_lo, kg)
   if (t >= (long long)G * ntn * nst * 512) return;
   int r = (int)(t & 511);
   const long long blk = t >> 9;
@@ -92,6 +91,32 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
   o[0] = make_uint4(PK(h[0], h[1]), PK(h[2], h[3]), PK(h[4], h[5]), PK(h[6], h[7]));
   o[256] = make_uint4(PK(m[0], m[1]), PK(m[2], m[3]), PK(m[4], m[5]), PK(m[6], m[7]));
   o[512] = make_uint4(PK(l[0], l[1]), PK(l[2], l[3]), PK(l[4], l[5]), PK(l[6], l[7]));
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int G, int K, int N, int w_is_kn,
+                                                           uint4* __restrict__ out) {
+  pack_weights_thread(w, G, K, N, w_is_kn, out, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Every operand copy a training step needs of the (just updated) weights in ONE launch: a table of jobs in device memory
+// (built once per model by the caller), job j owning the workgroups first_block[j] .. first_block[j+1].
+//   kind 0 / 1: bl_pack_weights_x6 with w_is_kn = kind;  kind 2: out[g][n][k] = w[g][k][n] in fp32 (W transposed, the
+//   operand of bl_routed_dgrad_nodes).
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_job_t* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;  // (a few dozen jobs: a linear walk of a cached table)
+  const bl_pack_job_t job = jobs[j];
+  const long long t = (long long)((int)blockIdx.x - job.first_block) * 256 + threadIdx.x;
+  if (job.kind <= 1) {
+    pack_weights_thread(job.w, job.G, job.K, job.N, job.kind, reinterpret_cast<uint4*>(job.out), t);
+  } else {
+    const long long per = (long long)job.K * job.N;
+    if (t >= per * job.G) return;
+    const int g = (int)(t / per);
+    const long long r = t - (long long)g * per;
+    const int n = (int)(r / job.K), k = (int)(r - (long long)n * job.K);  // consecutive threads -> consecutive k of the output row
+    reinterpret_cast<float*>(job.out)[t] = job.w[((size_t)g * job.K + k) * job.N + n];
+  }
 }
 
 // ---- GEMM -----------------------------------------------------------------------------------------
@@ -542,6 +567,19 @@ extern "C" int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t 
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, G, K,
                      N, w_is_kn, reinterpret_cast<uint4*>(out));
   BL_LAUNCH_CHECK("bl_pack_weights_x6");
+  return BL_OK;
+}
+
+extern "C" int64_t bl_pack_job_blocks(int32_t kind, int32_t G, int32_t K, int32_t N) {
+  if (kind <= 1) return ((int64_t)G * ((N + 127) / 128) * (K / 32) * 512 + 255) / 256;
+  return ((int64_t)G * K * N + 255) / 256;
+}
+
+extern "C" int bl_pack_weights_multi(const bl_pack_job_t* jobs_device, int32_t njobs, int32_t total_blocks, void* stream) {
+  if (njobs == 0 || total_blocks == 0) return BL_OK;
+  BL_CHECK_ARG(jobs_device && njobs > 0 && total_blocks > 0, "bl_pack_weights_multi: bad arguments");
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
+  BL_LAUNCH_CHECK("bl_pack_weights_multi");
   return BL_OK;
 }
 

@@ -247,8 +247,9 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
                                void* stream, void* side_stream, int32_t join_side) {
   BL_TRY(check_layer(L, "bl_mp_layer_bwd"));
   const int N = L->N, E = L->E, T = L->T, Din = L->Din, Dm = L->Dm, Dout = L->Dout;
-  BL_CHECK_ARG(h_out && g_out && w_packed_bwd && saved && ws && g_h_lo && g_W && g_ln_g && g_ln_b && g_Wd && g_bd,
-               "bl_mp_layer_bwd: null buffer");
+  BL_CHECK_ARG(h_out && g_out && saved && ws && g_h_lo && g_W && g_ln_g && g_ln_b && g_Wd && g_bd, "bl_mp_layer_bwd: null buffer");
+  BL_CHECK_ARG(w_packed_bwd || (L->Wt && L->E > 0 && bl_routed_dgrad_vec_ok(L->Dm, 2 * L->Din)) || L->E == 0,
+               "bl_mp_layer_bwd: w_packed_bwd may only be NULL when the input gradient takes the Wt path");
   BL_CHECK_ARG((g_h_hi == nullptr && width_lo == Din) || (g_h_hi != nullptr && width_lo > 0 && width_lo < Din),
                "bl_mp_layer_bwd: width_lo must be Din (one output) or below Din (two outputs)");
   hipStream_t st = (hipStream_t)stream, side = side_stream ? (hipStream_t)side_stream : st;
