@@ -214,6 +214,10 @@ int bl_layernorm_bwd(const float* g_y, const float* x, const float* mean, const 
  * here: it needs the pre-activation, see bl_segment_max_bwd.) */
 int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act, bl_dropout_t drop,
                float* g_z, float* g_bias, void* stream);
+/* the same with the result also (or only: g_z may then be NULL) in bl_pack_bf16x3's packed form [nrows, 3 N] (N % 8 == 0):
+ * the operand of the bf16x6 input- and weight-gradient GEMMs of a Linear */
+int bl_act_bwd_packed(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act, bl_dropout_t drop,
+                      float* g_z, float* g_bias, uint16_t* g_z_packed, void* stream);
 
 /* M1 backward, last step: gradient w.r.t. node states from the per-message input gradients
  *   g_h[n, 0:Din] (+)= sum_{e in src CSR of n} g_a[e, 0:Din] + sum_{e in tgt CSR of n} g_a[e, Din:2Din]

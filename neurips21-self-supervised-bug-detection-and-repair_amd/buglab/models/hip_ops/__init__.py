@@ -125,6 +125,7 @@ _SIGNATURES = {
     "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_act_bwd_packed": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gru_cell_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
     "bl_gru_cell_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
@@ -976,7 +977,8 @@ class _MpLayerFused(torch.autograd.Function):
         assert K2 == 2 * Din and T == g.num_types and N == g.num_nodes
         for t, nm in ((W, "W"), (ln_g, "ln_g"), (ln_b, "ln_b"), (Wd, "Wd"), (bd, "bd")):
             _f32(t, nm)
-        need_bwd = torch.is_grad_enabled() and any(t.requires_grad for t in (h_lo, W, Wd) if t is not None)
+        # (grad mode is always off inside Function.forward: whether a backward pass will follow is in needs_input_grad)
+        need_bwd = any(ctx.needs_input_grad[:7])
         # which form of W the input gradient will read: its fp32 transpose (vector-unit path) or the packed C = G . W^T form
         use_vec = DGRAD_VEC and E > 0 and bool(lib.bl_routed_dgrad_vec_ok(Dm, K2))
         wkn, wnk = _packed_layer_weights(W, need_bwd and not use_vec)
@@ -1196,6 +1198,22 @@ def gather_rows(x, idx):
     return _GatherRows.apply(x, idx)
 
 
+# Plain Linear layers with many rows (the sequence models' QKV / output / feed-forward projections) on the bf16x6 path:
+# packed input, epilogue-fused bias / activation / dropout, packed g_z from the activation backward, bf16x6 input and weight
+# gradients.  BL_LINEAR_X6=0: exact-fp32 MFMA GEMMs.
+LINEAR_X6 = os.environ.get("BL_LINEAR_X6", "1") != "0"
+LINEAR_X6_MIN_ROWS = 1024
+
+
+def act_bwd_packed(g_y, y, act, drop: "Dropout", g_bias=None):
+    """-> bf16x3-packed g_z int16 [R, 3 N] of y = drop(act(z + bias)) (bl_act_bwd_packed); g_bias accumulates column sums."""
+    R, N = y.shape
+    out = torch.empty((R, 3 * N), dtype=torch.int16, device=y.device)
+    _check(load_library().bl_act_bwd_packed(_f32(g_y).data_ptr(), _f32(y).data_ptr(), R, N, y.stride(0), int(act), drop.c(), None, _p(g_bias),
+                                            out.data_ptr(), _stream()), "bl_act_bwd_packed")
+    return out
+
+
 class _GatherLinear(torch.autograd.Function):
     """act(concat_j(X_j[idx_j]) @ W + b) without materialising the gather/concat."""
 
@@ -1207,17 +1225,33 @@ class _GatherLinear(torch.autograd.Function):
         xs, idxs = flat[:nsrc], flat[nsrc:]
         sources = list(zip(xs, idxs))
         R = idxs[0].shape[0] if idxs[0] is not None else xs[0].shape[0]
+        K, N = W.shape
+        x6 = (LINEAR_X6 and GEMM_MODE == "bf16x6" and nsrc == 1 and idxs[0] is None and R >= LINEAR_X6_MIN_ROWS and K % 32 == 0
+              and N % 32 == 0 and act in (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH) and xs[0].is_contiguous())
+        if x6:
+            need_bwd = any(ctx.needs_input_grad)
+            xp = pack_bf16x3(xs[0])
+            wkn, wnk = _packed_layer_weights(_f32(W, "W"), need_bwd)
+            out = gemm_rows_x6([(xp, None, K)], wkn, R, N, bias=bias, act=act, drop=drop, kind="linear_x6")
+            ctx.saved = (W, bias is not None, act, sources, out, drop, xp if need_bwd else None, wnk)
+            return out
         out = gemm_rows(sources, _f32(W, "W"), R, W.shape[1], bias=bias, act=act, drop=drop)
-        ctx.saved = (W, bias is not None, act, sources, out, drop)
+        ctx.saved = (W, bias is not None, act, sources, out, drop, None, None)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        W, has_bias, act, sources, out, drop = ctx.saved
+        W, has_bias, act, sources, out, drop, xp, wnk = ctx.saved
         R, N = out.shape
         K = W.shape[0]
         dev = W.device
         g_bias = torch.zeros((N,), dtype=torch.float32, device=dev) if has_bias else None
+        if xp is not None:  # bf16x6 path
+            gzp = act_bwd_packed(g_out.contiguous(), out, act, drop, g_bias)
+            g_W = torch.zeros_like(W)
+            gemm_wgrad_x6([(xp, None, K)], gzp, R, N, g_W)
+            g_x = gemm_rows_x6([(gzp, None, N)], wnk, R, K, kind="linear_dgrad_x6") if ctx.needs_input_grad[4] else None
+            return (g_W, g_bias, None, None, g_x, None) + ((None,) if drop is not NO_DROPOUT else ())
         g_z = act_bwd(g_out.contiguous(), out, act, drop, g_bias)
         g_W = torch.zeros_like(W)
         gemm_wgrad(sources, g_z, R, N, g_W)

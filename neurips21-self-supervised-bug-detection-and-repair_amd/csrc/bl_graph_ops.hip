@@ -842,6 +842,11 @@ extern "C" int bl_act_bwd(const float* g_y, const float* y, int32_t nrows, int32
   return bl_act_bwd_impl(g_y, y, nrows, N, ld, act, drop, g_z, g_bias, nullptr, stream);
 }
 
+extern "C" int bl_act_bwd_packed(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act,
+                                 bl_dropout_t drop, float* g_z, float* g_bias, uint16_t* g_z_packed, void* stream) {
+  return bl_act_bwd_impl(g_y, y, nrows, N, ld, act, drop, g_z, g_bias, g_z_packed, stream);
+}
+
 // + g_z_packed: the result also (or only: g_z may then be NULL) in bl_pack_bf16x3's packed form, rows N wide
 int bl_act_bwd_impl(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act, bl_dropout_t drop,
                     float* g_z, float* g_bias, uint16_t* g_z_packed, void* stream) {
