@@ -172,11 +172,21 @@ def receive_packed(item, device):
 
 
 def collated_minibatches_parallel(model, files: Sequence[str], num_workers: int, max_minibatch_size: int, rank: int = 0,
-                                  world: int = 1, packed: bool = False) -> Iterator:
+                                  world: int = 1, packed: bool = False, pool: "Optional[WorkerPool]" = None) -> Iterator:
     """Collated minibatches of `files`: every worker process reads its shard files, tensorises and collates; the
     consumer only copies a minibatch to the device.  packed = False: NumPy dicts (`buglab.data.collate.to_device` them);
-    packed = True: items for `receive_packed` (the int32 blob travels through shared memory, not the queue's pipe)."""
-    yield from _run_workers(_minibatch_worker, model, files, num_workers, (rank, world, max_minibatch_size, packed), 8, None)
+    packed = True: items for `receive_packed` (the int32 blob travels through shared memory, not the queue's pipe).
+    pool: a `minibatch_pool(...)` of the same arguments that was started earlier (its start-up then overlapped other work)."""
+    if pool is None:
+        pool = minibatch_pool(model, files, num_workers, max_minibatch_size, rank, world, packed)
+    yield from pool
+
+
+def minibatch_pool(model, files: Sequence[str], num_workers: int, max_minibatch_size: int, rank: int = 0, world: int = 1,
+                   packed: bool = False) -> "WorkerPool":
+    """The loader processes behind `collated_minibatches_parallel`, not started yet: `.start()` forks them (e.g. while the
+    previous epoch's validation is still running), iterating yields their minibatches, `.close()` shuts them down."""
+    return WorkerPool(_minibatch_worker, model, files, num_workers, (rank, world, max_minibatch_size, packed), 8, None)
 
 
 def tensorize_shards_parallel(model, files: Sequence[str], num_workers: int, rank: int = 0, world: int = 1,
@@ -184,7 +194,7 @@ def tensorize_shards_parallel(model, files: Sequence[str], num_workers: int, ran
     """Tensorised samples of `files`, produced by `num_workers` forked processes (worker w takes files w, w + W, ...).
     Under data parallelism every rank keeps the datapoints with index % world == rank of each file, like the in-process
     loader.  Sample order across files is not deterministic (files are shuffled by the trainer anyway)."""
-    yield from _run_workers(_worker, model, files, num_workers, (rank, world), 512, limit_num_yielded_elements)
+    yield from WorkerPool(_worker, model, files, num_workers, (rank, world), 512, limit_num_yielded_elements)
 
 
 def _discard(item) -> None:
@@ -199,62 +209,91 @@ def _discard(item) -> None:
             pass
 
 
-def _run_workers(target, model, files: Sequence[str], num_workers: int, extra_args, queue_size: int, limit: Optional[int]) -> Iterator:
-    files = list(files)
-    num_workers = max(1, min(num_workers, len(files))) if files else 0
-    if num_workers == 0:
-        return
-    # One resource tracker for the consumer and all workers: started BEFORE the fork so that the children inherit it.
-    # (A worker forked earlier would start its own tracker, which "cleans up" -- unlinks -- the shared-memory segments
-    # the worker created as soon as the worker exits, i.e. while its last minibatches are still waiting in the queue.)
-    from multiprocessing import resource_tracker
+class WorkerPool:
+    """`num_workers` forked loader processes (worker w takes files w, w + W, ...) feeding one queue.  Iterate to consume;
+    `start()` may be called ahead of time so that forking and the first shards overlap other work; `close()` is idempotent."""
 
-    resource_tracker.ensure_running()
-    ctx = mp.get_context("fork")  # the model (vocabulary, caches) is shared copy-on-write; nothing is pickled to start
-    out_q = ctx.Queue(maxsize=queue_size)
-    stop = ctx.Event()
-    procs = [ctx.Process(target=target, args=(model, files[w::num_workers], *extra_args, out_q, stop), daemon=True)
-             for w in range(num_workers)]
-    # The children inherit the interpreter's heap, including any unreachable-but-not-yet-collected objects of the
-    # trainer (device tensors, HIP events / streams in reference cycles).  A collection inside a child would run their
-    # destructors there, and HIP does not survive a fork: collect here, then freeze what exists so that no child's
-    # collector ever looks at it; the parent thaws its own heap again once the children are running.
-    import gc
+    def __init__(self, target, model, files: Sequence[str], num_workers: int, extra_args, queue_size: int, limit: Optional[int]):
+        self.files = list(files)
+        self.num_workers = max(1, min(num_workers, len(self.files))) if self.files else 0
+        self._args = (target, model, extra_args, queue_size)
+        self.limit = limit
+        self._procs = None
+        self._q = self._stop = None
+        self._closed = False
 
-    gc.collect()
-    gc.freeze()
-    try:
-        for p in procs:
-            p.start()
-    finally:
-        gc.unfreeze()
-    done, n = 0, 0
-    try:
-        while done < num_workers:
-            try:
-                item = out_q.get(timeout=1.0)
-            except queue_mod.Empty:
-                if not any(p.is_alive() for p in procs) and out_q.empty():
-                    raise RuntimeError(f"{num_workers - done} loader process(es) exited without finishing their shards "
-                                       "(killed? out of memory?): the epoch would silently be incomplete")
-                continue
-            if isinstance(item, str) and item == _DONE:
-                done += 1
-                continue
-            if isinstance(item, _WorkerError):
-                raise RuntimeError(item.text)
-            yield item
-            n += 1
-            if limit is not None and n >= limit:
-                break
-    finally:
-        # Shutdown.  Workers see `stop`, finish the item they are putting and exit; the queue is drained meanwhile so that
-        # nobody stays blocked on a full pipe (shared-memory segments of dropped items are unlinked).  A worker that is
-        # still alive after the grace period is killed -- and from then on the pipe may end in a truncated message, on
-        # which a read would block for ever: no reads after a kill.
+    def start(self) -> "WorkerPool":
+        if self._procs is not None or self.num_workers == 0 or self._closed:
+            return self
+        target, model, extra_args, queue_size = self._args
+        # One resource tracker for the consumer and all workers: started BEFORE the fork so that the children inherit it.
+        # (A worker forked earlier would start its own tracker, which "cleans up" -- unlinks -- the shared-memory segments
+        # the worker created as soon as the worker exits, i.e. while its last minibatches are still waiting in the queue.)
+        from multiprocessing import resource_tracker
+
+        resource_tracker.ensure_running()
+        ctx = mp.get_context("fork")  # the model (vocabulary, caches) is shared copy-on-write; nothing is pickled to start
+        self._q = ctx.Queue(maxsize=queue_size)
+        self._stop = ctx.Event()
+        procs = [ctx.Process(target=target, args=(model, self.files[w::self.num_workers], *extra_args, self._q, self._stop), daemon=True)
+                 for w in range(self.num_workers)]
+        # The children inherit the interpreter's heap, including any unreachable-but-not-yet-collected objects of the
+        # trainer (device tensors, HIP events / streams in reference cycles).  A collection inside a child would run their
+        # destructors there, and HIP does not survive a fork: collect here, then freeze what exists so that no child's
+        # collector ever looks at it; the parent thaws its own heap again once the children are running.
+        import gc
+
+        gc.collect()
+        gc.freeze()
+        try:
+            for p in procs:
+                p.start()
+        finally:
+            gc.unfreeze()
+        self._procs = procs
+        return self
+
+    def __iter__(self) -> Iterator:
+        if self.num_workers == 0:
+            return
+        self.start()
+        procs, out_q = self._procs, self._q
+        done, n = 0, 0
+        try:
+            while done < self.num_workers:
+                try:
+                    item = out_q.get(timeout=1.0)
+                except queue_mod.Empty:
+                    if not any(p.is_alive() for p in procs) and out_q.empty():
+                        raise RuntimeError(f"{self.num_workers - done} loader process(es) exited without finishing their shards "
+                                           "(killed? out of memory?): the epoch would silently be incomplete")
+                    continue
+                if isinstance(item, str) and item == _DONE:
+                    done += 1
+                    continue
+                if isinstance(item, _WorkerError):
+                    raise RuntimeError(item.text)
+                yield item
+                n += 1
+                if self.limit is not None and n >= self.limit:
+                    break
+        finally:
+            self.close()
+
+    def close(self) -> None:
+        """Shutdown.  Workers see `stop`, finish the item they are putting and exit; the queue is drained meanwhile so that
+        nobody stays blocked on a full pipe (shared-memory segments of dropped items are unlinked).  A worker that is
+        still alive after the grace period is killed -- and from then on the pipe may end in a truncated message, on
+        which a read would block for ever: no reads after a kill."""
+        if self._closed:
+            return
+        self._closed = True
+        if self._procs is None:
+            return
         import time as _time
 
-        stop.set()
+        procs, out_q = self._procs, self._q
+        self._stop.set()
         deadline = _time.monotonic() + 5.0
         while any(p.is_alive() for p in procs) and _time.monotonic() < deadline:
             try:

@@ -455,6 +455,19 @@ def test_trainer_epoch_loop_with_loader_processes_on_cpu(tmp_path, monkeypatch):
     trainer._run_validation(ds, 0, float("inf"), torch.device("cpu"), True, False)
     assert trainer.neural_module.graphs == 30
     assert set(glob.glob("/dev/shm/psm_*")) <= before
+    # the next epoch's loaders forked ahead of time (what train() does before validation): the epoch picks the pool up, sees
+    # every graph once, and leaves nothing behind; a pool nobody consumes is shut down by _drop_prestarted_pool
+    trainer._prestart_loaders(ds, 1, True)
+    pool = trainer._prestarted[2]
+    assert pool._procs is not None and all(p.is_alive() or p.exitcode == 0 for p in pool._procs)
+    trainer.neural_module.graphs = 0
+    trainer._run_training(ds, 1, torch.device("cpu"), FakeOpt(), None, True)
+    assert trainer.neural_module.graphs == 30 and trainer._prestarted is None and pool._closed
+    trainer._prestart_loaders(ds, 2, True)
+    pool = trainer._prestarted[2]
+    trainer._drop_prestarted_pool()
+    assert pool._closed and not any(p.is_alive() for p in pool._procs)
+    assert set(glob.glob("/dev/shm/psm_*")) <= before
     # the in-process path (loader workers off) sees the same graphs
     monkeypatch.setenv("BUGLAB_LOADER_WORKERS", "0")
     trainer.neural_module.graphs = 0

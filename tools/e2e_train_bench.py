@@ -30,6 +30,10 @@ def main():
     ap.add_argument("--minibatch-size", type=int, default=64)
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--profile", action="store_true", help="cProfile of the trainer thread during the reported epoch")
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--no-prestart", action="store_true", help="do not fork the next epoch's loaders ahead of time (what train() does "
+                    "before it runs validation); the stand-in for the validation pass here is a --validation-s pause")
+    ap.add_argument("--validation-s", type=float, default=1.0)
     a = ap.parse_args()
     os.environ["BUGLAB_LOADER_WORKERS"] = str(a.workers)
 
@@ -103,7 +107,11 @@ def main():
         zero_grad()
 
     opt.zero_grad = marked_zero_grad
-    for epoch in range(2):  # epoch 0 warms up (first-touch allocations, library load); epoch 1 is reported
+    for epoch in range(a.epochs):  # epoch 0 warms up (first-touch allocations, library load); later epochs are reported
+        if epoch > 0:
+            if not a.no_prestart:
+                trainer._prestart_loaders(ds, epoch, True)
+            time.sleep(a.validation_s)  # (stand-in for the validation pass between two training epochs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if a.profile and epoch == 1:
