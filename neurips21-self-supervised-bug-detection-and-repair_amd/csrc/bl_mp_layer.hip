@@ -292,7 +292,10 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
     ProfScope ps(6, 2.0 * N * (double)Dm * Dout, st, two);
     if (dense_x6) {
       p1.xp[0] = (const uint16_t*)B.g_z; p1.width[0] = Dout;
-      BL_TRY(bl_gemm_rows_x6(&p1, nullptr, 0, L->Wd_packed_bwd, 0, nullptr, nullptr, 1, N, Dm, Dout, B.g_ln, Dm, st));
+      // (the epilogue form with nothing in it: a kernel instantiation of its own, so that per-kernel profiles do not mix
+      // this small GEMM with the message GEMM's launches)
+      bl_dropout_t nodrop = {0.f, 0u, 0u};
+      BL_TRY(bl_gemm_rows_x6_epi(&p1, L->Wd_packed_bwd, 0, nullptr, nullptr, 1, N, Dm, Dout, nullptr, BL_ACT_NONE, nodrop, B.g_ln, Dm, st));
     } else {
       r1.x[0] = B.g_z; r1.ld[0] = Dout; r1.width[0] = Dout;
       bl_dropout_t nodrop = {0.f, 0u, 0u};

@@ -11,7 +11,7 @@ acc, n = collections.defaultdict(float), collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     if r["Counter_Name"] != counter:
         continue
-    k = r["Kernel_Name"].split("(")[0][:60]
+    k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
     acc[k] += float(r["Counter_Value"])
     n[k] += 1
 json.dump({k: {"per_launch": round(acc[k] / n[k], 1), "launches": n[k]} for k in acc}, sys.stdout, indent=1)

@@ -35,10 +35,8 @@ for name in ("bench_serial", "bench", "bench_seq"):
         continue
     rows = list(csv.DictReader(open(path)))
     tot = sum(int(x["TotalDurationNs"]) for x in rows)
-    # steps the process ran (warm-up + timed + bench.py's two profiling passes): one dropout-free marker per model
-    marker = "gemm_rows_x6_kernel<false, -1>" if name != "bench_seq" else "masked_softmax_fwd_kernel"
-    per_step = 8 if name != "bench_seq" else 5
-    steps = next(int(x["Calls"]) for x in rows if marker in x["Name"]) / per_step
+    # steps the process ran (warm-up + timed + bench.py's two profiling passes): one fused clip + Adam launch per step
+    steps = next(int(x["Calls"]) for x in rows if x["Name"].startswith("adam_clip_kernel"))
     print(f"--- {name}: kernel ms per step {tot / steps / 1e6:.3f}, {sum(int(x['Calls']) for x in rows) / steps:.0f} launches per step")
     for x in rows[:14]:
         print(f'{x["Name"][:64]:64s} calls/step {int(x["Calls"]) / steps:6.1f}  ms/step {int(x["TotalDurationNs"]) / steps / 1e6:7.3f}  avg us {float(x["AverageNs"]) / 1e3:8.1f}')
