@@ -37,6 +37,10 @@ def main():
             opt.distributed = True
             if mode == "dp":
                 opt.broadcast_parameters(0)
+                # the layer-wise bucketed reduction (asynchronous all-reduces on a communication stream, issued from the
+                # backward notifications) only arms itself for world sizes > 1: force it, so that this path runs on RCCL too
+                opt._dp_active = lambda: True
+                assert opt.set_overlap_groups(module.overlap_parameter_groups())
             for _ in range(3):
                 opt.zero_grad()
                 if mode == "dp" and hasattr(opt, "begin_data_parallel_step"):
@@ -65,7 +69,8 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         assert float(t.sum()) == float(1 << 20)
-        print(f"NCCL_SELFTEST_OK backend={dist.get_backend()} max |param diff| single vs data-parallel step: {diff:.2e}")
+        assert opt._buckets and opt._comm_stream is not None, "the bucketed path did not run"
+        print(f"NCCL_SELFTEST_OK backend={dist.get_backend()} buckets={len(opt._buckets)} max |param diff| single vs data-parallel step: {diff:.2e}")
     finally:
         dist.destroy_process_group()
 
