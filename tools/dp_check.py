@@ -45,6 +45,9 @@ def main():
     module = build()
     opt = FlatAdam(module.parameters(), lr=1e-3, num_warmup_steps=0)
     opt.broadcast_parameters(0)
+    buckets = os.environ.get("DP_CHECK_BUCKETS", "1") != "0"
+    if buckets:  # the trainer's layer-wise buckets: reduced asynchronously behind the backward pass, fixed order on every rank
+        assert opt.set_overlap_groups(module.overlap_parameter_groups())
 
     def replica_gap(t):
         both = [torch.zeros_like(t) for _ in range(2)]
@@ -67,11 +70,13 @@ def main():
             ropt.step_count = opt.step_count
             hip_ops.invalidate_weight_packs()
         opt.zero_grad()
-        B, my_loss = 0, 0.0
-        if not (rank == 1 and step == 3):  # rank 1 runs out of data one step early
+        has_data = not (rank == 1 and step == 3)  # rank 1 runs out of data one step early
+        B, my_loss = (sizes[rank] if has_data else 0), 0.0
+        if buckets:
+            opt.begin_data_parallel_step(B)
+        if has_data:
             loss = module(**mine)
             loss.backward()
-            B = sizes[rank]
             my_loss = float(loss.detach())
         opt.step_data_parallel(B)
         gaps = (replica_gap(opt.flat_grad), replica_gap(opt.sqnorm), replica_gap(opt.flat_param))
@@ -95,12 +100,15 @@ def main():
             worst = max(range(len(names)), key=lambda i: gap_per_param[i])
             report.append((step, dp_loss, float(l.detach()), g_gap, g_scale, gap_per_param[worst], names[worst]))
     opt.zero_grad()
+    if buckets:
+        opt.begin_data_parallel_step(0)
     opt.step_data_parallel(0)  # nobody has data: the idle step that ends an epoch
     assert opt.previous_step_was_idle() and opt.step_count == 4
     torch.cuda.synchronize()
     assert replica_gap(opt.flat_param) == 0.0
     if rank == 0:
-        print(f"dp_check: 2 ranks x {sizes} graphs on {torch.cuda.get_device_name(0)} over {dist.get_backend()}; replicas bit-identical after "
+        print(f"dp_check: 2 ranks x {sizes} graphs on {torch.cuda.get_device_name(0)} over {dist.get_backend()}, "
+              f"{'layer-wise buckets (' + str(len(opt._buckets)) + ') behind backward' if buckets else 'one all-reduce per step'}; replicas bit-identical after "
               f"every step; against one process on the union minibatch:", flush=True)
         for step, dp_loss, ref_loss, g_gap, g_scale, p_gap, p_name in report:
             print(f"  step {step}: loss {dp_loss:.6f} (graph-weighted over ranks) vs {ref_loss:.6f}; max |gradient gap| {g_gap:.2e} "
