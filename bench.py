@@ -81,7 +81,7 @@ def cpu_baseline(args, seconds_budget=25.0):
     from oracle import buglab_oracle as O
 
     nb = 2
-    cfg = O.OracleConfig(hidden=args.hidden, num_layers=args.layers, num_edge_types=args.types, dropout=0.0)
+    cfg = O.OracleConfig(hidden=args.hidden, num_layers=args.layers, num_edge_types=args.types, dropout=args.dropout)
     mb = collate_samples(make_samples(nb, seed=123, num_nodes=args.nodes, num_messages=args.messages, num_edge_types=args.types), args.types)
     params = O.init_params(cfg, seed=0)
     m = {k: torch.zeros_like(v) for k, v in params.items()}
@@ -89,7 +89,7 @@ def cpu_baseline(args, seconds_budget=25.0):
     step, t_spent, n_steps = 0, 0.0, 0
     while True:
         t0 = time.perf_counter()
-        _, grads = O.forward_backward(params, mb, cfg)
+        _, grads = O.forward_backward(params, mb, cfg, seed=step + 1 if args.dropout > 0 else None)  # same dropout rate as the GPU run
         step += 1
         O.adam_clip_step(params, grads, m, v, step)
         dt = time.perf_counter() - t0
@@ -103,7 +103,7 @@ def cpu_baseline(args, seconds_budget=25.0):
         "unit": "graphs/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{n_steps} train steps of {nb} graphs ({args.nodes} nodes/{args.messages} msgs, H{args.hidden}, {args.layers} layers, T{args.types}) on the CPU oracle, dropout 0",
+        "sample": f"{n_steps} train steps of {nb} graphs ({args.nodes} nodes/{args.messages} msgs, H{args.hidden}, {args.layers} layers, T{args.types}) on the CPU oracle, dropout {args.dropout}",
     }
 
 
