@@ -256,6 +256,13 @@ int bl_routed_dgrad_nodes(const float* gq, int32_t ld_gq, const int32_t* msg_src
                           const uint32_t* win_bits, int32_t ld_bits, const int32_t* type_ptr, int32_t T, const float* wt,
                           int32_t E, int32_t Dm, int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi,
                           int32_t ld_hi, void* stream);
+/* bl_routed_dgrad_nodes with the SOURCE half kept per message: g_src[e, 0:Din] = g_a[e, 0:Din] as plain rows (g_src != NULL;
+ * summed per node afterwards by bl_mp_scatter_grad over the source CSR with accumulate = 1), the target half by atomics as
+ * above.  Halves the fp32 atomics, which bound the all-atomic form (one 4-byte atomic per L2 channel per clock). */
+int bl_routed_dgrad_nodes_rows(const float* gq, int32_t ld_gq, const int32_t* msg_src, const int32_t* msg_tgt,
+                               const uint32_t* win_bits, int32_t ld_bits, const int32_t* type_ptr, int32_t T, const float* wt,
+                               int32_t E, int32_t Dm, int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi,
+                               int32_t ld_hi, float* g_src, int32_t ld_src, void* stream);
 
 /* GRU cell of the gated (`ggnn`) node update -- the elementwise part of torch.nn.GRUCell (gate order
  * r | z | n) after gi = x W_i + b_i and gh = h W_h + b_h [N, 3D] were produced by bl_gemm_rows:
@@ -301,8 +308,8 @@ typedef struct {
 } bl_mp_layer_t;
 
 /* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call.
- * backward: 0 = forward call, 1 = backward call, 2 = backward call that will take the bl_routed_dgrad_nodes path (Wt given,
- * shape supported, deterministic mode off): no [E, 2 Din] per-message gradient in the workspace */
+ * backward: 0 = forward call, 1 = backward call, 2 = backward call that will take the bl_routed_dgrad_nodes_rows path (Wt
+ * given, shape supported, deterministic mode off): [E, Din] source-half rows instead of the [E, 2 Din] per-message gradient */
 int64_t bl_mp_layer_saved_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t msg_act);
 int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t Dout, int32_t backward);
 /* uint16 elements of the packed weights a layer call takes: bl_pack_weights_x6(W, T, 2 Din, Dm, w_is_kn = 1) for
@@ -439,8 +446,14 @@ int bl_rel_attn_bias_bwd(const int32_t* row_ptr, const int32_t* ekey, const int3
                          const float* dS, float* g_q, float* g_k, float* g_bias_f, float* g_bias_r, void* stream);
 /* softmax over keys with the padding keys (key >= lens[row / rows_per_sample]) masked, in place (multihead_attention.py:65-71) */
 int bl_masked_softmax_fwd(float* S, int32_t R, int32_t L, int32_t rows_per_sample, const int32_t* lens, void* stream);
+/* ... and nn.Dropout on the probabilities in the same pass (multihead_attention.py:72): S <- P, Pd <- dropout(P) with mask
+ * element row * L + k (= bl_dropout_inplace on a copy of P); drop.p == 0: Pd is not written */
+int bl_masked_softmax_dropout_fwd(float* S, int32_t R, int32_t L, int32_t rows_per_sample, const int32_t* lens, bl_dropout_t drop,
+                                  float* Pd, void* stream);
 /* dP <- P * (dP - sum_k P dP) */
 int bl_softmax_bwd(const float* P, float* dP, int32_t R, int32_t L, void* stream);
+/* the same with dP arriving as the gradient of dropout(P): it passes the mask first (bl_dropout_inplace + bl_softmax_bwd) */
+int bl_softmax_dropout_bwd(const float* P, float* dP, int32_t R, int32_t L, bl_dropout_t drop, void* stream);
 /* `rat` edge value biases (relational_multihead_attention.py:155-178): ctx[b, h, i, :] += P[(b, h, i), key] * vb[code][h, :] */
 int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
                           int32_t dk, const float* P, const float* vb_f, const float* vb_r, float* ctx, void* stream);

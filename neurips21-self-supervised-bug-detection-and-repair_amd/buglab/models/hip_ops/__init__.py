@@ -83,6 +83,8 @@ _SIGNATURES = {
     "bl_routed_dgrad_vec": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_routed_dgrad_nodes": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_routed_dgrad_nodes_rows": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
@@ -112,6 +114,8 @@ _SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_masked_softmax_fwd": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_void_p], ctypes.c_int),
+    "bl_masked_softmax_dropout_fwd": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
+    "bl_softmax_dropout_bwd": ([c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p], ctypes.c_int),
     "bl_rel_value_bias_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_rel_value_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
@@ -1621,12 +1625,11 @@ class _RelAttention(torch.autograd.Function):
             _check(lib.bl_rel_attn_bias_fwd(edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr(), B, L, H, dk, mode,
                                             (kt if scalar_bias else qs).data_ptr(), _f32(bias_f).data_ptr(), _f32(bias_r).data_ptr(),
                                             S.data_ptr(), st), "bl_rel_attn_bias_fwd")
-        _check(lib.bl_masked_softmax_fwd(S.data_ptr(), G * L, L, H * L, _i32(lens).data_ptr(), st), "bl_masked_softmax_fwd")
         P = S
-        Pd = P
-        if drop.p > 0:  # nn.Dropout on the probabilities (multihead_attention.py:72)
-            Pd = P.clone()
-            _check(lib.bl_dropout_inplace(Pd.data_ptr(), Pd.numel(), drop.c(), st), "bl_dropout_inplace")
+        # softmax and nn.Dropout on the probabilities (multihead_attention.py:65-72) in one pass over the scores
+        Pd = torch.empty_like(P) if drop.p > 0 else P
+        _check(lib.bl_masked_softmax_dropout_fwd(S.data_ptr(), G * L, L, H * L, _i32(lens).data_ptr(), drop.c(), Pd.data_ptr(), st),
+               "bl_masked_softmax_dropout_fwd")
         ctx_t = gemm_rows([(Pd, None)], vt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
         if vb_f is not None and edges.num_entries > 0:
             _check(lib.bl_rel_value_bias_fwd(edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr(), B, L, H, dk,
@@ -1657,9 +1660,7 @@ class _RelAttention(torch.autograd.Function):
             if has_e:
                 _check(lib.bl_rel_value_bias_bwd(*ep, B, L, H, dk, T, Pd.data_ptr(), g_ct.data_ptr(), vb_f.data_ptr(), vb_r.data_ptr(),
                                                  dP.data_ptr(), g_vbf.data_ptr(), g_vbr.data_ptr(), st), "bl_rel_value_bias_bwd")
-        if drop.p > 0:
-            _check(lib.bl_dropout_inplace(dP.data_ptr(), dP.numel(), drop.c(), st), "bl_dropout_inplace")
-        _check(lib.bl_softmax_bwd(P.data_ptr(), dP.data_ptr(), G * L, L, st), "bl_softmax_bwd")
+        _check(lib.bl_softmax_dropout_bwd(P.data_ptr(), dP.data_ptr(), G * L, L, drop.c(), st), "bl_softmax_dropout_bwd")  # (mask, then softmax')
         dS = dP
         gemm_rows([(dS, None)], kt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G, out=g_qs.view(G * L, dk))
         gemm_wgrad([(dS, None)], qs.view(G * L, dk), G * L, dk, g_k.view(G, L, dk), gw_group_stride=L * dk, group_ptr=gptr, G=G)
@@ -1738,17 +1739,19 @@ def routed_dgrad_vec(gq, msg_tgt, win_bits, type_ptr, T, wt, E, K2):
     return out
 
 
-def routed_dgrad_nodes(gq, msg_src, msg_tgt, win_bits, type_ptr, T, wt, E, Din, out_lo, out_hi=None):
+def routed_dgrad_nodes(gq, msg_src, msg_tgt, win_bits, type_ptr, T, wt, E, Din, out_lo, out_hi=None, src_rows=None):
     """Adds the routed input gradient straight into the node gradient out_lo [N, split] (+ out_hi [N, Din - split]):
-    routed_dgrad_vec + mp_scatter_grad without the per-message rows (fp32 atomics; the outputs must be zeroed)."""
+    routed_dgrad_vec + mp_scatter_grad without the per-message rows (fp32 atomics; the outputs must be zeroed).
+    src_rows [E, Din]: the source half is written there per message instead (sum it with mp_scatter_grad, accumulate=1)."""
     Dm = gq.shape[1]
     split = out_lo.shape[1]
     with _timed("msg_dgrad_nodes", 2.0 * gq.shape[0] * Dm * 2 * Din):
-        _check(load_library().bl_routed_dgrad_nodes(_f32(gq).data_ptr(), gq.stride(0), _i32(msg_src).data_ptr(), _i32(msg_tgt).data_ptr(),
-                                                   win_bits.data_ptr(), win_bits.stride(0), _i32(type_ptr).data_ptr(), int(T),
-                                                   _f32(wt).data_ptr(), int(E), Dm, int(Din), int(split), out_lo.data_ptr(), out_lo.stride(0),
-                                                   _p(out_hi), out_hi.stride(0) if out_hi is not None else 0, _stream()),
-               "bl_routed_dgrad_nodes")
+        _check(load_library().bl_routed_dgrad_nodes_rows(_f32(gq).data_ptr(), gq.stride(0), _i32(msg_src).data_ptr(), _i32(msg_tgt).data_ptr(),
+                                                        win_bits.data_ptr(), win_bits.stride(0), _i32(type_ptr).data_ptr(), int(T),
+                                                        _f32(wt).data_ptr(), int(E), Dm, int(Din), int(split), out_lo.data_ptr(), out_lo.stride(0),
+                                                        _p(out_hi), out_hi.stride(0) if out_hi is not None else 0, _p(src_rows),
+                                                        src_rows.stride(0) if src_rows is not None else 0, _stream()),
+               "bl_routed_dgrad_nodes_rows")
     return out_lo, out_hi
 
 

@@ -11,6 +11,7 @@
 // ---- error plumbing ---------------------------------------------------------------------------
 void bl_set_error(const char* fmt, ...);
 extern "C" int32_t bl_get_deterministic(void);
+int bl_num_cus();  // bl_core.hip
 // n zeroed turn counters for one launch on `stream`, or nullptr when the deterministic mode is off (bl_core.hip)
 unsigned* bl_order_counters(int n, void* stream);
 
@@ -22,6 +23,9 @@ int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr,
                             uint16_t* ln_out_packed, int32_t num_hub_slots, void* stream);
 int bl_act_bwd_impl(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act, bl_dropout_t drop,
                     float* g_z, float* g_bias, uint16_t* g_z_packed, void* stream);
+int bl_mp_scatter_src_accum_impl(const float* g_src, int32_t ld_src, const int32_t* src_ptr, const int32_t* src_msgs, int32_t N,
+                                 int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi, int32_t ld_hi,
+                                 const int32_t* node_order, void* stream);
 
 #define BL_CHECK_ARG(cond, ...)   \
   do {                            \

@@ -26,6 +26,19 @@ extern "C" int bl_version(void) { return 1; }
 static int g_deterministic = -1;
 
 extern "C" void bl_set_deterministic(int32_t on) { g_deterministic = on ? 1 : 0; }
+// compute units of the current device (256 on MI355X; cached -- the library serves one device per process)
+int bl_num_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount
+              : 256;
+  }
+  return ncu;
+}
+
 extern "C" int32_t bl_get_deterministic(void) {
   if (g_deterministic < 0) {
     const char* e = getenv("BL_DETERMINISTIC");

@@ -542,11 +542,7 @@ static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, c
     hipError_t oe = g_mask ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_kernel<32, 1, 2, true>, 256, 0)
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_kernel<32, 1, 2, false>, 256, 0);
     if (oe != hipSuccess || per_cu <= 0) per_cu = 3;
-    int dev = 0, ncu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
-    resident = per_cu * ncu;
+    resident = per_cu * bl_num_cus();
   }
   const int ntiles_all = ((K + BM - 1) / BM) * ((N + BN - 1) / BN);
   const int extra = (group_ptr ? G : 0) * ntiles_all;  // partial last pieces of the groups

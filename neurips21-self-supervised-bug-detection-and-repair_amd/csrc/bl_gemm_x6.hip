@@ -642,11 +642,7 @@ int wgrad_x6_resident() {
     int per_cu = 0;
     hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_x6_kernel<ROUTED>, 256, 0);
     if (oe != hipSuccess || per_cu <= 0) per_cu = 2;
-    int dev = 0, ncu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
-    resident = per_cu * ncu;
+    resident = per_cu * bl_num_cus();
   }
   return resident;
 }

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int d = lane + 64 * j;
-    acc[j] = (accumulate && d < Din) ? g_h[(size_t)n * ld_gh + d] : 0.f;
+    acc[j] = (accumulate && d < Din) ? (d < split ? g_h[(size_t)n * ld_gh + d] : g_h2[(size_t)n * ld_gh2 + d - split]) : 0.f;
   }
 #pragma unroll
   for (int part = 0; part < 2; ++part) {
@@ -877,6 +877,22 @@ extern "C" int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t
                                        src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh, node_order, Din,
                                        (float*)nullptr, 0))
   BL_LAUNCH_CHECK("bl_mp_scatter_grad");
+  return BL_OK;
+}
+
+// g_h (+)= sums of the SOURCE-half rows g_src [E, Din] over the source CSR (the second step of the half-atomic input gradient,
+// bl_routed_dgrad_nodes_rows); split / g_h_hi as in bl_mp_scatter_grad_split, accumulate on top of what the atomics left there
+int bl_mp_scatter_src_accum_impl(const float* g_src, int32_t ld_src, const int32_t* src_ptr, const int32_t* src_msgs, int32_t N,
+                                 int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi, int32_t ld_hi,
+                                 const int32_t* node_order, void* stream) {
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(g_src && src_ptr && src_msgs && g_h_lo && Din > 0 && Din <= 512 && ld_src >= Din, "bl_mp_scatter_src_accum: bad argument");
+  BL_CHECK_ARG((split == Din && g_h_hi == nullptr) || (split > 0 && split < Din && g_h_hi), "bl_mp_scatter_src_accum: split");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_src, ld_src, src_ptr,
+                                       src_msgs, (const int*)nullptr, (const int*)nullptr, N, Din, 1, g_h_lo, ld_lo, node_order,
+                                       split, g_h_hi, ld_hi))
+  BL_LAUNCH_CHECK("bl_mp_scatter_src_accum");
   return BL_OK;
 }
 

@@ -130,10 +130,10 @@ struct WsBwd {
   float* g_z;      // [N, Dout] fp32, or its bf16x3-packed form [N, 3 Dout] (same region)
   float* g_ln;     // [N, Dm]
   uint16_t* gqp;   // [N, 3 Dm]
-  float* g_a;      // [E, 2 Din]
+  float* g_a;      // [E, 2 Din]; [E, Din] (source halves only) when the node sums are fused into the input gradient
   size_t bytes;
 };
-WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool with_ga = true) {
+WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool full_ga = true) {
   WsBwd w;
   char* p = (char*)base;
   size_t o = 0;
@@ -141,7 +141,7 @@ WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool with_g
   w.g_z = (float*)take((size_t)N * Dout * 6);
   w.g_ln = (float*)take((size_t)N * Dm * 4);
   w.gqp = (uint16_t*)take((size_t)N * 3 * Dm * 2);
-  w.g_a = with_ga ? (float*)take((size_t)E * 2 * Din * 4) : nullptr;
+  w.g_a = (float*)take((size_t)E * (full_ga ? 2 : 1) * Din * 4);
   w.bytes = o;
   return w;
 }
@@ -336,8 +336,15 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
           if (hipMemsetAsync(g_h_hi, 0, (size_t)N * (Din - split) * 4, st) != hipSuccess) { bl_set_error("bl_mp_layer_bwd: memset failed"); return BL_EINVAL; }
         } else if (hipMemset2DAsync(g_h_hi, (size_t)ld_hi * 4, 0, (size_t)(Din - split) * 4, N, st) != hipSuccess) { bl_set_error("bl_mp_layer_bwd: memset failed"); return BL_EINVAL; }
       }
-      BL_TRY(bl_routed_dgrad_nodes(B.g_ln, Dm, L->msg_src, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, Din, split, g_h_lo,
-                                   ld_lo, g_h_hi, ld_hi, st));
+      // target halves by atomics (one per run of equal targets), source halves as rows + a segmented sum over the source CSR:
+      // all-atomic, the kernel is bound by the L2's one fp32 atomic per channel per clock (0.475 vs 0.404 ms at c2's layer shape)
+      // (BL_DGRAD_ATOMIC_SRC=1 keeps the all-atomic form for A/B measurements)
+      static const bool atomic_src = getenv("BL_DGRAD_ATOMIC_SRC") && atoi(getenv("BL_DGRAD_ATOMIC_SRC")) != 0;
+      BL_TRY(bl_routed_dgrad_nodes_rows(B.g_ln, Dm, L->msg_src, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, Din, split,
+                                        g_h_lo, ld_lo, g_h_hi, ld_hi, atomic_src ? nullptr : B.g_a, Din, st));
+      if (!atomic_src)
+        BL_TRY(bl_mp_scatter_src_accum_impl(B.g_a, Din, L->src_ptr, L->src_msgs, N, Din, split, g_h_lo, ld_lo, g_h_hi, ld_hi,
+                                            L->node_order, st));
     } else if (vec_dgrad) {
       ProfScope ps(9, 2.0 * N * (2.0 * Din) * Dm, st, two);
       BL_TRY(bl_routed_dgrad_vec(B.g_ln, Dm, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, 2 * Din, B.g_a, 2 * Din, st));

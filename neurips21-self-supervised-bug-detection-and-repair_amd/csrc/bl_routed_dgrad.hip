@@ -182,10 +182,10 @@ __global__ __launch_bounds__(RD_THREADS, 1) void routed_dgrad_kernel(
         total += __popcll(m);
       }
       if (total == 0) {
-        if (!FUSED) {
+        if (!FUSED || g_a != nullptr) {
           float* __restrict__ o = g_a + (size_t)e * ld_ga + lane;
 #pragma unroll
-          for (int k = 0; k < OPL; ++k) o[64 * k] = 0.f;
+          for (int k = 0; k < (FUSED ? HALF : OPL); ++k) o[64 * k] = 0.f;
         }
         continue;
       }
@@ -227,7 +227,11 @@ __global__ __launch_bounds__(RD_THREADS, 1) void routed_dgrad_kernel(
           }
         }
       }
-      if (FUSED) {  // source half of this message -> its source node
+      if (FUSED && g_a != nullptr) {  // source half as a plain row of g_a [E, Din]: summed per node by bl_mp_scatter_grad afterwards
+        float* __restrict__ o = g_a + (size_t)e * ld_ga + lane;
+#pragma unroll
+        for (int k = 0; k < HALF; ++k) o[64 * k] = HALF == 1 ? acc[0].x : (k & 1 ? acc[k >> 1].y : acc[k >> 1].x);
+      } else if (FUSED) {  // source half of this message -> its source node
 #pragma unroll
         for (int k = 0; k < HALF; ++k) {
           const float val = HALF == 1 ? acc[0].x : (k & 1 ? acc[k >> 1].y : acc[k >> 1].x);
@@ -249,18 +253,6 @@ __global__ __launch_bounds__(RD_THREADS, 1) void routed_dgrad_kernel(
   }
 }
 
-int rd_num_cus() {
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount
-              : 256;
-  }
-  return ncu;
-}
-
 template <int OPL, int NG, bool FUSED>
 int rd_launch(const float* gq, int ld_gq, const int* msg_src, const int* msg_tgt, const uint32_t* win_bits, int ld_bits,
               const int* type_ptr, int T, const float* wt, int E, float* g_a, int ld_ga, RdOut out, hipStream_t st) {
@@ -273,7 +265,7 @@ int rd_launch(const float* gq, int ld_gq, const int* msg_src, const int* msg_tgt
     attr = true;
   }
   // one workgroup per CU is resident (LDS): two rounds of pieces; every type adds at most one short piece
-  const int ncu = rd_num_cus();
+  const int ncu = bl_num_cus();
   const int slots = 2 * ncu > 2 * T ? 2 * ncu - T : ncu;
   int piece = (int)(((long long)E + slots - 1) / slots);
   piece = ((piece < 256 ? 256 : piece) + RD_WAVES * RD_GROUP - 1) / (RD_WAVES * RD_GROUP) * (RD_WAVES * RD_GROUP);
@@ -323,14 +315,23 @@ extern "C" int bl_routed_dgrad_nodes(const float* gq, int32_t ld_gq, const int32
                                      const uint32_t* win_bits, int32_t ld_bits, const int32_t* type_ptr, int32_t T, const float* wt,
                                      int32_t E, int32_t Dm, int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi,
                                      int32_t ld_hi, void* stream) {
+  return bl_routed_dgrad_nodes_rows(gq, ld_gq, msg_src, msg_tgt, win_bits, ld_bits, type_ptr, T, wt, E, Dm, Din, split, g_h_lo, ld_lo,
+                                    g_h_hi, ld_hi, nullptr, 0, stream);
+}
+
+extern "C" int bl_routed_dgrad_nodes_rows(const float* gq, int32_t ld_gq, const int32_t* msg_src, const int32_t* msg_tgt,
+                                          const uint32_t* win_bits, int32_t ld_bits, const int32_t* type_ptr, int32_t T,
+                                          const float* wt, int32_t E, int32_t Dm, int32_t Din, int32_t split, float* g_h_lo,
+                                          int32_t ld_lo, float* g_h_hi, int32_t ld_hi, float* g_src, int32_t ld_src, void* stream) {
   if (E == 0) return BL_OK;
+  BL_CHECK_ARG(g_src == nullptr || ld_src >= Din, "bl_routed_dgrad_nodes_rows: ld_src");
   BL_CHECK_ARG(gq && msg_src && msg_tgt && win_bits && type_ptr && wt && g_h_lo, "bl_routed_dgrad_nodes: null pointer");
   BL_CHECK_ARG(bl_routed_dgrad_vec_ok(Dm, 2 * Din), "bl_routed_dgrad_nodes: unsupported shape Dm=%d Din=%d", Dm, Din);
   BL_CHECK_ARG(ld_bits * 32 >= Dm && ld_gq >= Dm, "bl_routed_dgrad_nodes: ld_bits / ld_gq");
   BL_CHECK_ARG((split == Din && ld_lo >= Din) || (split > 0 && split < Din && g_h_hi && ld_lo >= split && ld_hi >= Din - split),
                "bl_routed_dgrad_nodes: split must be Din (one output) or inside (0, Din) with a second output");
   RdOut out = {g_h_lo, ld_lo, g_h_hi, ld_hi, split};
-  const int rc = rd_dispatch<true>(gq, ld_gq, msg_src, msg_tgt, win_bits, ld_bits, type_ptr, T, wt, E, Dm, 2 * Din, nullptr, 0, out, (hipStream_t)stream);
+  const int rc = rd_dispatch<true>(gq, ld_gq, msg_src, msg_tgt, win_bits, ld_bits, type_ptr, T, wt, E, Dm, 2 * Din, g_src, ld_src, out, (hipStream_t)stream);
   if (rc != 0) {
     bl_set_error("bl_routed_dgrad_nodes: launch failed (%d)", rc);
     return rc;

@@ -177,9 +177,12 @@ __global__ __launch_bounds__(256) void rel_bias_bwd_kernel(const int* __restrict
 
 // ---- masked softmax over keys ------------------------------------------------------------------------
 // rows r = (b, h, i) of S [R, L]; keys >= len[b] are padding (score -inf, probability 0).  In place.  L <= 1024.
+// (+ Pd: the probabilities after nn.Dropout, element i = row * L + k of the counter-hash mask -- what bl_dropout_inplace
+// would make of a copy of P, without the copy and the second pass)
 template <int NV>
 __global__ __launch_bounds__(256) void masked_softmax_fwd_kernel(float* __restrict__ S, int R, int L, int rows_per_sample,
-                                                                 const int* __restrict__ lens) {
+                                                                 const int* __restrict__ lens, bl_drop_dev drop,
+                                                                 float* __restrict__ Pd) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -205,13 +208,19 @@ __global__ __launch_bounds__(256) void masked_softmax_fwd_kernel(float* __restri
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int k = lane + 64 * j;
-    if (k < L) s[k] = v[j] * inv;
+    if (k < L) {
+      const float pr = v[j] * inv;
+      s[k] = pr;
+      if (Pd) Pd[(size_t)row * L + k] = bl_keep(drop, (uint32_t)row * (uint32_t)L + (uint32_t)k) ? pr * drop.scale : 0.f;
+    }
   }
 }
 
-// dS = P * (dP - sum_k P dP), written over dP
-template <int NV>
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int R, int L) {
+// dS = P * (dP - sum_k P dP), written over dP; DROP: dP arrives as the gradient of the DROPPED probabilities and goes
+// through the dropout mask first (bl_dropout_inplace on dP without the extra pass)
+template <int NV, bool DROP>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int R, int L,
+                                                          bl_drop_dev drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     const int k = lane + 64 * j;
     pv[j] = k < L ? p[k] : 0.f;
     gv[j] = k < L ? g[k] : 0.f;
+    if (DROP) gv[j] = bl_keep(drop, (uint32_t)row * (uint32_t)L + (uint32_t)k) ? gv[j] * drop.scale : 0.f;
     dot += pv[j] * gv[j];
   }
   dot = bl_wave_sum(dot);
@@ -384,16 +394,42 @@ extern "C" int bl_masked_softmax_fwd(float* S, int32_t R, int32_t L, int32_t row
   if (R == 0) return BL_OK;
   BL_CHECK_ARG(S && lens && L > 0 && L <= 1024 && rows_per_sample > 0, "bl_masked_softmax_fwd: null pointer or L outside 1..1024");
   hipStream_t st = (hipStream_t)stream;
-  SEQ_DISPATCH(L, hipLaunchKernelGGL((masked_softmax_fwd_kernel<NV>), dim3((R + 3) / 4), dim3(256), 0, st, S, R, L, rows_per_sample, lens))
+  bl_dropout_t none = {0.f, 0u, 0u};
+  SEQ_DISPATCH(L, hipLaunchKernelGGL((masked_softmax_fwd_kernel<NV>), dim3((R + 3) / 4), dim3(256), 0, st, S, R, L, rows_per_sample, lens,
+                                     bl_make_drop(none), (float*)nullptr))
   BL_LAUNCH_CHECK("bl_masked_softmax_fwd");
   return BL_OK;
 }
 
+extern "C" int bl_masked_softmax_dropout_fwd(float* S, int32_t R, int32_t L, int32_t rows_per_sample, const int32_t* lens,
+                                             bl_dropout_t drop, float* Pd, void* stream) {
+  if (R == 0) return BL_OK;
+  BL_CHECK_ARG(S && lens && L > 0 && L <= 1024 && rows_per_sample > 0, "bl_masked_softmax_dropout_fwd: null pointer or L outside 1..1024");
+  BL_CHECK_ARG(drop.p <= 0.f || (Pd && Pd != S && (long long)R * L < (1ll << 32)),
+               "bl_masked_softmax_dropout_fwd: dropout needs a second output and fewer than 2^32 elements");
+  hipStream_t st = (hipStream_t)stream;
+  float* pd = drop.p > 0.f ? Pd : nullptr;
+  SEQ_DISPATCH(L, hipLaunchKernelGGL((masked_softmax_fwd_kernel<NV>), dim3((R + 3) / 4), dim3(256), 0, st, S, R, L, rows_per_sample, lens,
+                                     bl_make_drop(drop), pd))
+  BL_LAUNCH_CHECK("bl_masked_softmax_dropout_fwd");
+  return BL_OK;
+}
+
 extern "C" int bl_softmax_bwd(const float* P, float* dP, int32_t R, int32_t L, void* stream) {
+  bl_dropout_t none = {0.f, 0u, 0u};
+  return bl_softmax_dropout_bwd(P, dP, R, L, none, stream);
+}
+
+extern "C" int bl_softmax_dropout_bwd(const float* P, float* dP, int32_t R, int32_t L, bl_dropout_t drop, void* stream) {
   if (R == 0) return BL_OK;
   BL_CHECK_ARG(P && dP && L > 0 && L <= 1024, "bl_softmax_bwd: null pointer or L outside 1..1024");
+  BL_CHECK_ARG(drop.p <= 0.f || (long long)R * L < (1ll << 32), "bl_softmax_dropout_bwd: more than 2^32 elements");
   hipStream_t st = (hipStream_t)stream;
-  SEQ_DISPATCH(L, hipLaunchKernelGGL((softmax_bwd_kernel<NV>), dim3((R + 3) / 4), dim3(256), 0, st, P, dP, R, L))
+  if (drop.p > 0.f) {
+    SEQ_DISPATCH(L, hipLaunchKernelGGL((softmax_bwd_kernel<NV, true>), dim3((R + 3) / 4), dim3(256), 0, st, P, dP, R, L, bl_make_drop(drop)))
+  } else {
+    SEQ_DISPATCH(L, hipLaunchKernelGGL((softmax_bwd_kernel<NV, false>), dim3((R + 3) / 4), dim3(256), 0, st, P, dP, R, L, bl_make_drop(drop)))
+  }
   BL_LAUNCH_CHECK("bl_softmax_bwd");
   return BL_OK;
 }

@@ -126,6 +126,43 @@ def test_attention_dropout_and_padding():
     assert abs(num - ana) <= 5e-2 * abs(ana), (num, ana)
 
 
+def test_softmax_with_dropout_in_one_pass_equals_the_three_pass_form():
+    """bl_masked_softmax_dropout_fwd / bl_softmax_dropout_bwd are bit-identical to bl_masked_softmax_fwd + a copy +
+    bl_dropout_inplace and to bl_dropout_inplace + bl_softmax_bwd (the same counter-hash mask element per score)."""
+    from buglab.models import hip_ops as ops
+
+    lib = ops.load_library()
+    st = ops._stream()
+    B, H, L = 3, 4, 200
+    R = B * H * L
+    lens = torch.tensor([200, 0, 77], dtype=torch.int32).cuda()  # (a sample without tokens: 0/0 rows like torch.softmax)
+    S = torch.randn(R, L, device="cuda") * 3
+    drop = ops.Dropout(0.3, 11, 5)
+    P_ref = S.clone()
+    ops._check(lib.bl_masked_softmax_fwd(P_ref.data_ptr(), R, L, H * L, lens.data_ptr(), st), "softmax")
+    Pd_ref = P_ref.clone()
+    ops._check(lib.bl_dropout_inplace(Pd_ref.data_ptr(), Pd_ref.numel(), drop.c(), st), "dropout")
+    P, Pd = S.clone(), torch.full_like(S, 7.0)
+    ops._check(lib.bl_masked_softmax_dropout_fwd(P.data_ptr(), R, L, H * L, lens.data_ptr(), drop.c(), Pd.data_ptr(), st), "fused fwd")
+    valid = torch.ones(R, dtype=torch.bool, device="cuda")
+    valid[H * L : 2 * H * L] = False  # the empty sample's rows are NaN in both
+    assert torch.equal(P[valid], P_ref[valid]) and torch.equal(Pd[valid], Pd_ref[valid])
+    assert bool(torch.isnan(P[~valid]).all()) and bool(torch.isnan(P_ref[~valid]).all())
+    kept = float((Pd[valid] != 0).float().mean()) / float((P[valid] != 0).float().mean())
+    assert abs(kept - 0.7) < 0.01
+    # p == 0: the second output is left alone
+    P0, untouched = S.clone(), torch.full_like(S, 7.0)
+    ops._check(lib.bl_masked_softmax_dropout_fwd(P0.data_ptr(), R, L, H * L, lens.data_ptr(), ops.NO_DROPOUT.c(), untouched.data_ptr(), st), "p=0")
+    assert torch.equal(P0[valid], P_ref[valid]) and float(untouched.min()) == 7.0
+    g = torch.randn(R, L, device="cuda")
+    g_ref = g.clone()
+    ops._check(lib.bl_dropout_inplace(g_ref.data_ptr(), g_ref.numel(), drop.c(), st), "dropout")
+    ops._check(lib.bl_softmax_bwd(P_ref.data_ptr(), g_ref.data_ptr(), R, L, st), "softmax bwd")
+    g_f = g.clone()
+    ops._check(lib.bl_softmax_dropout_bwd(P.data_ptr(), g_f.data_ptr(), R, L, drop.c(), st), "fused bwd")
+    assert torch.equal(g_f[valid], g_ref[valid])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the whole model through the registry: host pipeline -> padded minibatch -> HIP encoder + heads, vs the CPU oracle
 _ENC = {"qkv_W": ("self_attn._selfatt_head_transforms.weight", True), "out_W": ("self_attn._out_proj.weight", True),

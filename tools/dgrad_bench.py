@@ -106,6 +106,18 @@ def main():
         ops.routed_dgrad_nodes(gq, src, tgt, bits, ptr, T, wt, E, Din, out_f)
         return out_f
 
+    g_src = torch.empty(E, Din, device="cuda")
+
+    def hybrid():
+        out_f.zero_()
+        ops.routed_dgrad_nodes(gq, src, tgt, bits, ptr, T, wt, E, Din, out_f, src_rows=g_src)
+        ops._check(lib.bl_mp_scatter_grad(g_src.data_ptr(), g_src.stride(0), src_ptr.data_ptr(), src_msgs.data_ptr(), None, None, N, Din, 1,
+                                          out_f.data_ptr(), out_f.stride(0), None, ops._stream()), "scatter")
+        return out_f
+
+    def hybrid_kernel_only():
+        ops.routed_dgrad_nodes(gq, src, tgt, bits, ptr, T, wt, E, Din, out_f, src_rows=g_src)
+
     want = shipped().clone()
     scale = float(want.abs().max())
     got_v = vec().clone()
@@ -121,6 +133,9 @@ def main():
     print(f"(a) shipped routed bf16x6 GEMM + node sums: {timeit(shipped):.3f} ms  (GEMM alone {timeit(gemm_only):.3f})")
     print(f"(b) vector non-zeros -> g_a + node sums:     {timeit(vec):.3f} ms  (kernel alone {timeit(vec_only):.3f})")
     print(f"(c) vector non-zeros, node sums fused:       {timeit(fused):.3f} ms  (incl. zero-fill)")
+    got_h = hybrid().clone()
+    print(f"hybrid         vs shipped: max |diff| {float((got_h - want).abs().max()):.3e}")
+    print(f"(d) target half fused, source half rows + sums: {timeit(hybrid):.3f} ms  (kernel alone {timeit(hybrid_kernel_only):.3f})")
 
 
 if __name__ == "__main__":
