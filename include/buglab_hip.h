@@ -454,6 +454,34 @@ int bl_masked_softmax_dropout_fwd(float* S, int32_t R, int32_t L, int32_t rows_p
 int bl_softmax_bwd(const float* P, float* dP, int32_t R, int32_t L, void* stream);
 /* the same with dP arriving as the gradient of dropout(P): it passes the mask first (bl_dropout_inplace + bl_softmax_bwd) */
 int bl_softmax_dropout_bwd(const float* P, float* dP, int32_t R, int32_t L, bl_dropout_t drop, void* stream);
+/* The attention probabilities of `seq-great` in one kernel (multihead_attention.py:54-72 with the edge terms of
+ * relational_multihead_attention.py:135-152, mode 0): P[(b, h, i), :] = softmax_keys(q[b, h, i, :] . k[b, h, :, :]^T + edge terms,
+ * keys >= lens[b] masked), Pd = dropout(P) (mask element row * L + key; drop.p == 0: Pd not written).  q (pre-scaled), k:
+ * [B, H, L, dk]; the edge CSR may be NULL (no entries); T edge types, bias_f / bias_r [T, H * dk].  Replaces the grouped
+ * Q.K^T GEMM + bl_rel_attn_bias_fwd + bl_masked_softmax_dropout_fwd (three passes over the [B H L, L] scores).
+ * bl_rel_attn_probs_ok: whether the shape is handled (L % 4 == 0, L <= 1024, dk in {16, 32, 64}, K^T of one head in 64 KB,
+ * 2 T dk <= 1024). */
+int32_t bl_rel_attn_probs_ok(int32_t L, int32_t dk, int32_t T);
+int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode,
+                          int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, const float* bias_f, const float* bias_r,
+                          const int32_t* lens, bl_dropout_t drop, float* P, float* Pd, void* stream);
+/* ... and their backward: g_ctx [B, H, L, dk] = gradient of the context, v, q [B, H, L, dk], P from the forward call ->
+ * dS [B H L, L] = d loss / d scores (the grouped GEMMs dQ = dS.K and dK = dS^T.Q read it);  with an edge CSR also
+ * gq_edge [B, H, L, dk] = the edge terms' part of d loss / d q (only rows with entries are written: pass it zeroed) and
+ * g_bias_f / g_bias_r [T, H dk] += (atomics).  Replaces dO.V^T GEMM + bl_softmax_dropout_bwd + bl_rel_attn_bias_bwd. */
+int bl_rel_attn_probs_bwd(const float* g_ctx, const float* v, const float* P, const float* q, const int32_t* row_ptr,
+                          const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T,
+                          const float* bias_f, const float* bias_r, bl_dropout_t drop, float* dS, float* gq_edge, float* g_bias_f,
+                          float* g_bias_r, void* stream);
+/* The attention's four tall-and-skinny products for head dimension 32 (bl_attn_mm32_ok: dk == 32, L % 4 == 0, L <= 1164),
+ * exact-fp32 matrix cores, the head's [L, 32] matrix whole in LDS and the [G L, L] operand streamed once:
+ *   bl_attn_rows_times        out[(g, i), :] = (sum_k A[(g, i), k] M[g, k, :] (+ add[(g, i), :])) * scale   -- P.V, dS.K
+ *   bl_attn_transposed_times  out[g, k, :]   = sum_i A[(g, i), k] Bm[g, i, :]                              -- P^T.dO, dS^T.Q
+ * (the grouped bl_gemm_rows / bl_gemm_wgrad calls of multihead_attention.py:73-77 and their autograd). */
+int32_t bl_attn_mm32_ok(int32_t L, int32_t dk);
+int bl_attn_rows_times(const float* A, const float* M, int32_t G, int32_t L, int32_t dk, const float* add, float scale, float* out,
+                       void* stream);
+int bl_attn_transposed_times(const float* A, const float* Bm, int32_t G, int32_t L, int32_t dk, float* out, void* stream);
 /* `rat` edge value biases (relational_multihead_attention.py:155-178): ctx[b, h, i, :] += P[(b, h, i), key] * vb[code][h, :] */
 int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
                           int32_t dk, const float* P, const float* vb_f, const float* vb_r, float* ctx, void* stream);

@@ -114,6 +114,14 @@ _SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_masked_softmax_fwd": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_void_p], ctypes.c_int),
+    "bl_rel_attn_probs_ok": ([c_int32, c_int32, c_int32], c_int32),
+    "bl_rel_attn_probs_fwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                               c_void_p, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_rel_attn_probs_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                               c_void_p, c_void_p, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_attn_mm32_ok": ([c_int32, c_int32], c_int32),
+    "bl_attn_rows_times": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_float, c_void_p, c_void_p], ctypes.c_int),
+    "bl_attn_transposed_times": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_masked_softmax_dropout_fwd": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
     "bl_softmax_dropout_bwd": ([c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p], ctypes.c_int),
     "bl_rel_value_bias_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
@@ -1602,6 +1610,9 @@ def _uniform_group_ptr(G: int, L: int, device):
     return t
 
 
+FUSED_ATTENTION = os.environ.get("BL_FUSED_ATTENTION", "1") != "0"  # seq-great: scores -> probabilities in one kernel
+
+
 class _RelAttention(torch.autograd.Function):
     """Relational multi-head self-attention between the QKV projection and the output projection
     (reference multihead_attention.py:46-80, relational_multihead_attention.py:72-178).  Q.K^T, P.V and their four
@@ -1619,23 +1630,40 @@ class _RelAttention(torch.autograd.Function):
         qs, kt, vt = t3[0], t3[1], t3[2]
         qs.mul_(scale)  # multihead_attention.py:54: queries pre-scaled
         gptr = _uniform_group_ptr(G, L, qkv.device)
-        S = gemm_rows([(qs.view(G * L, dk), None)], kt, G * L, L, b_is_nk=True, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
         mode = 1 if scalar_bias else 0
-        if edges.num_entries > 0:
-            _check(lib.bl_rel_attn_bias_fwd(edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr(), B, L, H, dk, mode,
-                                            (kt if scalar_bias else qs).data_ptr(), _f32(bias_f).data_ptr(), _f32(bias_r).data_ptr(),
-                                            S.data_ptr(), st), "bl_rel_attn_bias_fwd")
-        P = S
-        # softmax and nn.Dropout on the probabilities (multihead_attention.py:65-72) in one pass over the scores
-        Pd = torch.empty_like(P) if drop.p > 0 else P
-        _check(lib.bl_masked_softmax_dropout_fwd(S.data_ptr(), G * L, L, H * L, _i32(lens).data_ptr(), drop.c(), Pd.data_ptr(), st),
-               "bl_masked_softmax_dropout_fwd")
-        ctx_t = gemm_rows([(Pd, None)], vt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
+        has_e = edges.num_entries > 0
+        if FUSED_ATTENTION and mode == 0 and lib.bl_rel_attn_probs_ok(L, dk, T):
+            # scores, edge terms, masked softmax and nn.Dropout in one kernel: the scores never reach memory
+            P = torch.empty((G * L, L), dtype=torch.float32, device=qkv.device)
+            Pd = torch.empty_like(P) if drop.p > 0 else P
+            _check(lib.bl_rel_attn_probs_fwd(qs.data_ptr(), kt.data_ptr(), edges.row_ptr.data_ptr() if has_e else None,
+                                             edges.key.data_ptr() if has_e else None, edges.code.data_ptr() if has_e else None, B, L, H, dk, T,
+                                             _f32(bias_f).data_ptr(), _f32(bias_r).data_ptr(), _i32(lens).data_ptr(), drop.c(), P.data_ptr(),
+                                             Pd.data_ptr(), st), "bl_rel_attn_probs_fwd")
+        else:
+            S = gemm_rows([(qs.view(G * L, dk), None)], kt, G * L, L, b_is_nk=True, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
+            if has_e:
+                _check(lib.bl_rel_attn_bias_fwd(edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr(), B, L, H, dk, mode,
+                                                (kt if scalar_bias else qs).data_ptr(), _f32(bias_f).data_ptr(), _f32(bias_r).data_ptr(),
+                                                S.data_ptr(), st), "bl_rel_attn_bias_fwd")
+            P = S
+            # softmax and nn.Dropout on the probabilities (multihead_attention.py:65-72) in one pass over the scores
+            Pd = torch.empty_like(P) if drop.p > 0 else P
+            _check(lib.bl_masked_softmax_dropout_fwd(S.data_ptr(), G * L, L, H * L, _i32(lens).data_ptr(), drop.c(), Pd.data_ptr(), st),
+                   "bl_masked_softmax_dropout_fwd")
+        mm32 = bool(FUSED_ATTENTION and lib.bl_attn_mm32_ok(L, dk))  # the skinny products on their own kernels (head dimension 32)
+        if mm32:
+            ctx_t = torch.empty((G * L, dk), dtype=torch.float32, device=qkv.device)
+            _check(lib.bl_attn_rows_times(Pd.data_ptr(), vt.data_ptr(), G, L, dk, None, 1.0, ctx_t.data_ptr(), st), "bl_attn_rows_times")
+        else:
+            ctx_t = gemm_rows([(Pd, None)], vt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
         if vb_f is not None and edges.num_entries > 0:
             _check(lib.bl_rel_value_bias_fwd(edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr(), B, L, H, dk,
                                              Pd.data_ptr(), _f32(vb_f).data_ptr(), _f32(vb_r).data_ptr(), ctx_t.data_ptr(), st),
                    "bl_rel_value_bias_fwd")
         out = ctx_t.view(B, H, L, dk).permute(0, 2, 1, 3).contiguous().view(B * L, D)
+        ctx.fused = bool(FUSED_ATTENTION and mode == 0 and vb_f is None and lib.bl_rel_attn_probs_ok(L, dk, T))
+        ctx.mm32 = mm32
         ctx.saved = (qs, kt, vt, P, Pd, lens, edges, bias_f, bias_r, vb_f, vb_r, B, L, H, dk, T, mode, drop, gptr, scale)
         return out
 
@@ -1648,12 +1676,38 @@ class _RelAttention(torch.autograd.Function):
         dev = g_out.device
         st = _stream()
         g_ct = g_out.view(B, L, H, dk).permute(0, 2, 1, 3).contiguous().view(G * L, dk)
-        dP = gemm_rows([(g_ct, None)], vt, G * L, L, b_is_nk=True, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
-        g3 = torch.zeros((3, B, H, L, dk), dtype=torch.float32, device=dev)
+        mm32 = ctx.mm32
+        g3 = (torch.empty if mm32 else torch.zeros)((3, B, H, L, dk), dtype=torch.float32, device=dev)
         g_qs, g_k, g_v = g3[0], g3[1], g3[2]
-        gemm_wgrad([(Pd, None)], g_ct, G * L, dk, g_v.view(G, L, dk), gw_group_stride=L * dk, group_ptr=gptr, G=G)
+
+        def tn(a, bm, out):  # out[g] = a[g]^T . bm[g]
+            if mm32:
+                _check(lib.bl_attn_transposed_times(a.data_ptr(), bm.data_ptr(), G, L, dk, out.data_ptr(), st), "bl_attn_transposed_times")
+            else:
+                gemm_wgrad([(a, None)], bm.view(G * L, dk), G * L, dk, out.view(G, L, dk), gw_group_stride=L * dk, group_ptr=gptr, G=G)
+
+        tn(Pd, g_ct, g_v)
         has_e = edges.num_entries > 0
         ep = (edges.row_ptr.data_ptr(), edges.key.data_ptr(), edges.code.data_ptr()) if has_e else None
+        if ctx.fused:
+            # dO.V^T, dropout mask, softmax backward and the edge terms' gradients in one kernel; dS is written once
+            (g_bf, r_bf), (g_br, r_br) = _grad_target(bias_f), _grad_target(bias_r)
+            dS = torch.empty((G * L, L), dtype=torch.float32, device=dev)
+            gq_edge = torch.zeros((G * L, dk), dtype=torch.float32, device=dev) if has_e else None
+            _check(lib.bl_rel_attn_probs_bwd(g_ct.data_ptr(), vt.data_ptr(), P.data_ptr(), qs.data_ptr(), *(ep or (None, None, None)), B, L, H, dk, T,
+                                             bias_f.data_ptr(), bias_r.data_ptr(), drop.c(), dS.data_ptr(), _p(gq_edge), g_bf.data_ptr(),
+                                             g_br.data_ptr(), st), "bl_rel_attn_probs_bwd")
+            if mm32:  # dQ = (dS.K + edge part) * scale in one kernel
+                _check(lib.bl_attn_rows_times(dS.data_ptr(), kt.data_ptr(), G, L, dk, _p(gq_edge), scale, g_qs.data_ptr(), st), "bl_attn_rows_times")
+            else:
+                gemm_rows([(dS, None)], kt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G, out=g_qs.view(G * L, dk))
+                if has_e:
+                    g_qs.view(G * L, dk).add_(gq_edge)
+                g_qs.mul_(scale)
+            tn(dS, qs, g_k)
+            g_qkv = g3.permute(1, 3, 2, 0, 4).contiguous().view(B * L, 3 * D)
+            return g_qkv, None, None, r_bf, r_br, None, None, None, None, None, None, None, None, None
+        dP = gemm_rows([(g_ct, None)], vt, G * L, L, b_is_nk=True, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
         r_vbf = r_vbr = None
         if vb_f is not None:
             (g_vbf, r_vbf), (g_vbr, r_vbr) = _grad_target(vb_f), _grad_target(vb_r)
@@ -1662,8 +1716,11 @@ class _RelAttention(torch.autograd.Function):
                                                  dP.data_ptr(), g_vbf.data_ptr(), g_vbr.data_ptr(), st), "bl_rel_value_bias_bwd")
         _check(lib.bl_softmax_dropout_bwd(P.data_ptr(), dP.data_ptr(), G * L, L, drop.c(), st), "bl_softmax_dropout_bwd")  # (mask, then softmax')
         dS = dP
-        gemm_rows([(dS, None)], kt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G, out=g_qs.view(G * L, dk))
-        gemm_wgrad([(dS, None)], qs.view(G * L, dk), G * L, dk, g_k.view(G, L, dk), gw_group_stride=L * dk, group_ptr=gptr, G=G)
+        if mm32:
+            _check(lib.bl_attn_rows_times(dS.data_ptr(), kt.data_ptr(), G, L, dk, None, 1.0, g_qs.data_ptr(), st), "bl_attn_rows_times")
+        else:
+            gemm_rows([(dS, None)], kt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G, out=g_qs.view(G * L, dk))
+        tn(dS, qs, g_k)
         (g_bf, r_bf), (g_br, r_br) = _grad_target(bias_f), _grad_target(bias_r)
         if has_e:
             _check(lib.bl_rel_attn_bias_bwd(*ep, B, L, H, dk, mode, T, (kt if mode == 1 else qs).data_ptr(), bias_f.data_ptr(),

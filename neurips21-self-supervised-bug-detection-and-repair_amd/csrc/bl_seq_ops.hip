@@ -244,6 +244,377 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+// ---- attention probabilities of `seq-great` in one kernel ---------------------------------------------------------
+// P = softmax_keys(q.k^T + edge terms (mode 0), padding masked), Pd = dropout(P) for a block of query rows of one
+// (sample, head): Q.K^T on the vector units (dk = 32: the grouped MFMA GEMM ran one k-step per tile and wrote a [G L, L]
+// score matrix that the edge-term kernel, the softmax and the dropout each read and rewrote -- four passes over 268 MB per
+// layer at BASELINE configs[4]; here the scores live in registers and P / Pd are written once).
+// A 1024-thread workgroup keeps K^T of its (sample, head) in LDS ([dk][Lp + 4] fp32) and the head's edge-bias vectors
+// ([2T][dk + 1]); a wave takes four query rows at a time (every K^T read feeds four rows), a lane owns the keys
+// {256 c + 4 lane + x}: 16-byte LDS reads and 16-byte stores of P, one row = contiguous kilobytes.
+// Same arithmetic as the separate kernels except the order of the dk products of a score (sequential FMAs here).
+#define ATT_ROWS 4      // query rows per wave and step
+#define ATT_WG_ROWS 128 // query rows per workgroup
+template <int DK, int KC>  // KC = 16-byte key chunks per lane: Lp = 256 KC >= L
+__global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const int* __restrict__ row_ptr, const int* __restrict__ ekey,
+                                                              const int* __restrict__ ecode, int L, int H, int T,
+                                                              const float* __restrict__ bias_f, const float* __restrict__ bias_r,
+                                                              const int* __restrict__ lens, bl_drop_dev drop,
+                                                              float* __restrict__ P, float* __restrict__ Pd) {
+  constexpr int LP = 256 * KC, LS = LP + 4, NS = 4 * KC;
+  extern __shared__ __attribute__((aligned(16))) float att_lds[];
+  float* __restrict__ Kt = att_lds;              // [DK][LS]
+  float* __restrict__ bl = att_lds + DK * LS;    // [2 T][DK + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, b = g / H, h = g - b * H, HD = H * DK;
+  {
+    const float* __restrict__ kg = k + (size_t)g * L * DK;
+    for (int x = tid; x < LP * DK; x += 1024) {
+      const int j = x / DK, d = x - j * DK;
+      Kt[d * LS + j] = j < L ? kg[x] : 0.f;
+    }
+    for (int x = tid; x < 2 * T * DK; x += 1024) {
+      const int c = x / DK, d = x - c * DK;
+      bl[c * (DK + 1) + d] = ((c & 1) ? bias_r : bias_f)[(size_t)(c >> 1) * HD + h * DK + d];
+    }
+  }
+  __syncthreads();
+  const int n = lens[b];
+  const int rb = blockIdx.y * ATT_WG_ROWS, re = min(rb + ATT_WG_ROWS, L);
+  for (int i0 = rb + wave * ATT_ROWS; i0 < re; i0 += 16 * ATT_ROWS) {
+    float qv[ATT_ROWS];  // lane d < DK: q[i0 + r][d]
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) qv[r] = lane < DK ? q[((size_t)g * L + min(i0 + r, L - 1)) * DK + lane] : 0.f;
+    float s[ATT_ROWS][NS];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r)
+#pragma unroll
+      for (int x = 0; x < NS; ++x) s[r][x] = 0.f;
+#pragma unroll 2  // (fully unrolled, hipcc hoists every K^T read and query broadcast to the top and spills)
+    for (int d = 0; d < DK; ++d) {
+      float4 kv[KC];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) kv[c] = *reinterpret_cast<const float4*>(Kt + d * LS + 256 * c + 4 * lane);
+#pragma unroll
+      for (int r = 0; r < ATT_ROWS; ++r) {
+        const float qs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv[r]), d));
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          s[r][4 * c + 0] = fmaf(qs, kv[c].x, s[r][4 * c + 0]);
+          s[r][4 * c + 1] = fmaf(qs, kv[c].y, s[r][4 * c + 1]);
+          s[r][4 * c + 2] = fmaf(qs, kv[c].z, s[r][4 * c + 2]);
+          s[r][4 * c + 3] = fmaf(qs, kv[c].w, s[r][4 * c + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+      const int i = i0 + r;
+      if (i >= re) break;  // wave-uniform
+      if (row_ptr) {  // edge terms: <bias[code][h, :], q[i, :]> added at the entry's key, entries in list order
+        const int beg = row_ptr[b * L + i], end = row_ptr[b * L + i + 1];
+        if (beg < end) {
+          float term = 0.f;  // lane c < 2 T: the term of code c
+          if (lane < 2 * T) {
+#pragma unroll 4
+            for (int d = 0; d < DK; ++d)
+              term += bl[lane * (DK + 1) + d] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv[r]), d));
+          }
+          for (int p = beg; p < end; ++p) {
+            const int key = ekey[p], code = ecode[p];
+            const float t = __shfl(term, code, 64);
+            const int owner = (key & 255) >> 2, slot = ((key >> 8) << 2) | (key & 3);
+#pragma unroll
+            for (int x = 0; x < NS; ++x) s[r][x] += (lane == owner && slot == x) ? t : 0.f;
+          }
+        }
+      }
+      float m = NEG_INF_F;
+#pragma unroll
+      for (int x = 0; x < NS; ++x) {
+        const int key = 256 * (x >> 2) + 4 * lane + (x & 3);
+        s[r][x] = key < n ? s[r][x] : NEG_INF_F;
+        m = fmaxf(m, s[r][x]);
+      }
+      m = bl_wave_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int x = 0; x < NS; ++x) {
+        const int key = 256 * (x >> 2) + 4 * lane + (x & 3);
+        s[r][x] = key < n ? expf(s[r][x] - m) : 0.f;
+        sum += s[r][x];
+      }
+      sum = bl_wave_sum(sum);
+      const float inv = 1.0f / sum;  // n == 0 gives 0/0 like torch.softmax of an all -inf row
+      const size_t row = (size_t)g * L + i;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const int key = 256 * c + 4 * lane;
+        if (key < L) {  // (L % 4 == 0)
+          float4 pr = make_float4(s[r][4 * c] * inv, s[r][4 * c + 1] * inv, s[r][4 * c + 2] * inv, s[r][4 * c + 3] * inv);
+          *reinterpret_cast<float4*>(P + row * L + key) = pr;
+          if (Pd) {
+            const uint32_t e0 = (uint32_t)row * (uint32_t)L + (uint32_t)key;
+            pr.x = bl_keep(drop, e0) ? pr.x * drop.scale : 0.f;
+            pr.y = bl_keep(drop, e0 + 1) ? pr.y * drop.scale : 0.f;
+            pr.z = bl_keep(drop, e0 + 2) ? pr.z * drop.scale : 0.f;
+            pr.w = bl_keep(drop, e0 + 3) ? pr.w * drop.scale : 0.f;
+            *reinterpret_cast<float4*>(Pd + row * L + key) = pr;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ... and their backward: dP = dO.V^T on the vector units (V^T in LDS), the dropout mask, the softmax backward against the
+// saved P, and the gradients of the edge terms, per query row in registers; dS is written once (the grouped GEMMs for dQ
+// and dK read it).  Replaces the grouped dO.V^T GEMM + bl_softmax_dropout_bwd + bl_rel_attn_bias_bwd (mode 0).
+// Edge terms of row (b, h, i): coef[c] = sum of dS at the entries with code c;  g_q[i, :] (+)= sum_c coef[c] bias[c][h, :]
+// (written to gq_edge, zero elsewhere);  g_bias[c][h, :] += coef[c] q[i, :] -- summed per wave in registers (lane owns the
+// elements lane + 64 k of the [2 T][dk] table), then per workgroup in LDS, then one atomic per element and workgroup.
+#define ATT_TAB_REGS 16  // 2 T dk <= 1024
+template <int DK, int KC>
+__global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __restrict__ g_ctx, const float* __restrict__ v,
+                                                              const float* __restrict__ P, const float* __restrict__ q,
+                                                              const int* __restrict__ row_ptr, const int* __restrict__ ekey,
+                                                              const int* __restrict__ ecode, int L, int H, int T,
+                                                              const float* __restrict__ bias_f, const float* __restrict__ bias_r,
+                                                              bl_drop_dev drop, int has_drop, float* __restrict__ dS,
+                                                              float* __restrict__ gq_edge, float* __restrict__ g_bias_f,
+                                                              float* __restrict__ g_bias_r) {
+  constexpr int LP = 256 * KC, LS = LP + 4, NS = 4 * KC;
+  extern __shared__ __attribute__((aligned(16))) float att_lds[];
+  float* __restrict__ Vt = att_lds;                 // [DK][LS]
+  float* __restrict__ bl = att_lds + DK * LS;       // [2 T][DK + 1]
+  float* __restrict__ tab = bl + 2 * T * (DK + 1);  // [2 T][DK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, b = g / H, h = g - b * H, HD = H * DK;
+  const int ntab = 2 * T * DK;
+  {
+    const float* __restrict__ vg = v + (size_t)g * L * DK;
+    for (int x = tid; x < LP * DK; x += 1024) {
+      const int j = x / DK, d = x - j * DK;
+      Vt[d * LS + j] = j < L ? vg[x] : 0.f;
+    }
+    if (row_ptr) {
+      for (int x = tid; x < ntab; x += 1024) {
+        const int c = x / DK, d = x - c * DK;
+        bl[c * (DK + 1) + d] = ((c & 1) ? bias_r : bias_f)[(size_t)(c >> 1) * HD + h * DK + d];
+        tab[x] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  float tabacc[ATT_TAB_REGS];
+#pragma unroll
+  for (int kk = 0; kk < ATT_TAB_REGS; ++kk) tabacc[kk] = 0.f;
+  bool any_edges = false;
+  const int rb = blockIdx.y * ATT_WG_ROWS, re = min(rb + ATT_WG_ROWS, L);
+  for (int i0 = rb + wave * ATT_ROWS; i0 < re; i0 += 16 * ATT_ROWS) {
+    float gv[ATT_ROWS];  // lane d < DK: dO[i0 + r][d]
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) gv[r] = lane < DK ? g_ctx[((size_t)g * L + min(i0 + r, L - 1)) * DK + lane] : 0.f;
+    float s[ATT_ROWS][NS];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r)
+#pragma unroll
+      for (int x = 0; x < NS; ++x) s[r][x] = 0.f;
+#pragma unroll 2
+    for (int d = 0; d < DK; ++d) {
+      float4 kv[KC];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) kv[c] = *reinterpret_cast<const float4*>(Vt + d * LS + 256 * c + 4 * lane);
+#pragma unroll
+      for (int r = 0; r < ATT_ROWS; ++r) {
+        const float gs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gv[r]), d));
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          s[r][4 * c + 0] = fmaf(gs, kv[c].x, s[r][4 * c + 0]);
+          s[r][4 * c + 1] = fmaf(gs, kv[c].y, s[r][4 * c + 1]);
+          s[r][4 * c + 2] = fmaf(gs, kv[c].z, s[r][4 * c + 2]);
+          s[r][4 * c + 3] = fmaf(gs, kv[c].w, s[r][4 * c + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+      const int i = i0 + r;
+      if (i >= re) break;  // wave-uniform
+      const size_t row = (size_t)g * L + i;
+      float pv[NS];
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const int key = 256 * c + 4 * lane;
+        float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (key < L) pr = *reinterpret_cast<const float4*>(P + row * L + key);
+        pv[4 * c] = pr.x; pv[4 * c + 1] = pr.y; pv[4 * c + 2] = pr.z; pv[4 * c + 3] = pr.w;
+      }
+#pragma unroll
+      for (int x = 0; x < NS; ++x) {
+        if (has_drop) {
+          const uint32_t e = (uint32_t)row * (uint32_t)L + (uint32_t)(256 * (x >> 2) + 4 * lane + (x & 3));
+          s[r][x] = bl_keep(drop, e) ? s[r][x] * drop.scale : 0.f;
+        }
+        dot += pv[x] * s[r][x];
+      }
+      dot = bl_wave_sum(dot);
+#pragma unroll
+      for (int x = 0; x < NS; ++x) s[r][x] = pv[x] * (s[r][x] - dot);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const int key = 256 * c + 4 * lane;
+        if (key < L) *reinterpret_cast<float4*>(dS + row * L + key) = make_float4(s[r][4 * c], s[r][4 * c + 1], s[r][4 * c + 2], s[r][4 * c + 3]);
+      }
+      if (row_ptr) {
+        const int beg = row_ptr[b * L + i], end = row_ptr[b * L + i + 1];
+        if (beg < end) {
+          any_edges = true;
+          float coef = 0.f;  // lane c < 2 T: sum of dS over this row's entries with code c
+          for (int p = beg; p < end; ++p) {
+            const int key = ekey[p], code = ecode[p];
+            const int owner = (key & 255) >> 2, slot = ((key >> 8) << 2) | (key & 3);
+            float pick = 0.f;
+#pragma unroll
+            for (int x = 0; x < NS; ++x) pick = slot == x ? s[r][x] : pick;
+            const float gval = __shfl(pick, owner, 64);
+            coef += lane == code ? gval : 0.f;
+          }
+          const float qd = q[row * DK + (lane & (DK - 1))];
+          float gq = 0.f;
+          for (int c = 0; c < 2 * T; ++c) gq = fmaf(__shfl(coef, c, 64), bl[c * (DK + 1) + (lane & (DK - 1))], gq);
+          if (lane < DK) gq_edge[row * DK + lane] = gq;
+#pragma unroll
+          for (int kk = 0; kk < ATT_TAB_REGS; ++kk) {
+            const int e = lane + 64 * kk;  // element (code, d) = (e / DK, e % DK) of the table
+            const float cv = __shfl(coef, min(e / DK, 63), 64);  // (every lane takes part in the exchange)
+            if (e < ntab) tabacc[kk] = fmaf(cv, qd, tabacc[kk]);  // (64 % DK == 0: e % DK == lane % DK)
+          }
+        }
+      }
+    }
+  }
+  if (row_ptr) {
+    if (any_edges) {
+#pragma unroll
+      for (int kk = 0; kk < ATT_TAB_REGS; ++kk) {
+        const int e = lane + 64 * kk;
+        if (e < ntab && tabacc[kk] != 0.f) atomicAdd(&tab[e], tabacc[kk]);
+      }
+    }
+    __syncthreads();
+    for (int x = tid; x < ntab; x += 1024) {
+      const float val = tab[x];
+      if (val != 0.f) {
+        const int c = x / DK, d = x - c * DK;
+        unsafeAtomicAdd(((c & 1) ? g_bias_r : g_bias_f) + (size_t)(c >> 1) * HD + h * DK + d, val);
+      }
+    }
+  }
+}
+
+// ---- the four tall-and-skinny products of the attention (head dimension 32) on the exact-fp32 matrix cores --------------
+// P.V, dS.K (rows of a [G L, L] matrix times the head's [L, 32] matrix) and P^T.dO, dS^T.Q (its transpose times one).  The
+// general grouped GEMM stages both operands through LDS tile by tile and had ~48 KB in flight per CU (2 TB/s on a 268 MB
+// operand); here the [L, 32] matrix of the (sample, head) sits in LDS whole, and every lane streams its own elements of the
+// big operand straight from memory into v_mfma_f32_32x32x2_f32 -- 16 or 32 independent loads in flight per lane, no barrier
+// in the loop.  Transposed accumulator (operands swapped): a lane owns one output row and 4 x 4 consecutive columns.
+typedef float att_f32x16 __attribute__((ext_vector_type(16)));
+#define ATT_MM_WAVES 8
+
+// out[(g, i), :] = (sum_k A[(g, i), k] M[g, k, :] (+ add[(g, i), :])) * scale
+__global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const float* __restrict__ A, const float* __restrict__ M, int L,
+                                                                      const float* __restrict__ add, float scale,
+                                                                      float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float att_lds[];  // [L][33]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, half = lane >> 5;
+  const int g = blockIdx.x;
+  {
+    const float* __restrict__ mg = M + (size_t)g * L * 32;
+    for (int x = tid; x < L * 32; x += 64 * ATT_MM_WAVES) att_lds[(x >> 5) * 33 + (x & 31)] = mg[x];
+  }
+  __syncthreads();
+  const int r0 = (blockIdx.y * ATT_MM_WAVES + wave) * 32;
+  if (r0 >= L) return;
+  const int row = min(r0 + li, L - 1);
+  const float* __restrict__ arow = A + ((size_t)g * L + row) * L;
+  att_f32x16 acc;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+  for (int k0 = 0; k0 < L; k0 += 64) {
+    float4 a[8];
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      const int k = k0 + 8 * qq + 4 * half;
+      a[qq] = k < L ? *reinterpret_cast<const float4*>(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);  // (L % 4 == 0)
+    }
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      const int k = min(k0 + 8 * qq + 4 * half, L - 4);
+      const float av[4] = {a[qq].x, a[qq].y, a[qq].z, a[qq].w};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(att_lds[(k + s2) * 33 + li], av[s2], acc, 0, 0, 0);
+    }
+  }
+  if (r0 + li < L) {
+    const size_t o = ((size_t)g * L + row) * 32;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int n = 8 * g4 + 4 * half;
+      float4 v = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+      if (add) {
+        const float4 e = *reinterpret_cast<const float4*>(add + o + n);
+        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+      }
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+      *reinterpret_cast<float4*>(out + o + n) = v;
+    }
+  }
+}
+
+// out[g, key, :] = sum_i A[(g, i), key] Bm[g, i, :]
+__global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_tn32_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int L,
+                                                                      float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float att_lds[];  // [L][33]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, half = lane >> 5;
+  const int g = blockIdx.x;
+  {
+    const float* __restrict__ bg = Bm + (size_t)g * L * 32;
+    for (int x = tid; x < L * 32; x += 64 * ATT_MM_WAVES) att_lds[(x >> 5) * 33 + (x & 31)] = bg[x];
+  }
+  __syncthreads();
+  const int key0 = (blockIdx.y * ATT_MM_WAVES + wave) * 32;
+  if (key0 >= L) return;
+  const int key = min(key0 + li, L - 1);
+  const float* __restrict__ ag = A + (size_t)g * L * L;  // (uniform base + one per-lane offset: scalar-base addressing)
+  const int voff = half * L + key;
+  att_f32x16 acc;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+  for (int i0 = 0; i0 < L; i0 += 64) {
+    float a[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const float* __restrict__ rowp = ag + (size_t)(i0 + 2 * u) * L;
+      a[u] = i0 + 2 * u < L ? rowp[voff] : 0.f;  // (L is even: row i0 + 2 u + 1 exists whenever row i0 + 2 u does)
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int i = min(i0 + 2 * u + half, L - 1);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(att_lds[i * 33 + li], a[u], acc, 0, 0, 0);
+    }
+  }
+  if (key0 + li < L) {
+    const size_t o = ((size_t)g * L + key) * 32;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      *reinterpret_cast<float4*>(out + o + 8 * g4 + 4 * half) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+  }
+}
+
 // ---- edge value biases (`rat`, relational_multihead_attention.py:155-178) ------------------------------------
 // ctx[b, h, i, :] += P[(b, h, i), key] * vb[code][h, :] for every entry of row (b, i)
 template <int NV>
@@ -431,6 +802,128 @@ extern "C" int bl_softmax_dropout_bwd(const float* P, float* dP, int32_t R, int3
     SEQ_DISPATCH(L, hipLaunchKernelGGL((softmax_bwd_kernel<NV, false>), dim3((R + 3) / 4), dim3(256), 0, st, P, dP, R, L, bl_make_drop(drop)))
   }
   BL_LAUNCH_CHECK("bl_softmax_bwd");
+  return BL_OK;
+}
+
+static size_t att_lds_bytes(int L, int dk, int T) {  // K^T or V^T, the head's bias vectors, (backward) their gradient table
+  const int kc = (L + 255) / 256;
+  return ((size_t)dk * (256 * kc + 4) + (size_t)2 * T * (dk + 1) + (size_t)2 * T * dk) * 4;
+}
+// whether bl_rel_attn_probs_fwd handles the shape: K^T of one (sample, head) in 64 KB of LDS, 16-byte rows
+extern "C" int32_t bl_rel_attn_probs_ok(int32_t L, int32_t dk, int32_t T) {
+  if (L <= 0 || L % 4 != 0 || T <= 0 || 2 * T > 64) return 0;
+  const int kc = (L + 255) / 256;
+  if (kc != 1 && kc != 2 && kc != 4) return 0;
+  if (dk != 16 && dk != 32 && dk != 64) return 0;
+  if (2 * T * dk > 64 * ATT_TAB_REGS) return 0;  // the backward keeps the edge-bias gradient table in registers
+  return att_lds_bytes(L, dk, T) <= 72 * 1024;
+}
+
+extern "C" int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode,
+                                     int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, const float* bias_f, const float* bias_r,
+                                     const int32_t* lens, bl_dropout_t drop, float* P, float* Pd, void* stream) {
+  if (B == 0) return BL_OK;
+  BL_CHECK_ARG(q && k && bias_f && bias_r && lens && P && H > 0, "bl_rel_attn_probs_fwd: null pointer");
+  BL_CHECK_ARG((row_ptr == nullptr) == (ekey == nullptr) && (ekey == nullptr) == (ecode == nullptr), "bl_rel_attn_probs_fwd: partial edge CSR");
+  BL_CHECK_ARG(bl_rel_attn_probs_ok(L, dk, T), "bl_rel_attn_probs_fwd: unsupported shape L=%d dk=%d T=%d", L, dk, T);
+  BL_CHECK_ARG(drop.p <= 0.f || (Pd && Pd != P && (long long)B * H * L * L < (1ll << 32)),
+               "bl_rel_attn_probs_fwd: dropout needs a second output and fewer than 2^32 scores");
+  const int kc = (L + 255) / 256;
+  const size_t lds = att_lds_bytes(L, dk, T);
+  float* pd = drop.p > 0.f ? Pd : nullptr;
+  dim3 grid(B * H, (L + ATT_WG_ROWS - 1) / ATT_WG_ROWS);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = -1;
+#define ATT_CASE(DK_, KC_)                                                                                                        \
+  if (dk == DK_ && kc == KC_) {                                                                                                   \
+    static bool attr = false;                                                                                                     \
+    if (!attr) {                                                                                                                  \
+      if (hipFuncSetAttribute((const void*)attn_probs_fwd_kernel<DK_, KC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) { \
+        bl_set_error("bl_rel_attn_probs_fwd: cannot raise the LDS limit");                                                        \
+        return BL_EINVAL;                                                                                                         \
+      }                                                                                                                           \
+      attr = true;                                                                                                                \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((attn_probs_fwd_kernel<DK_, KC_>), grid, dim3(1024), lds, st, q, k, row_ptr, ekey, ecode, L, H, T, bias_f, \
+                       bias_r, lens, bl_make_drop(drop), P, pd);                                                                  \
+    rc = 0;                                                                                                                       \
+  }
+  ATT_CASE(32, 1) ATT_CASE(32, 2) ATT_CASE(16, 1) ATT_CASE(16, 2) ATT_CASE(16, 4) ATT_CASE(64, 1)
+#undef ATT_CASE
+  BL_CHECK_ARG(rc == 0, "bl_rel_attn_probs_fwd: no kernel for L=%d dk=%d", L, dk);
+  BL_LAUNCH_CHECK("bl_rel_attn_probs_fwd");
+  return BL_OK;
+}
+
+extern "C" int bl_rel_attn_probs_bwd(const float* g_ctx, const float* v, const float* P, const float* q, const int32_t* row_ptr,
+                                     const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T,
+                                     const float* bias_f, const float* bias_r, bl_dropout_t drop, float* dS, float* gq_edge,
+                                     float* g_bias_f, float* g_bias_r, void* stream) {
+  if (B == 0) return BL_OK;
+  BL_CHECK_ARG(g_ctx && v && P && q && bias_f && bias_r && dS && H > 0, "bl_rel_attn_probs_bwd: null pointer");
+  BL_CHECK_ARG((row_ptr == nullptr) == (ekey == nullptr) && (ekey == nullptr) == (ecode == nullptr), "bl_rel_attn_probs_bwd: partial edge CSR");
+  BL_CHECK_ARG(row_ptr == nullptr || (gq_edge && g_bias_f && g_bias_r), "bl_rel_attn_probs_bwd: edge entries need gq_edge, g_bias_f, g_bias_r");
+  BL_CHECK_ARG(bl_rel_attn_probs_ok(L, dk, T), "bl_rel_attn_probs_bwd: unsupported shape L=%d dk=%d T=%d", L, dk, T);
+  BL_CHECK_ARG(drop.p <= 0.f || (long long)B * H * L * L < (1ll << 32), "bl_rel_attn_probs_bwd: more than 2^32 scores");
+  const int kc = (L + 255) / 256;
+  const size_t lds = att_lds_bytes(L, dk, T);
+  dim3 grid(B * H, (L + ATT_WG_ROWS - 1) / ATT_WG_ROWS);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = -1;
+#define ATT_CASE(DK_, KC_)                                                                                                        \
+  if (dk == DK_ && kc == KC_) {                                                                                                   \
+    static bool attr = false;                                                                                                     \
+    if (!attr) {                                                                                                                  \
+      if (hipFuncSetAttribute((const void*)attn_probs_bwd_kernel<DK_, KC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) { \
+        bl_set_error("bl_rel_attn_probs_bwd: cannot raise the LDS limit");                                                        \
+        return BL_EINVAL;                                                                                                         \
+      }                                                                                                                           \
+      attr = true;                                                                                                                \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((attn_probs_bwd_kernel<DK_, KC_>), grid, dim3(1024), lds, st, g_ctx, v, P, q, row_ptr, ekey, ecode, L, H, T, \
+                       bias_f, bias_r, bl_make_drop(drop), drop.p > 0.f ? 1 : 0, dS, gq_edge, g_bias_f, g_bias_r);                \
+    rc = 0;                                                                                                                       \
+  }
+  ATT_CASE(32, 1) ATT_CASE(32, 2) ATT_CASE(16, 1) ATT_CASE(16, 2) ATT_CASE(16, 4) ATT_CASE(64, 1)
+#undef ATT_CASE
+  BL_CHECK_ARG(rc == 0, "bl_rel_attn_probs_bwd: no kernel for L=%d dk=%d", L, dk);
+  BL_LAUNCH_CHECK("bl_rel_attn_probs_bwd");
+  return BL_OK;
+}
+
+static int att_mm_lds(const void* fn, int L, const char* who) {
+  const size_t lds = (size_t)L * 33 * sizeof(float);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
+    bl_set_error("%s: cannot raise the LDS limit", who);
+    return BL_EINVAL;
+  }
+  return BL_OK;
+}
+
+extern "C" int32_t bl_attn_mm32_ok(int32_t L, int32_t dk) { return dk == 32 && L > 0 && L % 4 == 0 && (size_t)L * 33 * 4 <= 152 * 1024; }
+
+extern "C" int bl_attn_rows_times(const float* A, const float* M, int32_t G, int32_t L, int32_t dk, const float* add, float scale,
+                                  float* out, void* stream) {
+  if (G == 0) return BL_OK;
+  BL_CHECK_ARG(A && M && out, "bl_attn_rows_times: null pointer");
+  BL_CHECK_ARG(bl_attn_mm32_ok(L, dk), "bl_attn_rows_times: needs dk == 32, L %% 4 == 0, L <= 1164 (got L=%d dk=%d)", L, dk);
+  int rc = att_mm_lds((const void*)attn_nn32_kernel, L, "bl_attn_rows_times");
+  if (rc != BL_OK) return rc;
+  dim3 grid(G, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
+  hipLaunchKernelGGL(attn_nn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, M, L, add, scale, out);
+  BL_LAUNCH_CHECK("bl_attn_rows_times");
+  return BL_OK;
+}
+
+extern "C" int bl_attn_transposed_times(const float* A, const float* Bm, int32_t G, int32_t L, int32_t dk, float* out, void* stream) {
+  if (G == 0) return BL_OK;
+  BL_CHECK_ARG(A && Bm && out, "bl_attn_transposed_times: null pointer");
+  BL_CHECK_ARG(bl_attn_mm32_ok(L, dk), "bl_attn_transposed_times: needs dk == 32, L %% 4 == 0, L <= 1164 (got L=%d dk=%d)", L, dk);
+  int rc = att_mm_lds((const void*)attn_tn32_kernel, L, "bl_attn_transposed_times");
+  if (rc != BL_OK) return rc;
+  dim3 grid(G, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
+  hipLaunchKernelGGL(attn_tn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, Bm, L, out);
+  BL_LAUNCH_CHECK("bl_attn_transposed_times");
   return BL_OK;
 }
 

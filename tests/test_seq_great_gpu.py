@@ -126,6 +126,74 @@ def test_attention_dropout_and_padding():
     assert abs(num - ana) <= 5e-2 * abs(ana), (num, ana)
 
 
+@pytest.mark.parametrize("B,L,H,dk,T,p", [(2, 64, 4, 32, 3, 0.0), (3, 200, 2, 32, 8, 0.2), (1, 512, 8, 32, 8, 0.1), (2, 96, 4, 16, 5, 0.3),
+                                          (2, 40, 2, 64, 2, 0.0)])
+def test_fused_attention_kernels_equal_the_gemm_and_rowwise_path(B, L, H, dk, T, p):
+    """The one-kernel attention probabilities (and their backward) of seq-great against the grouped-GEMM + edge-term +
+    softmax + dropout kernels they replace: context and every gradient, ragged lengths, repeated edges, a row without edges."""
+    from buglab.data.seqcollate import edge_csr
+    from buglab.models import hip_ops as ops
+
+    rng = np.random.default_rng(L + dk)
+    D = H * dk
+    lens_np = rng.integers(max(1, L // 3), L + 1, B).astype(np.int32)
+    lens_np[0] = L
+    ne = 6 * L
+    e = np.stack([rng.integers(0, B, ne), rng.integers(0, L, ne), rng.integers(0, L, ne)], 1)
+    e = e[(e[:, 1] < lens_np[e[:, 0]]) & (e[:, 2] < lens_np[e[:, 0]]) & (e[:, 1] != 3)]  # (position 3 has no outgoing entries)
+    e = np.concatenate([e, e[:5]])  # repeated edges accumulate
+    kinds = rng.integers(0, T, e.shape[0])
+    rp, key, code = edge_csr(e, kinds, B, L)
+    edges = ops.RelEdges(torch.from_numpy(rp).cuda(), torch.from_numpy(key).cuda(), torch.from_numpy(code).cuda(), int(key.shape[0]))
+    lens = torch.from_numpy(lens_np).cuda()
+    torch.manual_seed(1)
+    qkv0 = torch.randn(B * L, 3 * D, device="cuda")
+    bf0, br0 = torch.randn(T, D, device="cuda") * 0.3, torch.randn(T, D, device="cuda") * 0.3
+    w = torch.randn(B * L, D, device="cuda")
+    valid = (torch.arange(L, device="cuda")[None, :] < lens[:, None]).reshape(-1)  # padded query rows attend to garbage in both paths
+    res = {}
+    assert ops.load_library().bl_rel_attn_probs_ok(L, dk, T) == 1
+    for fused in (True, False):
+        ops.FUSED_ATTENTION = fused
+        try:
+            qkv, bf, br = qkv0.clone().requires_grad_(True), bf0.clone().requires_grad_(True), br0.clone().requires_grad_(True)
+            out = ops.rel_attention(qkv, lens, edges, bf, br, None, None, B, L, H, dk, T, drop=ops.Dropout(p, 5, 2))
+            (out[valid] * w[valid]).sum().backward()
+            torch.cuda.synchronize()
+            res[fused] = (out.detach()[valid], qkv.grad.view(B * L, -1)[valid], bf.grad, br.grad)
+        finally:
+            ops.FUSED_ATTENTION = True
+    for a, b_, name in zip(res[True], res[False], ("context", "g_qkv", "g_bias_f", "g_bias_r")):
+        scale = max(1.0, float(b_.abs().max()))
+        assert float((a - b_).abs().max()) < 2e-5 * scale, name
+
+
+@pytest.mark.parametrize("G,L", [(3, 32), (5, 200), (2, 516), (1, 1024)])
+def test_skinny_attention_products_match_fp64(G, L):
+    """bl_attn_rows_times (P.V, dS.K with the fused add and scale) and bl_attn_transposed_times (P^T.dO, dS^T.Q), exact-fp32
+    matrix cores, against fp64 matmuls: partial 32-row / 32-key tiles and a length that is not a multiple of the k-chunk."""
+    from buglab.models import hip_ops as ops
+
+    lib = ops.load_library()
+    st = ops._stream()
+    assert lib.bl_attn_mm32_ok(L, 32) == 1 and lib.bl_attn_mm32_ok(L, 16) == 0 and lib.bl_attn_mm32_ok(L + 2, 32) == 0
+    torch.manual_seed(L)
+    A = torch.randn(G * L, L, device="cuda")
+    M = torch.randn(G, L, 32, device="cuda")
+    add = torch.randn(G * L, 32, device="cuda")
+    out = torch.full((G * L, 32), float("nan"), device="cuda")
+    ops._check(lib.bl_attn_rows_times(A.data_ptr(), M.data_ptr(), G, L, 32, add.data_ptr(), 0.25, out.data_ptr(), st), "nn")
+    ref = (torch.bmm(A.view(G, L, L).double(), M.double()).view(G * L, 32) + add.double()) * 0.25
+    assert float((out.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    ops._check(lib.bl_attn_rows_times(A.data_ptr(), M.data_ptr(), G, L, 32, None, 1.0, out.data_ptr(), st), "nn")
+    ref = torch.bmm(A.view(G, L, L).double(), M.double()).view(G * L, 32)
+    assert float((out.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    out_t = torch.full((G, L, 32), float("nan"), device="cuda")
+    ops._check(lib.bl_attn_transposed_times(A.data_ptr(), M.data_ptr(), G, L, 32, out_t.data_ptr(), st), "tn")
+    ref_t = torch.bmm(A.view(G, L, L).double().transpose(1, 2), M.double())
+    assert float((out_t.double() - ref_t).abs().max()) < 2e-5 * max(1.0, float(ref_t.abs().max()))
+
+
 def test_softmax_with_dropout_in_one_pass_equals_the_three_pass_form():
     """bl_masked_softmax_dropout_fwd / bl_softmax_dropout_bwd are bit-identical to bl_masked_softmax_fwd + a copy +
     bl_dropout_inplace and to bl_dropout_inplace + bl_softmax_bwd (the same counter-hash mask element per score)."""
