@@ -273,12 +273,14 @@ class KernelTimer:
         of the same layer ran on the side stream: their event spans share the GPU and must not be
         read as exclusive kernel time (the enclosing "*_pair" span is the exclusive one)."""
         out = {}
-        for kind, flop, e0, e1, overlapped in self.records:
+        for kind, flop, e0, e1, overlapped, nbytes in self.records:
             d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flop": 0.0, "overlapped": False})
             d["overlapped"] = d["overlapped"] or overlapped
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flop"] += flop
+            if nbytes:
+                d["bytes"] = d.get("bytes", 0.0) + nbytes  # algorithmic bytes of a memory-bound kind
         lib = load_library()
         for k in range(lib.bl_prof_num_kinds()):
             ms, flop, n, ov = ctypes.c_double(), ctypes.c_double(), c_int64(), c_int32()
@@ -298,9 +300,9 @@ _free_running = False  # weight-gradient GEMMs of earlier layers may still be ru
 
 
 class _timed:
-    def __init__(self, kind, flop, span=False):
+    def __init__(self, kind, flop, span=False, nbytes=0.0):
         self.t = KernelTimer.active
-        self.kind, self.flop, self.span = kind, flop, span
+        self.kind, self.flop, self.span, self.nbytes = kind, flop, span, nbytes
 
     def __enter__(self):
         if self.t is not None:
@@ -311,7 +313,7 @@ class _timed:
         if self.t is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.t.records.append((self.kind, self.flop, self.e0, e1, (not self.span) and (_overlap_depth > 0 or _free_running)))
+            self.t.records.append((self.kind, self.flop, self.e0, e1, (not self.span) and (_overlap_depth > 0 or _free_running), self.nbytes))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1636,10 +1638,11 @@ class _RelAttention(torch.autograd.Function):
             # scores, edge terms, masked softmax and nn.Dropout in one kernel: the scores never reach memory
             P = torch.empty((G * L, L), dtype=torch.float32, device=qkv.device)
             Pd = torch.empty_like(P) if drop.p > 0 else P
-            _check(lib.bl_rel_attn_probs_fwd(qs.data_ptr(), kt.data_ptr(), edges.row_ptr.data_ptr() if has_e else None,
-                                             edges.key.data_ptr() if has_e else None, edges.code.data_ptr() if has_e else None, B, L, H, dk, T,
-                                             _f32(bias_f).data_ptr(), _f32(bias_r).data_ptr(), _i32(lens).data_ptr(), drop.c(), P.data_ptr(),
-                                             Pd.data_ptr(), st), "bl_rel_attn_probs_fwd")
+            with _timed("attn_probs_fwd", 0.0, nbytes=4.0 * G * L * (L * (2 if drop.p > 0 else 1) + 2 * dk)):  # writes P (+ Pd), reads q, k
+                _check(lib.bl_rel_attn_probs_fwd(qs.data_ptr(), kt.data_ptr(), edges.row_ptr.data_ptr() if has_e else None,
+                                                 edges.key.data_ptr() if has_e else None, edges.code.data_ptr() if has_e else None, B, L, H, dk, T,
+                                                 _f32(bias_f).data_ptr(), _f32(bias_r).data_ptr(), _i32(lens).data_ptr(), drop.c(), P.data_ptr(),
+                                                 Pd.data_ptr(), st), "bl_rel_attn_probs_fwd")
         else:
             S = gemm_rows([(qs.view(G * L, dk), None)], kt, G * L, L, b_is_nk=True, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
             if has_e:
@@ -1654,7 +1657,8 @@ class _RelAttention(torch.autograd.Function):
         mm32 = bool(FUSED_ATTENTION and lib.bl_attn_mm32_ok(L, dk))  # the skinny products on their own kernels (head dimension 32)
         if mm32:
             ctx_t = torch.empty((G * L, dk), dtype=torch.float32, device=qkv.device)
-            _check(lib.bl_attn_rows_times(Pd.data_ptr(), vt.data_ptr(), G, L, dk, None, 1.0, ctx_t.data_ptr(), st), "bl_attn_rows_times")
+            with _timed("attn_rows_times", 2.0 * G * L * L * dk, nbytes=4.0 * G * L * (L + 2 * dk)):
+                _check(lib.bl_attn_rows_times(Pd.data_ptr(), vt.data_ptr(), G, L, dk, None, 1.0, ctx_t.data_ptr(), st), "bl_attn_rows_times")
         else:
             ctx_t = gemm_rows([(Pd, None)], vt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G)
         if vb_f is not None and edges.num_entries > 0:
@@ -1682,7 +1686,8 @@ class _RelAttention(torch.autograd.Function):
 
         def tn(a, bm, out):  # out[g] = a[g]^T . bm[g]
             if mm32:
-                _check(lib.bl_attn_transposed_times(a.data_ptr(), bm.data_ptr(), G, L, dk, out.data_ptr(), st), "bl_attn_transposed_times")
+                with _timed("attn_transposed_times", 2.0 * G * L * L * dk, nbytes=4.0 * G * L * (L + 2 * dk)):
+                    _check(lib.bl_attn_transposed_times(a.data_ptr(), bm.data_ptr(), G, L, dk, out.data_ptr(), st), "bl_attn_transposed_times")
             else:
                 gemm_wgrad([(a, None)], bm.view(G * L, dk), G * L, dk, out.view(G, L, dk), gw_group_stride=L * dk, group_ptr=gptr, G=G)
 
@@ -1694,11 +1699,13 @@ class _RelAttention(torch.autograd.Function):
             (g_bf, r_bf), (g_br, r_br) = _grad_target(bias_f), _grad_target(bias_r)
             dS = torch.empty((G * L, L), dtype=torch.float32, device=dev)
             gq_edge = torch.zeros((G * L, dk), dtype=torch.float32, device=dev) if has_e else None
-            _check(lib.bl_rel_attn_probs_bwd(g_ct.data_ptr(), vt.data_ptr(), P.data_ptr(), qs.data_ptr(), *(ep or (None, None, None)), B, L, H, dk, T,
-                                             bias_f.data_ptr(), bias_r.data_ptr(), drop.c(), dS.data_ptr(), _p(gq_edge), g_bf.data_ptr(),
-                                             g_br.data_ptr(), st), "bl_rel_attn_probs_bwd")
+            with _timed("attn_probs_bwd", 0.0, nbytes=4.0 * G * L * (2 * L + 3 * dk)):  # reads P, dO, v, q; writes dS
+                _check(lib.bl_rel_attn_probs_bwd(g_ct.data_ptr(), vt.data_ptr(), P.data_ptr(), qs.data_ptr(), *(ep or (None, None, None)), B, L, H, dk, T,
+                                                 bias_f.data_ptr(), bias_r.data_ptr(), drop.c(), dS.data_ptr(), _p(gq_edge), g_bf.data_ptr(),
+                                                 g_br.data_ptr(), st), "bl_rel_attn_probs_bwd")
             if mm32:  # dQ = (dS.K + edge part) * scale in one kernel
-                _check(lib.bl_attn_rows_times(dS.data_ptr(), kt.data_ptr(), G, L, dk, _p(gq_edge), scale, g_qs.data_ptr(), st), "bl_attn_rows_times")
+                with _timed("attn_rows_times", 2.0 * G * L * L * dk, nbytes=4.0 * G * L * (L + 2 * dk)):
+                    _check(lib.bl_attn_rows_times(dS.data_ptr(), kt.data_ptr(), G, L, dk, _p(gq_edge), scale, g_qs.data_ptr(), st), "bl_attn_rows_times")
             else:
                 gemm_rows([(dS, None)], kt, G * L, dk, b_group_stride=L * dk, ldb=dk, group_ptr=gptr, G=G, out=g_qs.view(G * L, dk))
                 if has_e:

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 // Same arithmetic as the separate kernels except the order of the dk products of a score (sequential FMAs here).
 #define ATT_ROWS 4      // query rows per wave and step
 #define ATT_WG_ROWS 128 // query rows per workgroup
+#define ATT_ITERS (ATT_WG_ROWS / (16 * ATT_ROWS))  // steps per wave
 template <int DK, int KC>  // KC = 16-byte key chunks per lane: Lp = 256 KC >= L
 __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const int* __restrict__ row_ptr, const int* __restrict__ ekey,
@@ -268,6 +269,12 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __res
   float* __restrict__ bl = att_lds + DK * LS;    // [2 T][DK + 1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x, b = g / H, h = g - b * H, HD = H * DK;
+  const int rb = blockIdx.y * ATT_WG_ROWS, re = min(rb + ATT_WG_ROWS, L);
+  // the CSR bounds of this wave's rows, requested before the staging of K^T: lane r <= ATT_ROWS of rpv[it] = row_ptr[b L + i0 + r]
+  int rpv[ATT_ITERS];
+#pragma unroll
+  for (int it = 0; it < ATT_ITERS; ++it)
+    rpv[it] = (row_ptr && lane <= ATT_ROWS) ? row_ptr[b * L + min(rb + (16 * it + wave) * ATT_ROWS + lane, L)] : 0;
   {
     const float* __restrict__ kg = k + (size_t)g * L * DK;
     for (int x = tid; x < LP * DK; x += 1024) {
@@ -281,11 +288,22 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __res
   }
   __syncthreads();
   const int n = lens[b];
-  const int rb = blockIdx.y * ATT_WG_ROWS, re = min(rb + ATT_WG_ROWS, L);
-  for (int i0 = rb + wave * ATT_ROWS; i0 < re; i0 += 16 * ATT_ROWS) {
+#pragma unroll
+  for (int it = 0; it < ATT_ITERS; ++it) {
+    const int i0 = rb + (16 * it + wave) * ATT_ROWS;
+    if (i0 >= re) break;
     float qv[ATT_ROWS];  // lane d < DK: q[i0 + r][d]
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r) qv[r] = lane < DK ? q[((size_t)g * L + min(i0 + r, L - 1)) * DK + lane] : 0.f;
+    // the rows' edge entries, up to 64 each, one per lane: requested here, used after the score loop
+    int ebeg[ATT_ROWS], ecnt[ATT_ROWS], ek[ATT_ROWS], ec[ATT_ROWS];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+      ebeg[r] = __builtin_amdgcn_readlane(rpv[it], r);
+      ecnt[r] = i0 + r < re ? __builtin_amdgcn_readlane(rpv[it], r + 1) - ebeg[r] : 0;
+      ek[r] = lane < ecnt[r] ? ekey[ebeg[r] + lane] : 0;
+      ec[r] = lane < ecnt[r] ? ecode[ebeg[r] + lane] : 0;
+    }
     float s[ATT_ROWS][NS];
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r)
@@ -312,22 +330,28 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __res
     for (int r = 0; r < ATT_ROWS; ++r) {
       const int i = i0 + r;
       if (i >= re) break;  // wave-uniform
-      if (row_ptr) {  // edge terms: <bias[code][h, :], q[i, :]> added at the entry's key, entries in list order
-        const int beg = row_ptr[b * L + i], end = row_ptr[b * L + i + 1];
-        if (beg < end) {
-          float term = 0.f;  // lane c < 2 T: the term of code c
-          if (lane < 2 * T) {
+      if (ecnt[r] > 0) {  // edge terms: <bias[code][h, :], q[i, :]> added at the entry's key, entries in list order
+        float term = 0.f;  // lane c < 2 T: the term of code c
+        if (lane < 2 * T) {
 #pragma unroll 4
-            for (int d = 0; d < DK; ++d)
-              term += bl[lane * (DK + 1) + d] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv[r]), d));
+          for (int d = 0; d < DK; ++d)
+            term += bl[lane * (DK + 1) + d] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv[r]), d));
+        }
+        for (int p = 0; p < ecnt[r]; ++p) {  // everything about an entry is wave-uniform: scalar registers and branches
+          int key, code;
+          if (p < 64) {
+            key = __builtin_amdgcn_readlane(ek[r], p);
+            code = __builtin_amdgcn_readlane(ec[r], p);
+          } else {
+            key = __builtin_amdgcn_readfirstlane(ekey[ebeg[r] + p]);
+            code = __builtin_amdgcn_readfirstlane(ecode[ebeg[r] + p]);
           }
-          for (int p = beg; p < end; ++p) {
-            const int key = ekey[p], code = ecode[p];
-            const float t = __shfl(term, code, 64);
-            const int owner = (key & 255) >> 2, slot = ((key >> 8) << 2) | (key & 3);
+          const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), code));
+          const int owner = (key & 255) >> 2, slot = ((key >> 8) << 2) | (key & 3);
+          const float tl = lane == owner ? t : 0.f;
 #pragma unroll
-            for (int x = 0; x < NS; ++x) s[r][x] += (lane == owner && slot == x) ? t : 0.f;
-          }
+          for (int x = 0; x < NS; ++x)
+            if (slot == x) s[r][x] += tl;
         }
       }
       float m = NEG_INF_F;
@@ -341,12 +365,13 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __res
       float sum = 0.f;
 #pragma unroll
       for (int x = 0; x < NS; ++x) {
-        const int key = 256 * (x >> 2) + 4 * lane + (x & 3);
-        s[r][x] = key < n ? expf(s[r][x] - m) : 0.f;
+        // e^(s - m) as one v_exp_f32: 2^((s - m) log2 e) -- within 2e-6 relative of expf for the terms that matter (|s - m| < 30),
+        // masked keys are -inf -> 0; an all-masked row (n == 0) has m = -inf -> NaN, like torch.softmax of an all -inf row
+        s[r][x] = __builtin_amdgcn_exp2f((s[r][x] - m) * 1.44269504088896340736f);
         sum += s[r][x];
       }
       sum = bl_wave_sum(sum);
-      const float inv = 1.0f / sum;  // n == 0 gives 0/0 like torch.softmax of an all -inf row
+      const float inv = 1.0f / sum;
       const size_t row = (size_t)g * L + i;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
@@ -392,6 +417,11 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x, b = g / H, h = g - b * H, HD = H * DK;
   const int ntab = 2 * T * DK;
+  const int rb = blockIdx.y * ATT_WG_ROWS, re = min(rb + ATT_WG_ROWS, L);
+  int rpv[ATT_ITERS];  // (as in the forward kernel)
+#pragma unroll
+  for (int it = 0; it < ATT_ITERS; ++it)
+    rpv[it] = (row_ptr && lane <= ATT_ROWS) ? row_ptr[b * L + min(rb + (16 * it + wave) * ATT_ROWS + lane, L)] : 0;
   {
     const float* __restrict__ vg = v + (size_t)g * L * DK;
     for (int x = tid; x < LP * DK; x += 1024) {
@@ -411,11 +441,29 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __res
 #pragma unroll
   for (int kk = 0; kk < ATT_TAB_REGS; ++kk) tabacc[kk] = 0.f;
   bool any_edges = false;
-  const int rb = blockIdx.y * ATT_WG_ROWS, re = min(rb + ATT_WG_ROWS, L);
-  for (int i0 = rb + wave * ATT_ROWS; i0 < re; i0 += 16 * ATT_ROWS) {
+#pragma unroll
+  for (int it = 0; it < ATT_ITERS; ++it) {
+    const int i0 = rb + (16 * it + wave) * ATT_ROWS;
+    if (i0 >= re) break;
     float gv[ATT_ROWS];  // lane d < DK: dO[i0 + r][d]
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r) gv[r] = lane < DK ? g_ctx[((size_t)g * L + min(i0 + r, L - 1)) * DK + lane] : 0.f;
+    int ebeg[ATT_ROWS], ecnt[ATT_ROWS], ek[ATT_ROWS], ec[ATT_ROWS];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+      ebeg[r] = __builtin_amdgcn_readlane(rpv[it], r);
+      ecnt[r] = i0 + r < re ? __builtin_amdgcn_readlane(rpv[it], r + 1) - ebeg[r] : 0;
+      ek[r] = lane < ecnt[r] ? ekey[ebeg[r] + lane] : 0;
+      ec[r] = lane < ecnt[r] ? ecode[ebeg[r] + lane] : 0;
+    }
+    float pv[NS];  // P of the row in turn: requested one row ahead
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int key = 256 * c + 4 * lane;
+      float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (key < L) pr = *reinterpret_cast<const float4*>(P + ((size_t)g * L + i0) * L + key);
+      pv[4 * c] = pr.x; pv[4 * c + 1] = pr.y; pv[4 * c + 2] = pr.z; pv[4 * c + 3] = pr.w;
+    }
     float s[ATT_ROWS][NS];
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r)
@@ -443,15 +491,20 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __res
       const int i = i0 + r;
       if (i >= re) break;  // wave-uniform
       const size_t row = (size_t)g * L + i;
-      float pv[NS];
-      float dot = 0.f;
+      float pn[NS];  // the next row's P
 #pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const int key = 256 * c + 4 * lane;
-        float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (key < L) pr = *reinterpret_cast<const float4*>(P + row * L + key);
-        pv[4 * c] = pr.x; pv[4 * c + 1] = pr.y; pv[4 * c + 2] = pr.z; pv[4 * c + 3] = pr.w;
+      for (int x = 0; x < NS; ++x) pn[x] = 0.f;
+      if (r + 1 < ATT_ROWS && i + 1 < re) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const int key = 256 * c + 4 * lane;
+          if (key < L) {
+            const float4 pr = *reinterpret_cast<const float4*>(P + (row + 1) * L + key);
+            pn[4 * c] = pr.x; pn[4 * c + 1] = pr.y; pn[4 * c + 2] = pr.z; pn[4 * c + 3] = pr.w;
+          }
+        }
       }
+      float dot = 0.f;
 #pragma unroll
       for (int x = 0; x < NS; ++x) {
         if (has_drop) {
@@ -468,32 +521,42 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __res
         const int key = 256 * c + 4 * lane;
         if (key < L) *reinterpret_cast<float4*>(dS + row * L + key) = make_float4(s[r][4 * c], s[r][4 * c + 1], s[r][4 * c + 2], s[r][4 * c + 3]);
       }
-      if (row_ptr) {
-        const int beg = row_ptr[b * L + i], end = row_ptr[b * L + i + 1];
-        if (beg < end) {
-          any_edges = true;
-          float coef = 0.f;  // lane c < 2 T: sum of dS over this row's entries with code c
-          for (int p = beg; p < end; ++p) {
-            const int key = ekey[p], code = ecode[p];
-            const int owner = (key & 255) >> 2, slot = ((key >> 8) << 2) | (key & 3);
-            float pick = 0.f;
-#pragma unroll
-            for (int x = 0; x < NS; ++x) pick = slot == x ? s[r][x] : pick;
-            const float gval = __shfl(pick, owner, 64);
-            coef += lane == code ? gval : 0.f;
+      if (ecnt[r] > 0) {
+        any_edges = true;
+        const float qd = q[row * DK + (lane & (DK - 1))];
+        float coef = 0.f;  // lane c < 2 T: sum of dS over this row's entries with code c
+        for (int p = 0; p < ecnt[r]; ++p) {  // (wave-uniform entry: scalar registers and branches)
+          int key, code;
+          if (p < 64) {
+            key = __builtin_amdgcn_readlane(ek[r], p);
+            code = __builtin_amdgcn_readlane(ec[r], p);
+          } else {
+            key = __builtin_amdgcn_readfirstlane(ekey[ebeg[r] + p]);
+            code = __builtin_amdgcn_readfirstlane(ecode[ebeg[r] + p]);
           }
-          const float qd = q[row * DK + (lane & (DK - 1))];
-          float gq = 0.f;
-          for (int c = 0; c < 2 * T; ++c) gq = fmaf(__shfl(coef, c, 64), bl[c * (DK + 1) + (lane & (DK - 1))], gq);
-          if (lane < DK) gq_edge[row * DK + lane] = gq;
+          const int owner = (key & 255) >> 2, slot = ((key >> 8) << 2) | (key & 3);
+          float pick = 0.f;
 #pragma unroll
-          for (int kk = 0; kk < ATT_TAB_REGS; ++kk) {
+          for (int x = 0; x < NS; ++x)
+            if (slot == x) pick = s[r][x];
+          const float gval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick), owner));
+          coef += lane == code ? gval : 0.f;
+        }
+        float gq = 0.f;
+        for (int c = 0; c < 2 * T; ++c)
+          gq = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), c)), bl[c * (DK + 1) + (lane & (DK - 1))], gq);
+        if (lane < DK) gq_edge[row * DK + lane] = gq;
+#pragma unroll
+        for (int kk = 0; kk < ATT_TAB_REGS; ++kk) {
+          if (64 * kk < ntab) {  // (uniform)
             const int e = lane + 64 * kk;  // element (code, d) = (e / DK, e % DK) of the table
             const float cv = __shfl(coef, min(e / DK, 63), 64);  // (every lane takes part in the exchange)
             if (e < ntab) tabacc[kk] = fmaf(cv, qd, tabacc[kk]);  // (64 % DK == 0: e % DK == lane % DK)
           }
         }
       }
+#pragma unroll
+      for (int x = 0; x < NS; ++x) pv[x] = pn[x];
     }
   }
   if (row_ptr) {
