@@ -194,16 +194,21 @@ __device__ __forceinline__ void segmax_scan(const float* __restrict__ x, int ldx
 }
 
 // GELU form: decide between the two extremes; raw = the winner's message before the activation
+// (werf: erf(raw / sqrt 2) of the winner -- the derivative at the winner needs it again: bl_gelu_grad without its erff)
 template <int NV, bool GELU2>
-__device__ __forceinline__ void segmax_pick(float (&best)[NV], int (&barg)[NV], const float (&low)[NV], const int (&larg)[NV], float (&raw)[NV]) {
+__device__ __forceinline__ void segmax_pick(float (&best)[NV], int (&barg)[NV], const float (&low)[NV], const int (&larg)[NV], float (&raw)[NV],
+                                            float (&werf)[NV]) {
   if (GELU2) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       raw[j] = best[j];
+      werf[j] = 0.f;
       if (barg[j] < 0) continue;  // empty segment / padding lane
-      const float gh = bl_gelu(best[j]), gl = bl_gelu(low[j]);  // a NaN message sits in best[j] and stays NaN
+      const float eh = erff(best[j] * 0.70710678118654752440f), el = erff(low[j] * 0.70710678118654752440f);
+      const float gh = 0.5f * best[j] * (1.0f + eh), gl = 0.5f * low[j] * (1.0f + el);  // = bl_gelu; a NaN message sits in best[j] and stays NaN
       best[j] = gh;
-      if (gl > gh || gl != gl) { best[j] = gl; barg[j] = larg[j]; raw[j] = low[j]; }
+      werf[j] = eh;
+      if (gl > gh || gl != gl) { best[j] = gl; barg[j] = larg[j]; raw[j] = low[j]; werf[j] = el; }
     }
   }
 }
@@ -235,7 +240,7 @@ __device__ __forceinline__ void segmax_winbits(const int* __restrict__ seg_items
 // outputs of one segment from its winners (one wave): aggregate, arg table, activation derivative, LayerNorm (+ packed copy)
 template <int NV, bool HAS_LN, bool GELU2>
 __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int ldx, int seg, int D, int act, float (&best)[NV],
-                                              const int (&barg)[NV], const float (&raw)[NV], float* __restrict__ out,
+                                              const int (&barg)[NV], const float (&raw)[NV], const float (&werf)[NV], float* __restrict__ out,
                                               int* __restrict__ arg, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                               float eps, float* __restrict__ ln_out, float* __restrict__ mean_out,
                                               float* __restrict__ rstd_out, float* __restrict__ dact,
@@ -254,7 +259,12 @@ __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int l
         float dv = 1.f;
         // (the winner's raw message is in a register: re-reading it would be 64 scattered 4-byte loads per wave,
         // several times the address-coalescing work of the whole message sweep above)
-        if (act == BL_ACT_GELU) dv = barg[j] >= 0 ? bl_gelu_grad(GELU2 ? raw[j] : x[(size_t)barg[j] * ldx + d]) : 0.f;
+        if (act == BL_ACT_GELU) {
+          if (GELU2)  // bl_gelu_grad(raw) with the erf that segmax_pick already evaluated
+            dv = barg[j] >= 0 ? 0.5f * (1.0f + werf[j]) + raw[j] * (0.39894228040143267794f * expf(-0.5f * raw[j] * raw[j])) : 0.f;
+          else
+            dv = barg[j] >= 0 ? bl_gelu_grad(x[(size_t)barg[j] * ldx + d]) : 0.f;
+        }
         dact[(size_t)seg * D + d] = dv;
       }
     }
@@ -308,14 +318,14 @@ __global__ __launch_bounds__(256) void segment_max_kernel(SEGMAX_PARAMS) {
   const int seg = seg_order ? seg_order[slot] : slot;
   if (segmax_is_hub(seg_ptr, hub_slots, slot, seg)) return;  // segment_max_hub_kernel's
   const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
-  float best[NV], low[NV], raw[NV];
+  float best[NV], low[NV], raw[NV], werf[NV];
   int barg[NV], larg[NV];
 #pragma unroll
-  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; raw[j] = 0.f; }
+  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; raw[j] = 0.f; werf[j] = 0.f; }
   segmax_scan<NV, GELU2>(x, ldx, seg_items, beg, end, D, act, best, barg, low, larg);
-  segmax_pick<NV, GELU2>(best, barg, low, larg, raw);
+  segmax_pick<NV, GELU2>(best, barg, low, larg, raw, werf);
   if (winbits) segmax_winbits<NV>(seg_items, beg, end, D, barg, winbits);
-  segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
+  segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, werf, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
                                    ln_out_packed);
 }
 
@@ -336,10 +346,10 @@ __global__ __launch_bounds__(64 * SEGMAX_HUB_WAVES) void segment_max_hub_kernel(
     const int len = seg_ptr[seg + 1] - seg_ptr[seg];
     if (len <= len_lo || len > len_hi) return;
   }
-  float best[NV], low[NV], raw[NV];
+  float best[NV], low[NV], raw[NV], werf[NV];
   int barg[NV], larg[NV];
 #pragma unroll
-  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; raw[j] = 0.f; }
+  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; raw[j] = 0.f; werf[j] = 0.f; }
   const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
   const int share = (end - beg + SEGMAX_HUB_WAVES - 1) / SEGMAX_HUB_WAVES;
   const int wb = min(end, beg + wave * share), we = min(end, wb + share);
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(64 * SEGMAX_HUB_WAVES) void segment_max_hub_kernel(
         if (GELU2 && al >= 0 && tl < low[j]) { low[j] = tl; larg[j] = al; }
       }
     }
-    segmax_pick<NV, GELU2>(best, barg, low, larg, raw);
+    segmax_pick<NV, GELU2>(best, barg, low, larg, raw, werf);
 #pragma unroll
     for (int j = 0; j < NV; ++j) hub_i[0][0][lane + 64 * j] = barg[j];  // the final winners
   }
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(64 * SEGMAX_HUB_WAVES) void segment_max_hub_kernel(
     segmax_winbits<NV>(seg_items, wb, we, D, fin, winbits);
   }
   if (wave == 0)
-    segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
+    segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, werf, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
                                      ln_out_packed);
 }
 
