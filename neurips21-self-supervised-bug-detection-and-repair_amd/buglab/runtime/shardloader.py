@@ -221,6 +221,7 @@ class WorkerPool:
         self._procs = None
         self._q = self._stop = None
         self._closed = False
+        self._finished = False  # every worker delivered its end marker (nothing can be left in the queue)
 
     def start(self) -> "WorkerPool":
         if self._procs is not None or self.num_workers == 0 or self._closed:
@@ -270,6 +271,7 @@ class WorkerPool:
                     continue
                 if isinstance(item, str) and item == _DONE:
                     done += 1
+                    self._finished = done == self.num_workers
                     continue
                 if isinstance(item, _WorkerError):
                     raise RuntimeError(item.text)
@@ -294,6 +296,24 @@ class WorkerPool:
 
         procs, out_q = self._procs, self._q
         self._stop.set()
+        if self._finished:
+            # The normal end of an epoch: the queue is empty and every worker is on its way out.  Reaping 32 exiting
+            # processes took 0.1-0.25 s of every epoch on the trainer's thread (seconds on a loaded host): a daemon thread
+            # does it instead (stragglers are killed there; daemonic children die with the interpreter in any case).
+            import threading
+
+            def reap():
+                for p in procs:
+                    p.join(timeout=5.0)
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                        p.join(timeout=2.0)
+                out_q.close()
+                out_q.cancel_join_thread()
+
+            threading.Thread(target=reap, name="buglab-loader-reaper", daemon=True).start()
+            return
         deadline = _time.monotonic() + 5.0
         while any(p.is_alive() for p in procs) and _time.monotonic() < deadline:
             try:

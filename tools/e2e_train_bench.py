@@ -131,6 +131,9 @@ def main():
         print(f"         allocator: {ms['num_device_alloc']} device allocations, {ms['num_device_free']} frees, {ms['num_alloc_retries']} retries so far; "
               f"reserved {ms['reserved_bytes.all.current'] / 2**30:.1f} GiB, peak allocated {ms['allocated_bytes.all.peak'] / 2**30:.1f} GiB")
         if len(marks) > 20:
+            t_end = t0 + dt
+            print(f"         epoch start -> first step {1e3 * (marks[0][0] - t0):.0f} ms; first 10 steps {1e3 * (marks[10][0] - marks[0][0]):.0f} ms; "
+                  f"last step's zero_grad -> epoch end {1e3 * (t_end - marks[-1][0]):.0f} ms")
             host = np.diff([m[0] for m in marks[10:]]) * 1e3
             devt = np.array([marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(10, len(marks) - 1)])
             lag = [(marks[i][1].elapsed_time(marks[-1][1])) for i in (10,)]
