@@ -142,6 +142,9 @@ def test_fused_attention_kernels_equal_the_gemm_and_rowwise_path(B, L, H, dk, T,
     e = np.stack([rng.integers(0, B, ne), rng.integers(0, L, ne), rng.integers(0, L, ne)], 1)
     e = e[(e[:, 1] < lens_np[e[:, 0]]) & (e[:, 2] < lens_np[e[:, 0]]) & (e[:, 1] != 3)]  # (position 3 has no outgoing entries)
     e = np.concatenate([e, e[:5]])  # repeated edges accumulate
+    # a hub: position 7 of sample 0 takes part in 90 more edges (more than the 64 entries a wave fetches ahead per row)
+    hub = np.stack([np.zeros(90, np.int64), np.full(90, 7), rng.integers(0, int(lens_np[0]), 90)], 1)
+    e = np.concatenate([e, hub, hub[:, [0, 2, 1]][:40]])
     kinds = rng.integers(0, T, e.shape[0])
     rp, key, code = edge_csr(e, kinds, B, L)
     edges = ops.RelEdges(torch.from_numpy(rp).cuda(), torch.from_numpy(key).cuda(), torch.from_numpy(code).cuda(), int(key.shape[0]))
