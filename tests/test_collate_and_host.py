@@ -463,6 +463,14 @@ def test_trainer_epoch_loop_with_loader_processes_on_cpu(tmp_path, monkeypatch):
     trainer.neural_module.graphs = 0
     trainer._run_training(ds, 1, torch.device("cpu"), FakeOpt(), None, True)
     assert trainer.neural_module.graphs == 30 and trainer._prestarted is None and pool._closed
+    # a pool that ran to its end is reaped by a background thread, not on the trainer's thread: the workers are gone shortly after
+    assert pool._finished
+    import time as _time
+
+    deadline = _time.monotonic() + 10.0
+    while any(p.is_alive() for p in pool._procs) and _time.monotonic() < deadline:
+        _time.sleep(0.05)
+    assert not any(p.is_alive() for p in pool._procs)
     trainer._prestart_loaders(ds, 2, True)
     pool = trainer._prestarted[2]
     trainer._drop_prestarted_pool()
