@@ -41,6 +41,7 @@ class TensorizedGraphData:
     token_lens: np.ndarray  # int32 [n]
     adjacency_lists: List[np.ndarray]  # per presented edge type: int32 [E_t, 2] (src, tgt)
     reference_nodes: Dict[str, np.ndarray] = field(default_factory=dict)
+    edge_feature_ids: Optional[List[np.ndarray]] = None  # per presented edge type: int32 [E_t] feature-token ids (edge features on)
 
     @property
     def num_nodes(self) -> int:
@@ -149,7 +150,8 @@ def _collate_graph_arrays_numpy(graphs, num_edge_types: int, node_off: np.ndarra
     # all messages of the batch at once: per graph one concatenation (edge lists in type order), then two stable
     # counting sorts -- by target, then by type -- give "type-major, target-sorted inside a type" with ties in
     # (graph, list) order, exactly what sorting each type's concatenated list by target gives
-    srcs, tgts, typs = [], [], []
+    srcs, tgts, typs, feats = [], [], [], []
+    with_feat = any(g.edge_feature_ids is not None for g in graphs)  # edge features: a feature-token id travels with every message
     for g, o in zip(graphs, node_off[:-1]):
         lists = [a for a in g.adjacency_lists[:num_edge_types]]
         counts = [a.shape[0] for a in lists]
@@ -159,15 +161,24 @@ def _collate_graph_arrays_numpy(graphs, num_edge_types: int, node_off: np.ndarra
         srcs.append(adj[:, 0] + I32(o))
         tgts.append(adj[:, 1] + I32(o))
         typs.append(np.repeat(np.arange(len(lists), dtype=I32), counts))
+        if with_feat:
+            assert g.edge_feature_ids is not None and [f.shape[0] for f in g.edge_feature_ids[:num_edge_types]] == counts, \
+                "every graph of the minibatch needs one feature id per edge"
+            feats.append(np.concatenate(g.edge_feature_ids[:num_edge_types]).astype(I32, copy=False))
+    msg_feat = None
     if srcs:
         all_src, all_tgt, all_typ = np.concatenate(srcs), np.concatenate(tgts), np.concatenate(typs)
         _, by_tgt = _csr(all_tgt, N)
         type_ptr, by_typ = _csr(all_typ[by_tgt], num_edge_types)
         order = by_tgt[by_typ]
         msg_src, msg_tgt = np.ascontiguousarray(all_src[order], dtype=I32), np.ascontiguousarray(all_tgt[order], dtype=I32)
+        if with_feat:
+            msg_feat = np.ascontiguousarray(np.concatenate(feats)[order], dtype=I32)
     else:
         msg_src = msg_tgt = np.zeros(0, dtype=I32)
         type_ptr = np.zeros(num_edge_types + 1, dtype=I32)
+        if with_feat:
+            msg_feat = np.zeros(0, dtype=I32)
     tgt_ptr, tgt_msgs = _csr(msg_tgt, N)
     src_ptr, src_msgs = _csr(msg_src, N)
     # per-node kernels (one wave per node) take hubs first: a node with hundreds of messages keeps its wave busy
@@ -182,9 +193,12 @@ def _collate_graph_arrays_numpy(graphs, num_edge_types: int, node_off: np.ndarra
     else:
         node_order = np.arange(N, dtype=I32)
 
-    return {"token_ids": token_ids, "token_lens": token_lens, "msg_src": msg_src, "msg_tgt": msg_tgt, "type_ptr": np.asarray(type_ptr, dtype=I32),
-            "tgt_ptr": tgt_ptr, "tgt_msgs": tgt_msgs, "src_ptr": src_ptr, "src_msgs": src_msgs, "node_order": node_order,
-            "tok_occ": tok_occ, "tok_chunk_ptr": tok_chunk_ptr, "tok_chunk_id": tok_chunk_id}
+    out = {"token_ids": token_ids, "token_lens": token_lens, "msg_src": msg_src, "msg_tgt": msg_tgt, "type_ptr": np.asarray(type_ptr, dtype=I32),
+           "tgt_ptr": tgt_ptr, "tgt_msgs": tgt_msgs, "src_ptr": src_ptr, "src_msgs": src_msgs, "node_order": node_order,
+           "tok_occ": tok_occ, "tok_chunk_ptr": tok_chunk_ptr, "tok_chunk_id": tok_chunk_id}
+    if msg_feat is not None:
+        out["msg_feat"] = msg_feat
+    return out
 
 
 def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -> Dict[str, Any]:
@@ -197,7 +211,8 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
 
     from buglab.data import native
 
-    if native.available() and os.environ.get("BUGLAB_NATIVE_COLLATE", "1") != "0":
+    with_feat = any(g.edge_feature_ids is not None for g in graphs)  # (the native collator does not carry per-edge payloads)
+    if native.available() and os.environ.get("BUGLAB_NATIVE_COLLATE", "1") != "0" and not with_feat:
         arr = native.collate_graph_arrays(graphs, num_edge_types, HUB_DEGREE, _token_chunk())  # one GIL-free native call
     else:
         arr = _collate_graph_arrays_numpy(graphs, num_edge_types, node_off, N)
@@ -247,6 +262,7 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
     # (localizationmodule.py:66-77: ids = cat(candidate_to_sample_idx, arange(B)))
     loc_ptr, loc_items = _csr(np.concatenate([cand_graph.astype(np.int64), np.arange(B, dtype=np.int64)]), B)
     return {
+        **({"msg_feat": arr["msg_feat"]} if "msg_feat" in arr else {}),
         "loc_group_ptr": loc_ptr,
         "loc_group_items": loc_items,
         "token_ids": token_ids,
@@ -372,8 +388,8 @@ _INT_KEYS_GD = ("loc_group_ptr", "loc_group_items", "token_ids", "token_lens", "
                 "head_gather_idx", "head_local_idx", "node_order", "msg_src", "msg_tgt", "type_ptr", "tgt_ptr", "tgt_msgs", "src_ptr", "src_msgs", "node_to_graph", "candidate_ptr")
 
 
-# present only in minibatches of the sequence models (buglab.models.seqmodel.collate_sequences)
-_INT_KEYS_GD_SEQ = ("seq_lens", "erow_ptr", "ekey", "ecode")
+# present only in minibatches of the sequence models (buglab.models.seqmodel.collate_sequences) / with edge features on
+_INT_KEYS_GD_SEQ = ("seq_lens", "erow_ptr", "ekey", "ecode", "msg_feat")
 
 
 def pack_minibatch(mb: Dict[str, Any], out: Optional[np.ndarray] = None):

@@ -304,23 +304,26 @@ def const_weight_schedule(_epoch_idx: int, weight: float = 1.0) -> float:
 def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_edge_types: int = 16,
                          vocabulary_size: int = 15000, max_num_subtokens: int = 6, rewrite_vocabulary_size: int = 48,
                          dropout_rate: float = 0.2, message_activation: str = "gelu",
-                         buggy_samples_weight: float = 1.0, dropout_base_seed: int = 0, model: str = "gnn-mlp") -> GnnBugLabModule:
+                         buggy_samples_weight: float = 1.0, dropout_base_seed: int = 0, model: str = "gnn-mlp",
+                         edge_feature_size: int = 0, edge_vocabulary_size: int = 0) -> GnnBugLabModule:
     """Device module for given hyper-parameters without a metadata pass (bench / tests / synthetic
     runs).  `GnnBugLabModel.build_neural_module()` goes through the same constructors."""
     from functools import partial
 
     from buglab.models.gnnlayerdefs import create_mlp_mp_layers
-    from buglab.models.layers.messagepassing import SubtokenEmbedder
+    from buglab.models.layers.messagepassing import SubtokenEmbedder, TokenEmbedder
 
     embed = SubtokenEmbedder(vocabulary_size, hidden_state_size, max_num_subtokens, dropout_rate)
+    edge_embed = TokenEmbedder(edge_vocabulary_size, edge_feature_size) if edge_feature_size > 0 else None
     if model == "ggnn":
+        assert edge_embed is None
         from buglab.models.gnnlayerdefs import create_ggnn_mp_layers
 
         recipe = create_ggnn_mp_layers(hidden_state_size, dropout_rate, num_edge_types)
     else:
-        recipe = create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edge_types, num_layers=num_layers,
-                                      message_activation=message_activation)
-    return GnnBugLabModule(GraphNeuralNetwork(embed, recipe), rewrite_vocabulary_size,
+        recipe = create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edge_types, features_dimension=edge_feature_size,
+                                      num_layers=num_layers, message_activation=message_activation)
+    return GnnBugLabModule(GraphNeuralNetwork(embed, recipe, edge_embedder=edge_embed), rewrite_vocabulary_size,
                            buggy_samples_weight_schedule=partial(const_weight_schedule, weight=buggy_samples_weight),
                            dropout_base_seed=dropout_base_seed)
 

@@ -24,8 +24,9 @@ class StrElementRepresentationModel:
     def __init__(self, *, token_splitting: str = "subtoken", embedding_size: int = 128, vocabulary_size: int = 15000,
                  max_num_subtokens: int = 6, subtoken_combination: str = "max", dropout_rate: float = 0.0,
                  min_freq_threshold: int = 5):
-        if token_splitting != "subtoken" or subtoken_combination != "max":
-            raise NotImplementedError("the HIP embedder implements the reference's gnn-mlp default: subtoken / max (modelregistry.py:61-67)")
+        if token_splitting not in ("subtoken", "token") or (token_splitting == "subtoken" and subtoken_combination != "max"):
+            raise NotImplementedError("the HIP embedders implement subtoken / max (the node model, modelregistry.py:61-67) and "
+                                      "token (the edge-feature model, modelregistry.py:70-74)")
         self.token_splitting, self.subtoken_combination = token_splitting, subtoken_combination
         self.embedding_size, self.vocabulary_size = embedding_size, vocabulary_size
         self.max_num_subtokens, self.dropout_rate = max_num_subtokens, dropout_rate
@@ -36,7 +37,10 @@ class StrElementRepresentationModel:
         self._native_vocab = None  # buglab.data.native.NativeVocabulary, built on first use
 
     def update_metadata_from(self, node_str: str) -> None:
-        self._counter.update(split_identifier_into_parts(node_str))
+        if self.token_splitting == "token":
+            self._counter[node_str] += 1  # whole strings: the edges' feature tokens (modelregistry.py:70-74)
+        else:
+            self._counter.update(split_identifier_into_parts(node_str))
 
     def finalize_metadata(self) -> None:
         self.vocabulary = Vocabulary.create_vocabulary(self._counter, max_size=self.vocabulary_size,
@@ -44,9 +48,17 @@ class StrElementRepresentationModel:
         self._counter = None
 
     def build_neural_module(self):
-        from buglab.models.layers.messagepassing import SubtokenEmbedder
+        from buglab.models.layers.messagepassing import SubtokenEmbedder, TokenEmbedder
 
+        if self.token_splitting == "token":
+            return TokenEmbedder(len(self.vocabulary), self.embedding_size)
         return SubtokenEmbedder(len(self.vocabulary), self.embedding_size, self.max_num_subtokens, self.dropout_rate)
+
+    def tensorize_tokens(self, strs) -> np.ndarray:
+        """token mode: one vocabulary id per string (the pad token is a vocabulary entry; unseen strings -> unk)."""
+        assert self.token_splitting == "token"
+        get = self.vocabulary.get_id_or_unk
+        return np.fromiter((get(s) for s in strs), dtype=np.int32, count=len(strs))
 
     def tensorize_nodes(self, node_strs: List[str]):
         S = self.max_num_subtokens
@@ -87,8 +99,10 @@ class GraphNeuralNetworkModel:
                  add_self_edges: bool = False, add_backwards_edges: bool = True,
                  message_passing_layer_creator: Callable[[int], List[Any]] = None,
                  stop_extending_minibatch_after_num_nodes: int = 30000, max_nodes_per_graph: int = 35000):
-        if edge_representation_model is not None:
-            raise NotImplementedError("edge features (edge_feature_size > 0) are off in every reference configuration")
+        # edge features (modelregistry.py:70-86): a token-level vocabulary over the edges' third elements; every message carries
+        # the id of its edge's token -- reversed edges their forward edge's, self loops the pad token's (frozen here: ptgnn's
+        # source is unavailable)
+        self.edge_representation_model = edge_representation_model
         self.node_representation_model = node_representation_model
         self.add_self_edges, self.add_backwards_edges = add_self_edges, add_backwards_edges
         self.message_passing_layer_creator = message_passing_layer_creator
@@ -102,9 +116,15 @@ class GraphNeuralNetworkModel:
         for node in graph.node_information:
             self.node_representation_model.update_metadata_from(node)
         self._edge_types_seen.update(graph.edges.keys())
+        if self.edge_representation_model is not None and graph.edge_features is not None:
+            for feats in graph.edge_features.values():
+                for f in feats:
+                    self.edge_representation_model.update_metadata_from(f)
 
     def finalize_metadata(self) -> None:
         self.node_representation_model.finalize_metadata()
+        if self.edge_representation_model is not None:
+            self.edge_representation_model.finalize_metadata()
         self.edge_types = sorted(self._edge_types_seen)
         self._edge_types_seen = None
 
@@ -116,8 +136,9 @@ class GraphNeuralNetworkModel:
     def build_neural_module(self):
         from buglab.models.layers.messagepassing import GraphNeuralNetwork
 
+        edge_embedder = self.edge_representation_model.build_neural_module() if self.edge_representation_model is not None else None
         return GraphNeuralNetwork(self.node_representation_model.build_neural_module(),
-                                  self.message_passing_layer_creator(self.num_presented_edge_types))
+                                  self.message_passing_layer_creator(self.num_presented_edge_types), edge_embedder=edge_embedder)
 
     def tensorize(self, graph: GraphData) -> Optional[TensorizedGraphData]:
         n = len(graph.node_information)
@@ -133,4 +154,18 @@ class GraphNeuralNetworkModel:
             ar = np.arange(n, dtype=np.int32)
             adj.append(np.stack([ar, ar], axis=1))
         refs = {k: np.asarray(v, dtype=np.int32) for k, v in graph.reference_nodes.items()}
-        return TensorizedGraphData(ids, lens, adj, refs)
+        feat_ids = None
+        if self.edge_representation_model is not None:
+            em = self.edge_representation_model
+            pad = Vocabulary.get_pad()
+            feats = graph.edge_features or {}
+            f_fwd = []
+            for t, a in zip(self.edge_types, fwd):
+                f = feats.get(t)
+                f_fwd.append(em.tensorize_tokens(list(f)) if f is not None and len(f) == a.shape[0] else em.tensorize_tokens([pad] * a.shape[0]))
+            feat_ids = list(f_fwd)
+            if self.add_backwards_edges:
+                feat_ids += [f.copy() for f in f_fwd]
+            if self.add_self_edges:
+                feat_ids.append(em.tensorize_tokens([pad] * n))
+        return TensorizedGraphData(ids, lens, adj, refs, feat_ids)

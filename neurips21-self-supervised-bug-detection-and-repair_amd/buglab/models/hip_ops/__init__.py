@@ -1175,6 +1175,66 @@ def gated_mp_layer(h, W, Wi, bi, Wh, bh, graph: GraphIndex, drop: Dropout = NO_D
     return _GatedMpLayer.apply(h.contiguous(), W, Wi, bi, Wh, bh, graph, drop)
 
 
+class _MpLayerFeat(torch.autograd.Function):
+    """MlpMessagePassingLayer with edge features (`features_dimension` F > 0, reference gnnlayerdefs.py:13,22): the message
+    input is [h_src ; h_tgt ; f_e] with f_e = edge_table[msg_feat[e]] read as a THIRD gathered source of the message GEMM --
+    the [E, F] feature matrix is never materialised.  Non-default configuration: exact-fp32 GEMM kernels, kernel by kernel."""
+
+    @staticmethod
+    def forward(ctx, h, W, ln_g, ln_b, Wd, bd, table, msg_feat, g: GraphIndex, msg_act: int, drop: Dropout):
+        _f32(h, "node states")
+        N, Din = h.shape
+        T, K3, Dm = W.shape
+        F = table.shape[1]
+        Dout = Wd.shape[1]
+        E = g.num_messages
+        assert K3 == 2 * Din + F and T == g.num_types and N == g.num_nodes and msg_feat.shape[0] == E
+        src3 = [(h, g.msg_src), (h, g.msg_tgt), (_f32(table, "edge table"), msg_feat)]
+        pre = gemm_rows(src3, _f32(W, "W"), E, Dm, b_group_stride=K3 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
+        agg, arg, ln_out, mean, rstd, dact = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)),
+                                                         want_dact=True, seg_order=g.node_order)[:6]
+        if WINNER_SINK is not None:
+            WINNER_SINK.append(arg.clone())
+        del pre
+        if msg_act == ACT_NONE:
+            dact = None
+        out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
+        ctx.saved = (h, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, out, g, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        h, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, out, g, drop = ctx.saved
+        ctx.saved = None
+        N, Din = h.shape
+        T, K3, Dm = W.shape
+        F, Dout, E, dev = table.shape[1], Wd.shape[1], g.num_messages, h.device
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        g_bd, g_Wd, g_W, g_lng, g_lnb, g_table = z(Dout), torch.zeros_like(Wd), torch.zeros_like(W), z(Dm), z(Dm), torch.zeros_like(table)
+        g_z = act_bwd(g_out.contiguous(), out, ACT_TANH, drop, g_bd)
+        gemm_wgrad([(ln_out, None)], g_z, N, Dout, g_Wd)
+        g_ln = gemm_rows([(g_z, None)], Wd, N, Dm, b_is_nk=True, ldb=Dout)
+        gq = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact)  # d loss / d (winning pre-activation) per node
+        src3 = [(h, g.msg_src), (h, g.msg_tgt), (table, msg_feat)]
+        gemm_wgrad_routed(src3, gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K3 * Dm, group_ptr=g.type_ptr, G=T)
+        g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K3, b_group_stride=K3 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)  # [E, 2 Din + F]
+        g_h = torch.empty((N, Din), dtype=torch.float32, device=dev)
+        _check(load_library().bl_mp_scatter_grad(g_a.data_ptr(), g_a.stride(0), g.src_ptr.data_ptr(), g.src_msgs.data_ptr(), g.tgt_ptr.data_ptr(),
+                                                 g.tgt_msgs.data_ptr(), N, Din, 0, g_h.data_ptr(), g_h.stride(0), _p(g.node_order), _stream()),
+               "bl_mp_scatter_grad")
+        if E > 0:
+            scatter_add_rows(g_a, 2 * Din, F, msg_feat, g_table)  # the feature columns go back to the table rows they came from
+        return g_h, g_W, g_lng, g_lnb, g_Wd, g_bd, g_table, None, None, None, None
+
+
+def mp_layer_with_edge_features(h, W, ln_g, ln_b, Wd, bd, table, msg_feat, graph: GraphIndex, msg_act: str = "gelu",
+                                drop: Dropout = NO_DROPOUT):
+    """mp_layer with [h_src ; h_tgt ; table[msg_feat]] as the message input (W: [T, 2 Din + F, Dm])."""
+    if isinstance(h, (tuple, list)):
+        h = torch.cat(list(h), dim=-1)
+    return _MpLayerFeat.apply(h.contiguous(), W, ln_g, ln_b, Wd, bd, table, msg_feat, graph, _ACTS[msg_act], drop)
+
+
 def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu", drop: Dropout = NO_DROPOUT):
     """h: the node states [N, Din], or a pair (stash, current) standing for their concatenation (ConcatResidual)."""
     pair = isinstance(h, (tuple, list))

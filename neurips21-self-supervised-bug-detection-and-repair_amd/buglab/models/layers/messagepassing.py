@@ -6,6 +6,8 @@ Arithmetic spec (frozen here because ptgnn's source is unavailable; DESIGN.md se
   message    m_e  = act_msg([h_src ; h_tgt] @ W[type(e)])     W: [T, 2*Din, Dm], no bias
   aggregate  a_v  = max over incoming messages (0 if none; ties -> lowest message id)
   update     h'_v = Dropout(tanh(LayerNorm(a_v) @ Wd + bd))
+  edge features (features_dimension F > 0): m_e = act_msg([h_src ; h_tgt ; f_e] @ W[type(e)]), W: [T, 2*Din + F, Dm],
+             f_e = edge-embedding row of the edge's feature token (reversed edge: its forward edge's; self loop: pad)
 Every FLOP runs in libbuglab_hip (buglab.models.hip_ops); this file only owns parameters.
 """
 from __future__ import annotations
@@ -53,6 +55,18 @@ class SubtokenEmbedder(nn.Module):
         return hip_ops.embed_subtoken_max(self.table, token_ids, token_lens, drop, tok_csr)
 
 
+class TokenEmbedder(nn.Module):
+    """StrElementRepresentationModel in "token" mode: the edge-feature embedding (modelregistry.py:70-74).  The table is read
+    as a gathered source of every layer's message GEMM: forward here is the identity on the table."""
+
+    def __init__(self, vocabulary_size: int, embedding_size: int):
+        super().__init__()
+        if embedding_size % 4 != 0:
+            raise ValueError("edge_feature_size must be a multiple of 4 (row alignment of the gathered GEMM operand)")
+        self.embedding_size = embedding_size
+        self.table = nn.Parameter(torch.randn(vocabulary_size, embedding_size))  # nn.Embedding init
+
+
 class MlpMessagePassingLayer(nn.Module):
     """kwargs as at the reference call site gnnlayerdefs.py:6-23."""
 
@@ -62,18 +76,24 @@ class MlpMessagePassingLayer(nn.Module):
         super().__init__()
         if message_aggregation_function != "max":
             raise NotImplementedError("the HIP path implements the reference's `max` aggregation (gnnlayerdefs.py:11,21)")
-        if features_dimension != 0:
-            raise NotImplementedError("edge features are off in every reference gnn-mlp configuration (modelregistry.py:57)")
         din, dm, dout, T = input_state_dimension, message_dimension, output_state_dimension, num_edge_types
         self.input_state_dimension, self.message_dimension, self.output_state_dimension = din, dm, dout
         self.num_edge_types, self.dropout_rate, self.message_activation = T, dropout_rate, message_activation
-        self.W = nn.Parameter(_uniform_(torch.empty(T, 2 * din, dm), 1.0 / math.sqrt(2 * din)))
+        self.features_dimension = F = int(features_dimension)  # edge features: the message input is [h_src ; h_tgt ; f_e]
+        self.W = nn.Parameter(_uniform_(torch.empty(T, 2 * din + F, dm), 1.0 / math.sqrt(2 * din + F)))
         self.ln_g = nn.Parameter(torch.ones(dm))
         self.ln_b = nn.Parameter(torch.zeros(dm))
         self.Wd = nn.Parameter(_uniform_(torch.empty(dm, dout), math.sqrt(6.0 / (dm + dout))))
         self.bd = nn.Parameter(_uniform_(torch.empty(dout), 1.0 / math.sqrt(dm)))
 
-    def forward(self, node_states, graph: GraphIndex, drop: Dropout):
+    def forward(self, node_states, graph: GraphIndex, drop: Dropout, edge_features=None):
+        """edge_features: (table [V, F], msg_feat int32 [E]) when the layer was built with features_dimension = F > 0."""
+        if self.features_dimension > 0:
+            if edge_features is None:
+                raise ValueError("this layer was built with features_dimension > 0: the minibatch must carry `msg_feat`")
+            table, msg_feat = edge_features
+            return hip_ops.mp_layer_with_edge_features(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, table, msg_feat,
+                                                       graph, self.message_activation, drop)
         return hip_ops.mp_layer(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, graph,
                                 self.message_activation, drop)
 
@@ -125,9 +145,10 @@ class GraphNeuralNetwork(nn.Module):
     """Embeds nodes then applies the layer recipe.  Called as `gnn(**graph_data, return_all_states=bool)`
     (reference gnn.py:117)."""
 
-    def __init__(self, node_embedder: SubtokenEmbedder, layer_recipe: List[Any]):
+    def __init__(self, node_embedder: SubtokenEmbedder, layer_recipe: List[Any], edge_embedder: Optional[TokenEmbedder] = None):
         super().__init__()
         self.embed = node_embedder
+        self.edge_embed = edge_embedder  # edge features (modelregistry.py:70-86) or None
         self._recipe = layer_recipe
         mp, seen = [], set()
         for l in layer_recipe:  # a layer object may appear several times (weight sharing, ggnn recipe)
@@ -145,7 +166,7 @@ class GraphNeuralNetwork(nn.Module):
     def forward(self, *, token_ids, token_lens, msg_src, msg_tgt, type_ptr, tgt_ptr, tgt_msgs, src_ptr, src_msgs,
                 node_to_graph, reference_node_ids, reference_node_graph_idx, num_graphs, num_nodes, num_messages,
                 return_all_states: bool = False, dropout_seed: Optional[int] = None, tok_occ=None, tok_chunk_ptr=None,
-                tok_chunk_id=None, node_order=None, num_hub_nodes: int = -1, **_unused) -> GnnOutput:
+                tok_chunk_id=None, node_order=None, num_hub_nodes: int = -1, msg_feat=None, **_unused) -> GnnOutput:
         graph = GraphIndex(msg_src, msg_tgt, type_ptr, tgt_ptr, tgt_msgs, src_ptr, src_msgs, int(num_nodes),
                            int(num_messages), int(type_ptr.shape[0]) - 1, node_order, int(num_hub_nodes))
         training = self.training and dropout_seed is not None
@@ -153,6 +174,11 @@ class GraphNeuralNetwork(nn.Module):
         mk = lambda rate, stream: Dropout(rate if training else 0.0, seed, stream)
         tok_csr = (tok_occ, tok_chunk_ptr, tok_chunk_id) if tok_occ is not None else None
         h0 = self.embed(token_ids, token_lens, mk(self.embed.dropout_rate, 0), tok_csr)
+        edge_features = None
+        if self.edge_embed is not None:
+            if msg_feat is None:
+                raise ValueError("the model has an edge-feature embedding but the minibatch carries no `msg_feat`")
+            edge_features = (self.edge_embed.table, msg_feat)
         h = h0
         all_states = [h0]
         stash: Dict[int, torch.Tensor] = {}
@@ -167,7 +193,10 @@ class GraphNeuralNetwork(nn.Module):
             else:
                 if isinstance(h, tuple) and not isinstance(layer, MlpMessagePassingLayer):
                     h = torch.cat(h, dim=-1)
-                h = layer(h, graph, mk(layer.dropout_rate, 1 + li))
+                if isinstance(layer, MlpMessagePassingLayer) and layer.features_dimension > 0:
+                    h = layer(h, graph, mk(layer.dropout_rate, 1 + li), edge_features)
+                else:
+                    h = layer(h, graph, mk(layer.dropout_rate, 1 + li))
                 li += 1
                 all_states.append(h)
         if isinstance(h, tuple):

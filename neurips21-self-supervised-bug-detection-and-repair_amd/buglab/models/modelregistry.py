@@ -56,8 +56,11 @@ def gnn(*, mp_layer, add_self_edge: bool, use_all_gnn_layer_outputs: bool = Fals
     node_representations.setdefault("max_num_subtokens", 6)
     node_representations.setdefault("subtoken_combination", "max")
     node_representations.setdefault("vocabulary_size", 15000)
-    if edge_feature_size > 0:
-        raise NotImplementedError("edge_feature_size > 0 is not used by any reference configuration of this path")
+    edge_representation_model = None
+    if edge_feature_size > 0:  # reference :70-76: a token-level embedding of the edges' third elements
+        if mp_layer is not create_mlp_mp_layers:
+            raise NotImplementedError("edge features are implemented for the gnn-mlp layers (MlpMessagePassingLayer)")
+        edge_representation_model = StrElementRepresentationModel(token_splitting="token", embedding_size=edge_feature_size)
     extra = {}
     if num_layers is not None:
         extra["num_layers"] = num_layers
@@ -67,7 +70,7 @@ def gnn(*, mp_layer, add_self_edge: bool, use_all_gnn_layer_outputs: bool = Fals
         GraphNeuralNetworkModel(
             node_representation_model=StrElementRepresentationModel(embedding_size=hidden_state_size, dropout_rate=dropout_rate,
                                                                     **node_representations),
-            edge_representation_model=None,
+            edge_representation_model=edge_representation_model,
             add_self_edges=add_self_edge,
             add_backwards_edges=add_backwards_edges,
             message_passing_layer_creator=partial(_mp_layers, mp_layer, hidden_state_size, dropout_rate, edge_feature_size, extra),

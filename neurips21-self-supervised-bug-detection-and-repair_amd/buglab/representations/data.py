@@ -4,6 +4,8 @@ buglab/representations/data.py:14-20 (BugLabGraph), :97-121 (HasSubtoken open-vo
 import re
 from typing import Any, Dict, List, NamedTuple, Optional, Tuple, Union
 
+from collections.abc import Mapping
+
 import numpy as np
 from typing_extensions import TypedDict
 
@@ -66,6 +68,29 @@ def _as_np_array(arr):
     return np.array(arr, dtype=np.int32)
 
 
+class _NativeEdgeFeatures(Mapping):
+    """`GraphData.edge_features` of a natively read graph: edge kind -> the edges' third elements (pad where an edge has
+    none), built on demand -- only a model with `edge_feature_size > 0` ever looks (reference data.py:158-161)."""
+
+    def __init__(self, edges):
+        self._edges = edges
+
+    def __getitem__(self, kind):
+        arr = self._edges.arrays[kind]
+        f = self._edges._feats.get(kind)
+        pad = Vocabulary.get_pad()
+        if f is None:
+            return [pad] * int(arr.shape[0])
+        strings = self._edges._feat_strings
+        return [strings[int(i)] if i >= 0 else pad for i in f.tolist()]
+
+    def __iter__(self):
+        return iter(self._edges.arrays)
+
+    def __len__(self):
+        return len(self._edges.arrays)
+
+
 class BugLabData(TypedDict):
     graph: BugLabGraph
     candidate_rewrites: List[Tuple[str, Any]]
@@ -88,7 +113,7 @@ class BugLabData(TypedDict):
             target_node_idx = None
             if data["target_fix_action_idx"] is not None:
                 target_node_idx = int(inv[data["target_fix_action_idx"]])
-            return (GraphData(node_information=g.nodes, edges=dict(g.edges.arrays),
+            return (GraphData(node_information=g.nodes, edges=dict(g.edges.arrays), edge_features=_NativeEdgeFeatures(g.edges),
                               reference_nodes={"candidate_nodes": candidate_node_idxs.astype(np.int32)}), target_node_idx)
         candidate_node_idxs, inv = np.unique(data["graph"]["reference_nodes"], return_inverse=True)
         if data["target_fix_action_idx"] is not None:

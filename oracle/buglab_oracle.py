@@ -87,6 +87,9 @@ class MpSpec:
     dm: int
     dout: int
     msg_act: str = "gelu"  # "gelu" (exact erf form) or "none"
+    # edge features (`features_dimension` = F > 0, gnnlayerdefs.py:13,22): the message input is [h_src ; h_tgt ; f_e],
+    # W: [T, 2*Din + F, Dm]; f_e = row of the edge-embedding table picked by the edge's feature token (modelregistry.py:70-74)
+    features_dimension: int = 0
 
 
 def gnn_mlp_stack(hidden: int, num_layers: int = 8) -> List[Tuple]:
@@ -124,6 +127,8 @@ class OracleConfig:
     buggy_samples_weight: float = 1.0
     abstain_weight: float = 0.0  # LocalizationModule(abstain_weight=...), localizationmodule.py:15,95-100
     use_all_gnn_layer_outputs: bool = False  # gnn.py:68-74,118-121
+    edge_feature_size: int = 0  # modelregistry.py:56,70-76,86: width of the per-edge feature embedding fed to every MP layer
+    edge_vocab_size: int = 0    # rows of that embedding table (whole-token vocabulary of the edges' third elements)
 
 
 # ----------------------------------------------------------------------------
@@ -138,6 +143,9 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32) -> Dict[s
 
     p: Dict[str, torch.Tensor] = {}
     p["embed.table"] = torch.randn((cfg.vocab_size, H), generator=g, dtype=torch.float64).to(dtype)
+    F = cfg.edge_feature_size
+    if F > 0:
+        assert cfg.model != "ggnn" and cfg.edge_vocab_size > 0
     if cfg.model == "ggnn":
         for li, (D, Dm) in enumerate(((H, H), (2 * H, H))):
             k = 1.0 / math.sqrt(D)
@@ -152,12 +160,14 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32) -> Dict[s
             continue
         _, li, din, dm, dout = op
         # each W[t] initialised like nn.Linear(2*din, dm, bias=False): U(-1/sqrt(fan_in), +)
-        p[f"mp.{li}.W"] = uni((cfg.num_edge_types, 2 * din, dm), 1.0 / math.sqrt(2 * din))
+        p[f"mp.{li}.W"] = uni((cfg.num_edge_types, 2 * din + F, dm), 1.0 / math.sqrt(2 * din + F))
         p[f"mp.{li}.ln_g"] = torch.ones(dm, dtype=dtype)
         p[f"mp.{li}.ln_b"] = torch.zeros(dm, dtype=dtype)
         p[f"mp.{li}.Wd"] = uni((dm, dout), math.sqrt(6.0 / (dm + dout)))  # xavier uniform
         p[f"mp.{li}.bd"] = uni((dout,), 1.0 / math.sqrt(dm))
 
+    if F > 0:  # (drawn after the layer weights: configurations without edge features keep their parameter values)
+        p["edge_embed.table"] = torch.randn((cfg.edge_vocab_size, F), generator=g, dtype=torch.float64).to(dtype)  # nn.Embedding init
     if cfg.use_all_gnn_layer_outputs:  # nn.Linear(H + sum of layer output widths -> output width), gnn.py:68-74
         assert cfg.model != "ggnn"
         in_f = cfg.hidden * (1 + cfg.num_layers)
@@ -244,14 +254,17 @@ def _gelu(x):
 # ----------------------------------------------------------------------------
 # M1-M3  one MlpMessagePassingLayer (spec: MpSpec)
 # ----------------------------------------------------------------------------
-def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_drop, seed, stream, trace=None, force_arg=None):
+def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_drop, seed, stream, trace=None, force_arg=None,
+             feat=None):
+    """feat: [E, F] per-message edge-feature embeddings (message order), or None."""
     N = h.shape[0]
     src = torch.as_tensor(msg_src, dtype=torch.int64)
     tgt = torch.as_tensor(msg_tgt, dtype=torch.int64)
     msgs = []
     for t in range(W.shape[0]):
         lo, hi = int(type_ptr[t]), int(type_ptr[t + 1])
-        a = torch.cat([h[src[lo:hi]], h[tgt[lo:hi]]], dim=-1)  # [E_t, 2*Din]
+        parts = [h[src[lo:hi]], h[tgt[lo:hi]]] + ([feat[lo:hi]] if feat is not None else [])
+        a = torch.cat(parts, dim=-1)  # [E_t, 2*Din (+ F)]
         msgs.append(a @ W[t])
     pre = torch.cat(msgs, dim=0) if msgs else h.new_zeros((0, W.shape[2]))
     m = _gelu(pre) if msg_act == "gelu" else pre
@@ -301,6 +314,9 @@ def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None, force_arg=
     all_states = [h]
     stash = {}
     napplied = 0
+    feat = None
+    if cfg.edge_feature_size > 0:  # one embedding lookup per message, shared by all layers
+        feat = params["edge_embed.table"][torch.as_tensor(gd["msg_feat"], dtype=torch.int64)]
     for op in (gnn_mlp_stack(cfg.hidden, cfg.num_layers) if cfg.model != "ggnn" else ggnn_stack(cfg.hidden)):
         if op[0] == "stash":
             stash[op[1]] = h
@@ -329,6 +345,7 @@ def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None, force_arg=
                 stream=1 + li,
                 trace=trace,
                 force_arg=None if force_arg is None else force_arg[li],
+                feat=feat,
             )
         if op[0] in ("gg", "mp"):
             all_states.append(h)

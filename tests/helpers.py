@@ -5,6 +5,7 @@ import torch
 from oracle import buglab_oracle as O
 
 _PREFIX = {
+    "edge_embed.": "_gnn.edge_embed.",
     "embed.": "_gnn.embed.",
     "mp.": "_gnn.mp.",
     "loc.": "_localization_module.",
@@ -53,7 +54,8 @@ def build_module_like(cfg, params=None, device="cuda"):
     from buglab.models.gnn import build_gnn_mlp_module
 
     m = build_gnn_mlp_module(cfg.hidden, cfg.num_layers, cfg.num_edge_types, cfg.vocab_size, cfg.max_subtokens,
-                             cfg.rewrite_vocab_size, cfg.dropout, cfg.msg_act, cfg.buggy_samples_weight, model=cfg.model).to(device)
+                             cfg.rewrite_vocab_size, cfg.dropout, cfg.msg_act, cfg.buggy_samples_weight, model=cfg.model,
+                             edge_feature_size=cfg.edge_feature_size, edge_vocabulary_size=cfg.edge_vocab_size).to(device)
     if params is not None:
         load_oracle_params(m, params)
     return m
