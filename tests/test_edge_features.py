@@ -86,6 +86,43 @@ def test_feature_ids_follow_their_edges_through_tensorize_collate_and_packing():
     assert plain.tensorize(graphs[0]).edge_feature_ids is None and "msg_feat" not in collate_graphs([plain.tensorize(g) for g in graphs], T)
 
 
+def _edge_feature_golden():
+    import json
+    import os
+
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gdir, "edge_features.json"), encoding="utf-8") as f:
+        return os.path.join(gdir, "reference_shard_edge_features.msgpack.l.gz"), json.load(f)["datapoints"]
+
+
+@pytest.mark.parametrize("reader", ["python", "native"])
+def test_edge_features_of_as_graph_data_match_the_reference(reader, monkeypatch):
+    """`GraphData.edge_features` against what the REFERENCE's own `as_graph_data` produced for the same shard
+    (tests/golden/make_golden_edge_features.py; reference data.py:158-161): labels, pads, empty and non-ASCII labels, edge order
+    -- on the Python reader path and on the native one (where the strings stay in the reader's blob until asked for)."""
+    from buglab.data import native
+    from buglab.representations.data import BugLabData
+    from buglab.utils.msgpackutils import load_msgpack_l_gz
+
+    shard, want = _edge_feature_golden()
+    if reader == "native":
+        if not native.available():
+            pytest.skip("libbuglab_data.so not built")
+        points = list(native.load_msgpack_l_gz_native(shard))
+        assert isinstance(points[0]["graph"], native.NativeGraph)
+    else:
+        monkeypatch.setenv("BUGLAB_NATIVE_READER", "0")
+        points = list(load_msgpack_l_gz(shard))
+        assert not isinstance(points[0]["graph"], native.NativeGraph)
+    assert len(points) == len(want) == 8
+    for d, w in zip(points, want):
+        gd, _ = BugLabData.as_graph_data(d)
+        assert set(gd.edge_features.keys()) == set(w.keys()) == set(gd.edges.keys())
+        for kind in w:
+            assert list(gd.edge_features[kind]) == w[kind], kind
+            assert len(w[kind]) == np.asarray(gd.edges[kind]).reshape(-1, 2).shape[0]
+
+
 def _case_with_features(F=8, V=11, **kw):
     from buglab.data.collate import collate_samples
     from tests import helpers as Hh
