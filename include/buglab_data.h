@@ -73,6 +73,9 @@ typedef struct {
   const int32_t* token_lens;      /* [num_nodes] */
   const int32_t* const* adj;      /* T pointers to int32 [count][2] (source, target), graph-local node ids */
   const int32_t* adj_count;       /* [T] */
+  const int32_t* const* adj_feat; /* optional (NULL = none): T pointers to int32 [count], one value per edge -- the edge-feature
+                                   * token ids of a model with edge_feature_size > 0 (modelregistry.py:70-86); they travel with
+                                   * their messages into bl_collated_t.msg_feat.  (bl_data_version() >= 3) */
 } bl_graph_in_t;
 
 typedef struct {                  /* caller-allocated outputs; N = sum of num_nodes, E = sum of all adj_count */
@@ -87,6 +90,8 @@ typedef struct {                  /* caller-allocated outputs; N = sum of num_no
   int64_t occ_capacity;           /* >= number of valid subtoken slots; sizes tok_occ, tok_chunk_id, tok_chunk_ptr (+1) */
   int32_t* tok_occ; int32_t* tok_chunk_ptr; int32_t* tok_chunk_id;
   int64_t num_occ, num_chunks;    /* written by the call */
+  int32_t* msg_feat;              /* optional (NULL = none): [E] the graphs' adj_feat values in message order; every graph must
+                                   * then supply adj_feat.  (bl_data_version() >= 3) */
 } bl_collated_t;
 
 int32_t bl_collate_graphs(const bl_graph_in_t* graphs, int32_t B, int32_t T, int32_t S, int32_t hub_degree,

@@ -211,8 +211,7 @@ def collate_graphs(graphs: Sequence[TensorizedGraphData], num_edge_types: int) -
 
     from buglab.data import native
 
-    with_feat = any(g.edge_feature_ids is not None for g in graphs)  # (the native collator does not carry per-edge payloads)
-    if native.available() and os.environ.get("BUGLAB_NATIVE_COLLATE", "1") != "0" and not with_feat:
+    if native.available() and os.environ.get("BUGLAB_NATIVE_COLLATE", "1") != "0":
         arr = native.collate_graph_arrays(graphs, num_edge_types, HUB_DEGREE, _token_chunk())  # one GIL-free native call
     else:
         arr = _collate_graph_arrays_numpy(graphs, num_edge_types, node_off, N)

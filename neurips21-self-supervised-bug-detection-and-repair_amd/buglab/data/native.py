@@ -42,14 +42,15 @@ class bl_datapoint_t(Structure):
 
 class bl_graph_in_t(Structure):
     _fields_ = [("num_nodes", c_int32), ("token_stride", c_int32), ("token_ids", c_void_p), ("token_lens", c_void_p),
-                ("adj", c_void_p), ("adj_count", c_void_p)]
+                ("adj", c_void_p), ("adj_count", c_void_p), ("adj_feat", c_void_p)]
 
 
 class bl_collated_t(Structure):
     _fields_ = [("num_nodes", c_int64), ("num_messages", c_int64), ("token_ids", c_void_p), ("token_lens", c_void_p),
                 ("msg_src", c_void_p), ("msg_tgt", c_void_p), ("type_ptr", c_void_p), ("tgt_ptr", c_void_p), ("tgt_msgs", c_void_p),
                 ("src_ptr", c_void_p), ("src_msgs", c_void_p), ("node_order", c_void_p), ("occ_capacity", c_int64),
-                ("tok_occ", c_void_p), ("tok_chunk_ptr", c_void_p), ("tok_chunk_id", c_void_p), ("num_occ", c_int64), ("num_chunks", c_int64)]
+                ("tok_occ", c_void_p), ("tok_chunk_ptr", c_void_p), ("tok_chunk_id", c_void_p), ("num_occ", c_int64), ("num_chunks", c_int64),
+                ("msg_feat", c_void_p)]
 
 
 _SIGNATURES = {
@@ -126,6 +127,9 @@ def collate_graph_arrays(graphs, num_edge_types: int, hub_degree: int, token_chu
     keep = []  # arrays referenced by raw pointers must outlive the call
     N = E = 0
     empty = np.zeros((0, 2), dtype=np.int32)
+    with_feat = any(getattr(g, "edge_feature_ids", None) is not None for g in graphs)  # per-edge feature-token ids (edge features on)
+    if with_feat and lib.bl_data_version() < 3:
+        raise RuntimeError("libbuglab_data.so predates the per-edge payload of bl_collate_graphs: rebuild it")
     for b, g in enumerate(graphs):
         ids = np.ascontiguousarray(g.token_ids, dtype=np.int32)
         lens = np.ascontiguousarray(g.token_lens, dtype=np.int32)
@@ -137,6 +141,17 @@ def collate_graph_arrays(graphs, num_edge_types: int, hub_degree: int, token_chu
         gin[b].num_nodes, gin[b].token_stride = ids.shape[0], max(1, ids.shape[1])
         gin[b].token_ids, gin[b].token_lens = ids.ctypes.data, lens.ctypes.data
         gin[b].adj, gin[b].adj_count = ctypes.cast(ptrs, c_void_p), counts.ctypes.data
+        gin[b].adj_feat = None
+        if with_feat:
+            if g.edge_feature_ids is None:
+                raise ValueError("every graph of the minibatch needs one feature id per edge")
+            feats = [np.ascontiguousarray(g.edge_feature_ids[t] if t < len(g.edge_feature_ids) else np.zeros(0, np.int32), dtype=np.int32).reshape(-1)
+                     for t in range(T)]
+            if [f.shape[0] for f in feats] != counts.tolist():
+                raise ValueError("every graph of the minibatch needs one feature id per edge")
+            fptrs = (c_void_p * T)(*[f.ctypes.data for f in feats])
+            keep.append((feats, fptrs))
+            gin[b].adj_feat = ctypes.cast(fptrs, c_void_p)
         N += ids.shape[0]
         E += int(counts.sum())
     cap = N * S
@@ -145,7 +160,10 @@ def collate_graph_arrays(graphs, num_edge_types: int, hub_degree: int, token_chu
          "tgt_msgs": np.empty(E, np.int32), "src_ptr": np.empty(N + 1, np.int32), "src_msgs": np.empty(E, np.int32),
          "node_order": np.empty(N, np.int32), "tok_occ": np.empty(cap, np.int32), "tok_chunk_ptr": np.empty(cap + 1, np.int32),
          "tok_chunk_id": np.empty(cap, np.int32)}
+    if with_feat:
+        o["msg_feat"] = np.empty(E, np.int32)
     c = bl_collated_t()
+    c.msg_feat = None
     c.num_nodes, c.num_messages, c.occ_capacity = N, E, cap
     for k, a in o.items():
         setattr(c, k, a.ctypes.data)

@@ -490,7 +490,7 @@ bool parse_datapoint(bl_reader* r, P p, P end, bl_datapoint_t* out) {
 }  // namespace
 
 extern "C" const char* bl_data_last_error(void) { return g_err; }
-extern "C" int32_t bl_data_version(void) { return 2; }
+extern "C" int32_t bl_data_version(void) { return 3; }  // 3: bl_graph_in_t.adj_feat / bl_collated_t.msg_feat
 
 extern "C" int32_t bl_pyset_order(const int32_t* inserted, int32_t n, int32_t* out) {
   if (n < 0 || (n > 0 && (!inserted || !out))) { set_err("bl_pyset_order: bad arguments"); return -1; }
@@ -654,21 +654,24 @@ extern "C" int32_t bl_collate_graphs(const bl_graph_in_t* graphs, int32_t B, int
     }
   }
   // messages: per type, gather in graph order, then a stable counting sort by target inside the type
-  std::vector<int32_t> tsrc, ttgt, cnt((size_t)N + 1);
+  std::vector<int32_t> tsrc, ttgt, tfeat, cnt((size_t)N + 1);
+  const bool with_feat = out->msg_feat != nullptr;  // a per-edge payload (edge-feature token ids) travels with the messages
   int64_t pos = 0;
   out->type_ptr[0] = 0;
   for (int32_t t = 0; t < T; ++t) {
-    tsrc.clear(); ttgt.clear();
+    tsrc.clear(); ttgt.clear(); tfeat.clear();
     for (int32_t b = 0; b < B; ++b) {
       const bl_graph_in_t& g = graphs[b];
       const int32_t c = g.adj_count ? g.adj_count[t] : 0;
       const int32_t* a = g.adj ? g.adj[t] : nullptr;
       const int32_t off = (int32_t)node_off[b];
+      if (with_feat && c > 0 && (!g.adj_feat || !g.adj_feat[t])) { set_err("bl_collate_graphs: graph %d type %d: msg_feat requested but no adj_feat", b, t); return -1; }
       for (int32_t e = 0; e < c; ++e) {
         const int32_t u = a[2 * e], v = a[2 * e + 1];
         if (u < 0 || u >= g.num_nodes || v < 0 || v >= g.num_nodes) { set_err("bl_collate_graphs: graph %d type %d edge %d: node id out of range", b, t, e); return -2; }
         tsrc.push_back(u + off);
         ttgt.push_back(v + off);
+        if (with_feat) tfeat.push_back(g.adj_feat[t][e]);
       }
     }
     const size_t m = ttgt.size();
@@ -684,6 +687,7 @@ extern "C" int32_t bl_collate_graphs(const bl_graph_in_t* graphs, int32_t B, int
         const int32_t p = cnt[(size_t)(ttgt[i] - lo)]++;
         out->msg_src[pos + p] = tsrc[i];
         out->msg_tgt[pos + p] = ttgt[i];
+        if (with_feat) out->msg_feat[pos + p] = tfeat[i];
       }
     }
     pos += (int64_t)m;

@@ -43,7 +43,7 @@ def test_exports_match_header():
     declared = sorted(set(re.findall(r"\b(bl_[a-z0-9_]+)\s*\(", src)))
     nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert declared == sorted(set(re.findall(r" T (bl_[a-z0-9_]+)", nm))) == sorted(native.EXPORTED_SYMBOLS)
-    assert native.load_library().bl_data_version() >= 1
+    assert native.load_library().bl_data_version() >= 3  # 3: per-edge payload in bl_collate_graphs
 
 
 def test_subtoken_split_matches_python_regex():
@@ -154,6 +154,25 @@ def test_native_collator_equals_numpy_collator(degree, monkeypatch):
               "tok_occ", "tok_chunk_ptr", "tok_chunk_id"):
         assert a[k].dtype == np.int32 and np.array_equal(a[k], b[k]), k
     assert (np.diff(a["tgt_ptr"]) + np.diff(a["src_ptr"])).max() > C.HUB_DEGREE or degree == "uniform"
+    assert "msg_feat" not in a and "msg_feat" not in b
+    # a per-edge payload (edge-feature token ids, edge_feature_size > 0) follows its message through both collators
+    rng = np.random.default_rng(3)
+    for smp in samples:
+        smp.graph_data.edge_feature_ids = [rng.integers(0, 1000, adj.shape[0]).astype(np.int32) for adj in smp.graph_data.adjacency_lists]
+    monkeypatch.setenv("BUGLAB_NATIVE_COLLATE", "1")
+    a = C.collate_samples(samples, 6)["graph_data"]
+    monkeypatch.setenv("BUGLAB_NATIVE_COLLATE", "0")
+    b = C.collate_samples(samples, 6)["graph_data"]
+    assert a["msg_feat"].dtype == np.int32 and a["msg_feat"].shape == a["msg_src"].shape
+    for k in ("msg_src", "msg_tgt", "type_ptr", "msg_feat"):
+        assert np.array_equal(a[k], b[k]), k
+    samples[2].graph_data.edge_feature_ids = None  # a graph without ids in a minibatch that has them: refused by both
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BUGLAB_NATIVE_COLLATE", flag)
+        with pytest.raises((ValueError, AssertionError)):
+            C.collate_samples(samples, 6)
+    for smp in samples:
+        smp.graph_data.edge_feature_ids = None
     # an empty minibatch of graphs without edges
     empty = C.collate_graphs([], 4)
     assert empty["msg_src"].size == 0 and empty["type_ptr"].tolist() == [0] * 5
