@@ -204,6 +204,37 @@ def test_host_pipeline_tags_the_args_edges_of_raw_datapoints():
             assert (seg == pad_id).all()
 
 
+def test_loader_processes_hand_over_the_feature_ids(tmp_path):
+    """Shards on disk -> loader processes (native reader, tensorise, native collator, packed through shared memory) ->
+    `receive_packed`: `msg_feat` arrives with the other index arrays and equals what the in-process NumPy path builds."""
+    from buglab.data import collate as C
+    from buglab.data.synthetic import make_buglab_dataset
+    from buglab.models.modelregistry import load_model
+    from buglab.runtime.shardloader import ShardDataset, collated_minibatches_parallel, receive_packed
+    from buglab.utils.msgpackutils import save_msgpack_l_gz
+
+    data = make_buglab_dataset(24, seed=12)
+    for i in range(3):
+        save_msgpack_l_gz(data[8 * i : 8 * i + 8], tmp_path / f"s{i}.msgpack.l.gz")
+    ds = ShardDataset(str(tmp_path))
+    model, _, _ = load_model({"modelName": "gnn-mlp", "edge_feature_size": 8, "hidden_state_size": 32, "num_layers": 4}, tmp_path / "m.pkl.gz")
+    for d in ds:
+        model.update_metadata_from(d)
+    model.finalize_metadata()
+    args_id = model._gnn_model.edge_representation_model.vocabulary.get_id_or_unk("args")
+    plain = {int(m["graph_data"]["msg_src"].sum()): C.to_device(m, "cpu") for m in collated_minibatches_parallel(model, ds.shard_files(), 1, 4)}
+    got = [receive_packed(it, "cpu") for it in collated_minibatches_parallel(model, ds.shard_files(), 2, 4, packed=True)]
+    assert len(got) == len(plain) == 6
+    n_args = 0
+    for g in got:
+        ref = plain[int(g["graph_data"]["msg_src"].sum())]
+        for k in ("msg_src", "msg_tgt", "type_ptr", "msg_feat"):
+            assert torch.equal(g["graph_data"][k], ref["graph_data"][k]), k
+        assert g["graph_data"]["msg_feat"].dtype == torch.int32 and g["graph_data"]["msg_feat"].shape == g["graph_data"]["msg_src"].shape
+        n_args += int((g["graph_data"]["msg_feat"] == args_id).sum())
+    assert n_args == 2 * sum(1 for d in data for e in d["graph"]["edges"]["Child"] if len(e) >= 3)  # forward + reversed messages
+
+
 @pytest.mark.gpu
 def test_train_cli_with_edge_features(tmp_path):
     """`train.py gnn-mlp ... --model-spec '{"edge_feature_size": 8}'` end to end (loader processes, trainer, evaluation)."""
