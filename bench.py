@@ -4,6 +4,8 @@
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            # no launcher: re-runs itself under torch.distributed.run (self_launch)
+    python bench.py --gpus 2 --dry-launch   # launcher self-test, CPU / gloo when no GPU is visible
 
 One "step" = forward + backward + gradient all-reduce (N > 1) + clip + Adam on one minibatch of
 synthetic PyPI-shaped code graphs that is already resident in HBM.  Workload at every N (weak
@@ -69,6 +71,81 @@ def algorithmic_work_per_graph(H, layers, N, E, T, B):
         theta = T * 2 * din * dm + dm * dout + 2 * dm + dout
         byts += 4.0 * N * din + 8.0 * E + 4.0 * N * dout + 4.0 * theta / B
     return flop, byts
+
+
+def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, fwd_flop, fwd_bytes, brief=False):
+    """The `roofline` object of a bench line from the HIP-event tables of the profiling passes (hip_ops.KernelTimer).
+    Dominant kernel = largest EXCLUSIVE time per step among the MFMA GEMM kinds of the serial pass (msg_dgrad_nodes runs
+    on the vector units / LDS: listed with its non-zero FLOP rate, not a candidate; seq-great's attention kernels stream
+    [B H L, L] score-sized matrices -- kinds that carry algorithmic bytes are candidates too, priced against the HBM peak).
+    brief: the short form attached to an `also` entry (no per-kind tables)."""
+    gemm = {k: v for k, v in kern.items() if (v["flop"] > 0 or v.get("bytes", 0) > 0) and v["ms"] > 0 and not k.endswith(("_nodes", "_vec"))}
+    if not gemm:
+        return None
+    dom = max(gemm, key=lambda k: gemm[k]["ms"])
+    d = kern[dom]
+    hbm = d.get("bytes", 0) > 0
+    achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if hbm else d["flop"] / (d["ms"] * 1e-3) / 1e12
+    x6 = "x6" in dom
+    peak = HBM_PEAK_GBS if hbm else (MFMA_X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS)
+    traffic, traffic_src = measured_traffic(dom)
+    per_step = lambda table: {k: {"ms_per_step": round(v["ms"] / prof_steps, 3),
+                                  **({"tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flop"] > 0 and v["ms"] > 0 else {}),
+                                  **({"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v.get("bytes", 0) > 0 and v["ms"] > 0 else {}),
+                                  **({"overlapped": True} if v.get("overlapped") else {})} for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])}
+    roof = {
+        "bound": "hbm" if hbm else "mfma",
+        "kernel": dom,
+        "achieved": round(achieved, 2),
+        "peak": round(peak, 1),
+        "peak_basis": ("HBM3E peak; achieved = algorithmic bytes of the launch (operands read once, results written once) / its duration"
+                       if hbm else "dense bf16 MFMA peak 2500 TF/s / 6 (bf16x6: six bf16 MFMA terms per fp32-accurate product)"
+                       if x6 else "dense fp32 MFMA peak"),
+        "unit": "GB/s" if hbm else "TFLOP/s",
+        "frac": round(achieved / peak, 4),
+        **({} if hbm else {"frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4)}),
+        "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+        "launches_per_step": d["launches"] / prof_steps,
+        "share_of_serial_gpu_time": round(d["ms"] / sum(v["ms"] for v in kern.values()), 4),
+        "serial_ms_per_step": round(1e3 * serial_step_s, 3),
+        # whole-step view against both ceilings (SURVEY section 8d): training ~ 3x forward work
+        "step_frac_of_mfma_x6_roofline": round(per_gpu_rate * 3 * fwd_flop / (MFMA_X6_PEAK_TFLOPS * 1e12), 4),
+    }
+    mfma_busy = measured_mfma_busy(dom)
+    if mfma_busy is not None:
+        roof["mfma_busy_frac"], roof["mfma_busy_source"] = mfma_busy
+    if brief:
+        top = sorted(gemm, key=lambda k: -gemm[k]["ms"])[:4]
+        roof["top_kernels_serial"] = {k: per_step(kern)[k] for k in top}
+        return roof
+    roof.update({
+        "traffic": None if traffic is None else round(traffic),
+        "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits included)",
+        "traffic_source": traffic_src,
+        "measured": f"HIP events around every launch, {prof_steps} serial steps (side stream off) after the timed region: exclusive kernel time",
+        "kernels_serial": per_step(kern),
+        "kernels_as_timed": per_step(kern_overlap),
+        "step_frac_of_mfma_f32_roofline": round(per_gpu_rate * 3 * fwd_flop / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),
+        "step_frac_of_hbm_roofline_compulsory_bytes": round(per_gpu_rate * 3 * fwd_bytes / (HBM_PEAK_GBS * 1e9), 4),
+    })
+    return roof
+
+
+def measured_mfma_busy(kind):
+    """Matrix-pipe busy fraction of `kind`'s kernel from the newest committed SQ counter summary under profiles/
+    (`*_pmc_sq.json`: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMDs x CUs), a separate rocprofv3 --pmc pass over
+    this same bench command).  None if there is no such file."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]*_pmc_sq.json")))
+    name = _KIND_TO_KERNEL.get(kind)
+    if not files or name is None:
+        return None
+    with open(files[-1]) as f:
+        rec = json.load(f).get("kernels", {}).get(name)
+    if not rec or rec.get("mfma_busy_frac") is None:
+        return None
+    return round(float(rec["mfma_busy_frac"]), 4), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(args, seconds_budget=25.0):
@@ -151,6 +228,48 @@ def cpu_baseline_seq(args, seconds_budget=25.0):
             "sample": f"{n_steps} forward+backward passes of {nb} sequences ({args.seq_len} tokens, H{D}, {args.layers} layers) on the CPU oracle, dropout 0"}
 
 
+def self_launch(nproc: int) -> int:
+    """Re-run this very command line under `python -m torch.distributed.run --nproc-per-node nproc` and return its exit
+    code.  The children see WORLD_SIZE and take the normal path; rank 0's JSON line goes to our stdout unchanged."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL / cross-process tensors)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // nproc)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(expected_world: int) -> int:
+    """Proves the launch path without touching a kernel: every rank joins the process group (RCCL when a GPU is
+    visible, gloo otherwise), the ranks all-reduce their rank numbers, rank 0 prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+
+    from buglab.runtime import distributed as D
+
+    on_gpu = torch.cuda.is_available()
+    rank, world, device = D.init_from_env("cuda" if on_gpu else "cpu")
+    total = float(rank)
+    if world > 1:
+        t = torch.tensor([float(rank)], device=device)
+        dist.all_reduce(t)
+        total = float(t.item())
+        dist.barrier()
+    ok = world == expected_world and total == world * (world - 1) / 2.0
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "ok": ok, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None,
+                          "rank_sum": total}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +293,15 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce per step instead of layer-wise buckets behind backward")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under `also` (configs[2] shard, seq-great)")
     ap.add_argument("--no-predict", action="store_true", help="skip the forward-only passes after the timed training steps (profiling)")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher self-test: start the --gpus ranks, initialise the process group "
+                    "(gloo on CPU when there is no GPU), all-reduce one number, print one JSON line and exit -- no kernels")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  One process per GPU under
+        # torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container host name may not resolve).
+        sys.exit(self_launch(args.gpus))
+    if args.dry_launch:
+        sys.exit(dry_launch(args.gpus))
     seq = args.model == "seq-great"
     if args.hidden is None:
         args.hidden = 256 if seq else 128
@@ -194,7 +321,8 @@ def main():
     from buglab.runtime.optim import FlatAdam
 
     rank, world, device = D.init_from_env("cuda")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus and rank == 0:  # the launcher decides; the line reports what actually ran (n_gpus = world)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running and reporting n_gpus={world}", file=sys.stderr)
     hip_ops.load_library()  # fail loudly if the HIP extension is missing
     if args.serial:
         hip_ops.USE_SIDE_STREAM = False
@@ -218,7 +346,9 @@ def main():
             samples = make_samples(a.graphs, seed=1000 + rank, num_nodes=a.nodes, num_messages=a.messages, num_edge_types=a.types,
                                    degree=a.degree, max_degree=512)
             mb_ = to_device(collate_samples(samples, a.types), device)
-            module_ = build_gnn_mlp_module(a.hidden, a.layers, a.types, dropout_rate=a.dropout, dropout_base_seed=rank).to(device).train()
+            # what the registry's gnn() builds: layer dropout a.dropout, node-embedder dropout 0 (reference modelregistry.py:79-82)
+            module_ = build_gnn_mlp_module(a.hidden, a.layers, a.types, dropout_rate=a.dropout, dropout_base_seed=rank,
+                                           embedder_dropout_rate=0.0).to(device).train()
         opt_ = FlatAdam(module_.parameters())
         if world > 1:
             opt_.broadcast_parameters(0)  # what the trainer does before its first step
@@ -256,6 +386,34 @@ def main():
         torch.cuda.synchronize()
         return D.max_over_ranks(time.perf_counter() - t0_, device), loss_
 
+    prof_steps = max(3, min(args.steps, 10))
+
+    def profile_pass(step_, side_stream: bool):
+        prev = hip_ops.USE_SIDE_STREAM
+        hip_ops.USE_SIDE_STREAM = side_stream and not args.serial
+        try:
+            step_()
+            torch.cuda.synchronize()
+            with hip_ops.KernelTimer() as timer:
+                tp0 = time.perf_counter()
+                for _ in range(prof_steps):
+                    step_()
+                torch.cuda.synchronize()
+                wall = time.perf_counter() - tp0
+                return timer.summary(), wall / prof_steps
+        finally:
+            hip_ops.USE_SIDE_STREAM = prev
+
+    def fwd_work(a):
+        """(forward FLOPs, compulsory forward bytes) per graph / sequence of configuration `a` (SURVEY 8d / 8f formulas)."""
+        if a.model == "seq-great":
+            # per sequence and layer: QKV + output projections 8 L D^2, feed-forward 4 L D FF, Q.K^T + P.V 4 L^2 D (SURVEY 8f: ~5.4 GFLOP)
+            Ls, Dh, FFd = a.seq_len, a.hidden, 4 * a.hidden
+            n_par = a.layers * (4 * Dh * Dh + 2 * Dh * FFd)
+            return (a.layers * (8.0 * Ls * Dh * Dh + 4.0 * Ls * Dh * FFd + 4.0 * Ls * Ls * Dh),
+                    a.layers * (3 * 4.0 * Ls * Dh) + 4.0 * n_par / a.graphs)
+        return algorithmic_work_per_graph(a.hidden, a.layers, a.nodes, a.messages, a.types, a.graphs)
+
     def side_config(**over):
         """One more BASELINE configuration, timed the same way (warm-up, barrier + synchronize on both sides, max over
         ranks) AFTER the headline run, on its own model and minibatch: reported under `also`, never as `value`."""
@@ -266,15 +424,19 @@ def main():
         for k, v in over.items():
             setattr(a, k, v)
         m_, mb2_, o_ = build_workload(a)
-        el_, _ = timed(make_step(m_, mb2_, o_, a.graphs), args.steps, args.warmup)
+        st_ = make_step(m_, mb2_, o_, a.graphs)
+        el_, _ = timed(st_, args.steps, args.warmup)
+        kern_, serial_s_ = profile_pass(st_, False)  # exclusive kernel times of this configuration (after its timed region)
         hip_ops.join_side_stream()
         torch.cuda.synchronize()
-        del m_, mb2_, o_
+        del m_, mb2_, o_, st_
         gc.collect()
         torch.cuda.empty_cache()
         unit = "sequences/s" if a.model == "seq-great" else "graphs/s"
-        return {"value": round(a.graphs * world * args.steps / el_, 2), "unit": unit, "ms_per_step": round(1e3 * el_ / args.steps, 3),
-                "per_gpu": a.graphs, "n_gpus": world}
+        rate_ = a.graphs * world * args.steps / el_
+        return {"value": round(rate_, 2), "unit": unit, "ms_per_step": round(1e3 * el_ / args.steps, 3),
+                "per_gpu": a.graphs, "n_gpus": world,
+                "roofline": build_roofline(kern_, {}, prof_steps, serial_s_, rate_ / world, *fwd_work(a), brief=True)}
 
     module, mb, opt = build_workload(args)
 
@@ -303,26 +465,8 @@ def main():
     #       overlap and are flagged;
     #   (b) serial (side stream off): every span is exclusive kernel time.  The roofline entry is taken from (b):
     #       the kernel with the largest exclusive share of the step.
-    prof_steps = max(3, min(args.steps, 10))
-
-    def profile_pass(side_stream: bool):
-        prev = hip_ops.USE_SIDE_STREAM
-        hip_ops.USE_SIDE_STREAM = side_stream and not args.serial
-        try:
-            step()
-            torch.cuda.synchronize()
-            with hip_ops.KernelTimer() as timer:
-                tp0 = time.perf_counter()
-                for _ in range(prof_steps):
-                    step()
-                torch.cuda.synchronize()
-                wall = time.perf_counter() - tp0
-                return timer.summary(), wall / prof_steps
-        finally:
-            hip_ops.USE_SIDE_STREAM = prev
-
-    kern_overlap, _ = profile_pass(True)      # every rank steps (the optimiser all-reduces); rank 0 reports
-    kern, serial_step_s = profile_pass(False)
+    kern_overlap, _ = profile_pass(step, True)      # every rank steps (the optimiser all-reduces); rank 0 reports
+    kern, serial_step_s = profile_pass(step, False)
     if world > 1:
         dist.barrier()
 
@@ -365,59 +509,9 @@ def main():
 
     if rank == 0:
         total_graphs = args.graphs * world * args.steps
-        if seq:
-            # per sequence and layer: QKV + output projections 8 L D^2, feed-forward 4 L D FF, Q.K^T + P.V 4 L^2 D (~5.4 GFLOP)
-            Ls, Dh, FFd = args.seq_len, args.hidden, 4 * args.hidden
-            fwd_flop = args.layers * (8.0 * Ls * Dh * Dh + 4.0 * Ls * Dh * FFd + 4.0 * Ls * Ls * Dh)
-            n_par = args.layers * (4 * Dh * Dh + 2 * Dh * FFd)
-            fwd_bytes = args.layers * (3 * 4.0 * Ls * Dh) + 4.0 * n_par / args.graphs
-        else:
-            fwd_flop, fwd_bytes = algorithmic_work_per_graph(args.hidden, args.layers, args.nodes, args.messages, args.types, args.graphs)
+        fwd_flop, fwd_bytes = fwd_work(args)
         value = total_graphs / elapsed
-        # dominant kernel = largest EXCLUSIVE time per step among the MFMA GEMM kinds (serial pass)
-        # (msg_dgrad_nodes runs on the vector units / LDS: listed with its non-zero FLOP rate, not a candidate here)
-        # (seq-great: its attention kernels stream the [B H L, L] score-sized matrices -- kinds that carry algorithmic bytes are
-        # candidates too and are priced against the HBM peak)
-        gemm = {k: v for k, v in kern.items() if (v["flop"] > 0 or v.get("bytes", 0) > 0) and v["ms"] > 0 and not k.endswith(("_nodes", "_vec"))}
-        dom = max(gemm, key=lambda k: gemm[k]["ms"]) if gemm else None
-        roof = None
-        if dom:
-            d = kern[dom]
-            hbm = d.get("bytes", 0) > 0
-            achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if hbm else d["flop"] / (d["ms"] * 1e-3) / 1e12
-            x6 = "x6" in dom
-            peak = HBM_PEAK_GBS if hbm else (MFMA_X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS)
-            traffic, traffic_src = measured_traffic(dom)
-            per_step = lambda table: {k: {"ms_per_step": round(v["ms"] / prof_steps, 3),
-                                          **({"tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flop"] > 0 and v["ms"] > 0 else {}),
-                                          **({"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v.get("bytes", 0) > 0 and v["ms"] > 0 else {}),
-                                          **({"overlapped": True} if v.get("overlapped") else {})} for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])}
-            roof = {
-                "bound": "hbm" if hbm else "mfma",
-                "kernel": dom,
-                "achieved": round(achieved, 2),
-                "peak": round(peak, 1),
-                "peak_basis": ("HBM3E peak; achieved = algorithmic bytes of the launch (operands read once, results written once) / its duration"
-                               if hbm else "dense bf16 MFMA peak 2500 TF/s / 6 (bf16x6: six bf16 MFMA terms per fp32-accurate product)"
-                               if x6 else "dense fp32 MFMA peak"),
-                "unit": "GB/s" if hbm else "TFLOP/s",
-                "frac": round(achieved / peak, 4),
-                **({} if hbm else {"frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4)}),
-                "traffic": None if traffic is None else round(traffic),
-                "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits included)",
-                "traffic_source": traffic_src,
-                "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                "launches_per_step": d["launches"] / prof_steps,
-                "measured": f"HIP events around every launch, {prof_steps} serial steps (side stream off) after the timed region: exclusive kernel time",
-                "share_of_serial_gpu_time": round(d["ms"] / sum(v["ms"] for v in kern.values()), 4),
-                "kernels_serial": per_step(kern),
-                "kernels_as_timed": per_step(kern_overlap),
-                "serial_ms_per_step": round(1e3 * serial_step_s, 3),
-                # whole-step view against both ceilings: training ~ 3x forward work
-                "step_frac_of_mfma_x6_roofline": round(value / world * 3 * fwd_flop / (MFMA_X6_PEAK_TFLOPS * 1e12), 4),
-                "step_frac_of_mfma_f32_roofline": round(value / world * 3 * fwd_flop / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),
-                "step_frac_of_hbm_roofline_compulsory_bytes": round(value / world * 3 * fwd_bytes / (HBM_PEAK_GBS * 1e9), 4),
-            }
+        roof = build_roofline(kern, kern_overlap, prof_steps, serial_step_s, value / world, fwd_flop, fwd_bytes)
         line = {
             "metric": "code-graphs/sec (train: fwd+bwd+optimizer)",
             "value": round(value, 2),

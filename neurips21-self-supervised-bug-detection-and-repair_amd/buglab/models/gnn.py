@@ -305,15 +305,20 @@ def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_
                          vocabulary_size: int = 15000, max_num_subtokens: int = 6, rewrite_vocabulary_size: int = 48,
                          dropout_rate: float = 0.2, message_activation: str = "gelu",
                          buggy_samples_weight: float = 1.0, dropout_base_seed: int = 0, model: str = "gnn-mlp",
-                         edge_feature_size: int = 0, edge_vocabulary_size: int = 0) -> GnnBugLabModule:
+                         edge_feature_size: int = 0, edge_vocabulary_size: int = 0,
+                         embedder_dropout_rate: Optional[float] = None) -> GnnBugLabModule:
     """Device module for given hyper-parameters without a metadata pass (bench / tests / synthetic
-    runs).  `GnnBugLabModel.build_neural_module()` goes through the same constructors."""
+    runs).  `GnnBugLabModel.build_neural_module()` goes through the same constructors.
+    `embedder_dropout_rate`: dropout of the node embedder; None = `dropout_rate` (the oracle's single-rate
+    configuration the parity tests use).  The registry-built gnn models pass 0.0 unless `node_representations` carries a
+    rate: the reference's `gnn()` does not hand `dropout_rate` to the node embedder (modelregistry.py:79-82)."""
     from functools import partial
 
     from buglab.models.gnnlayerdefs import create_mlp_mp_layers
     from buglab.models.layers.messagepassing import SubtokenEmbedder, TokenEmbedder
 
-    embed = SubtokenEmbedder(vocabulary_size, hidden_state_size, max_num_subtokens, dropout_rate)
+    embed = SubtokenEmbedder(vocabulary_size, hidden_state_size, max_num_subtokens,
+                             dropout_rate if embedder_dropout_rate is None else embedder_dropout_rate)
     edge_embed = TokenEmbedder(edge_vocabulary_size, edge_feature_size) if edge_feature_size > 0 else None
     if model == "ggnn":
         assert edge_embed is None

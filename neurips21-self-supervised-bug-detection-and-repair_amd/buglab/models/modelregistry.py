@@ -68,8 +68,10 @@ def gnn(*, mp_layer, add_self_edge: bool, use_all_gnn_layer_outputs: bool = Fals
         extra["message_activation"] = message_activation
     return GnnBugLabModel(
         GraphNeuralNetworkModel(
-            node_representation_model=StrElementRepresentationModel(embedding_size=hidden_state_size, dropout_rate=dropout_rate,
-                                                                    **node_representations),
+            # reference :79-82: the node embedder gets NO dropout_rate from gnn() -- only what `node_representations` carries,
+            # else the representation model's own default (0.0 here; ptgnn's constructor default, which is not in the tree).
+            # The sequence models do pass theirs (seqmodel.py:425-431).
+            node_representation_model=StrElementRepresentationModel(embedding_size=hidden_state_size, **node_representations),
             edge_representation_model=edge_representation_model,
             add_self_edges=add_self_edge,
             add_backwards_edges=add_backwards_edges,

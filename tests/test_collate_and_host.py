@@ -121,6 +121,20 @@ def test_registry_contract():
     assert model.gnn_model.node_representation_model.vocabulary_size == 15000 and model.gnn_model.max_nodes_per_graph == 35000
 
 
+def test_node_embedder_dropout_comes_from_node_representations_only():
+    """reference modelregistry.py:79-82: gnn() builds the node embedder as StrElementRepresentationModel(embedding_size=...,
+    **node_representations) -- `dropout_rate` reaches the message-passing layers only.  The sequence models do hand their rate
+    to the embedder (seqmodel.py:425-431)."""
+    from buglab.models import modelregistry as R
+
+    m, _, _ = R.load_model({"modelName": "gnn-mlp", "dropout_rate": 0.3}, Path("/tmp/x.pkl.gz"))
+    assert m.gnn_model.node_representation_model.dropout_rate == 0.0
+    m, _, _ = R.load_model({"modelName": "gnn-mlp", "dropout_rate": 0.3, "node_representations": {"dropout_rate": 0.15}}, Path("/tmp/x.pkl.gz"))
+    assert m.gnn_model.node_representation_model.dropout_rate == 0.15
+    m, _, _ = R.load_model({"modelName": "ggnn", "dropout_rate": 0.3}, Path("/tmp/x.pkl.gz"))
+    assert m.gnn_model.node_representation_model.dropout_rate == 0.0
+
+
 def test_tensorize_rewrite_bookkeeping_and_drop_rule():
     data = make_buglab_dataset(10, seed=4)
     model = _model()

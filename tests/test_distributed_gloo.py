@@ -4,6 +4,7 @@ gradient.  The per-rank gradient comes from the CPU oracle (tests may use it); t
 the product's (buglab.runtime.optim.FlatAdam.reduce_gradients, buglab.runtime.distributed)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +14,8 @@ import torch.multiprocessing as mp
 
 from oracle import buglab_oracle as O
 from tests import helpers as Hh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -273,3 +276,19 @@ def test_layerwise_gradient_buckets_equal_single_allreduce(tmp_path):
     step; no hang under out-of-order notifications."""
     _spawn(_bucket_worker, (2, _free_port(), str(tmp_path)))
     assert torch.equal(torch.load(tmp_path / "b0.pt"), torch.load(tmp_path / "b1.pt"))
+
+
+def test_bench_launches_itself_for_several_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must become the launcher (torch.distributed.run on 127.0.0.1)
+    and get both ranks through init_process_group -- the first hardware SCALE run may be started exactly like that.
+    --dry-launch stops after one all-reduce (gloo here: no GPU)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec == {"dry_launch": True, "ok": True, "n_gpus": 2, "backend": "gloo", "rank_sum": 1.0}
