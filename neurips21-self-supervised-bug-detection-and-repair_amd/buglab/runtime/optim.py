@@ -163,6 +163,25 @@ class FlatAdam:
         if self._armed_B > 0:
             hip_ops.set_grad_ready_callback(self._on_layer_backward_launched)
 
+    def abort_data_parallel_step(self) -> None:
+        """Leave an armed step cleanly when forward / backward raised between `begin_data_parallel_step` and
+        `step_data_parallel` (an out-of-memory minibatch, a caller that skips the step): the backward callback is
+        disarmed -- a later backward must not issue collectives nobody expects -- and the collectives of THIS step's plan
+        that were not issued yet are issued and waited for, so that the peers, which issue the same plan, are not left
+        hanging in it while the exception travels up on this rank.  The reduced values are meaningless; no update follows."""
+        hip_ops.set_grad_ready_callback(None)
+        if self._armed_B is None:
+            return
+        try:
+            self._issue_ready(everything=True)
+            for lo, hi in self._rest:
+                self._all_reduce_range(lo, hi)
+            for w in self._works:
+                w.wait()
+        finally:
+            self._works = []
+            self._armed_B = None
+
     def _on_layer_backward_launched(self, params) -> None:
         for p in params:
             b = self._bucket_of.get(id(p))

@@ -165,7 +165,9 @@ class ModelTrainer:
         rank, world = self._world()
         yield from D.balanced_rank_share(data, rank, world)
 
-    def _iter_minibatches(self, data, device, parallelize, shuffle_key=None):
+    def _iter_minibatches(self, data, device, parallelize, shuffle_key=None, use_prestarted: bool = False):
+        """use_prestarted: only the TRAINING epoch loop passes True -- the pool forked by `_prestart_loaders` belongs to the
+        next training epoch; validation runs in between and must neither consume nor close it."""
         from buglab.runtime.shardloader import collated_minibatches_parallel, default_num_workers
 
         workers = default_num_workers() if (parallelize and self._use_multiprocessing) else 0
@@ -189,7 +191,8 @@ class ModelTrainer:
             def received():  # runs in a prefetch thread: the staging copy + pinned H2D copy overlap the trainer
                 seen = 0     # thread's kernel launches; the int32 blob comes through shared memory, not the pipe
                 files = data.shard_files()
-                pool = self._take_prestarted_pool(data, files)  # forked while the previous epoch's validation was running
+                # forked while the previous epoch's validation was running (validation itself never takes it)
+                pool = self._take_prestarted_pool(data, files) if use_prestarted else None
                 source = collated_minibatches_parallel(self.model, files, workers, self._minibatch_size, rank, world, packed=True, pool=pool)
                 try:
                     while True:
@@ -281,7 +284,7 @@ class ModelTrainer:
         nn.reset_metrics()
         if hasattr(training_data, "set_epoch"):
             training_data.set_epoch(epoch)  # every rank shuffles the shard files with the same per-epoch seed
-        it = iter(self._iter_minibatches(training_data, device, parallelize))
+        it = iter(self._iter_minibatches(training_data, device, parallelize, use_prestarted=True))
         step, num_graphs, t0 = 0, 0, time.time()
         B = 0
         _, world = self._world()
@@ -310,8 +313,15 @@ class ModelTrainer:
                     if hasattr(optimizer, "begin_data_parallel_step"):
                         optimizer.begin_data_parallel_step(B)  # layer-wise gradient buckets reduce during backward
                     if mb is not None:
-                        loss = nn(**mb)
-                        loss.backward()
+                        try:
+                            loss = nn(**mb)
+                            loss.backward()
+                        except BaseException:
+                            # the layer-wise all-reduces are armed: disarm them and complete this step's plan before the
+                            # exception leaves (a stale callback would issue collectives the peers do not expect)
+                            if hasattr(optimizer, "abort_data_parallel_step"):
+                                optimizer.abort_data_parallel_step()
+                            raise
                     optimizer.step_data_parallel(B)
                 else:
                     if not self._all_ranks_have(mb is not None, device):

@@ -12,6 +12,7 @@
 void bl_set_error(const char* fmt, ...);
 extern "C" int32_t bl_get_deterministic(void);
 int bl_num_cus();  // bl_core.hip
+int bl_max_lds_per_block();  // bl_core.hip: LDS bytes a workgroup may declare on the current device
 // n zeroed turn counters for one launch on `stream`, or nullptr when the deterministic mode is off (bl_core.hip)
 unsigned* bl_order_counters(int n, void* stream);
 

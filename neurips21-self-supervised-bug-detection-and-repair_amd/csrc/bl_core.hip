@@ -39,6 +39,14 @@ int bl_num_cus() {
   return ncu;
 }
 
+// LDS bytes one workgroup may declare on the CURRENT device (160 KiB on gfx950); queried per call -- a process may drive more
+// than one device
+int bl_max_lds_per_block() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return 0;
+  return v;
+}
+
 extern "C" int32_t bl_get_deterministic(void) {
   if (g_deterministic < 0) {
     const char* e = getenv("BL_DETERMINISTIC");

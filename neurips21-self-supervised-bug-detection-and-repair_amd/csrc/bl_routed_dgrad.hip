@@ -29,9 +29,9 @@ constexpr int RD_GROUP = 4;  // messages whose operands a wave requests together
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct RdPair {
-  int row_off;  // channel * NOUT (floats): offset of the channel's weight row in the LDS block
-  float g;
+struct RdPair {  // one non-zero of a message's routed gradient; both members int so that the list is written and read as ints
+  int row_off;   // offset of the weight row in the LDS image
+  int g_bits;    // the gradient value's bit pattern
 };
 
 // which (type, first message, message count) piece workgroup `t` works on
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(RD_THREADS, 1) void routed_dgrad_kernel(
         if (set) {
           RdPair pr;
           pr.row_off = (lane + 64 * j) * NOUT;
-          pr.g = gq_g[p][j];
+          pr.g_bits = __builtin_bit_cast(int, gq_g[p][j]);
           mine[total + pos] = pr;
         }
         total += __popcll(m);
@@ -193,13 +193,17 @@ __global__ __launch_bounds__(RD_THREADS, 1) void routed_dgrad_kernel(
       if (lane < 3) {
         RdPair z;
         z.row_off = 0;
-        z.g = 0.f;
+        z.g_bits = 0;
         mine[total + lane] = z;
       }
+      // the list is written by some lanes and read back by all: same wave, so program order + this fence is the ordering
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       // (2) multiply: four non-zeros per trip; the pair reads are wave-uniform (LDS broadcast), two pairs per 16-byte read
 #pragma unroll 2  // (4 runs into the 128-register cap of a 16-wave workgroup and spills)
       for (int i = 0; i < total; i += 4) {
-        RdPair pr[4];
+        struct { int row_off; float g; } pr[4];
         const int4 lo = *reinterpret_cast<const int4*>(mine + i), hi = *reinterpret_cast<const int4*>(mine + i + 2);
         pr[0].row_off = lo.x; pr[0].g = __builtin_bit_cast(float, lo.y);
         pr[1].row_off = lo.z; pr[1].g = __builtin_bit_cast(float, lo.w);
@@ -258,11 +262,9 @@ int rd_launch(const float* gq, int ld_gq, const int* msg_src, const int* msg_tgt
               const int* type_ptr, int T, const float* wt, int E, float* g_a, int ld_ga, RdOut out, hipStream_t st) {
   constexpr int NOUT = 64 * OPL, Dm = 64 * NG;
   const size_t lds = (size_t)Dm * NOUT * sizeof(float) + (size_t)RD_WAVES * (Dm + 4) * sizeof(RdPair);
-  static bool attr = false;
-  if (!attr) {
+  {  // per device, not per process: set on every launch (a host-side table write)
     hipError_t e = hipFuncSetAttribute((const void*)routed_dgrad_kernel<OPL, NG, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
   }
   // one workgroup per CU is resident (LDS): two rounds of pieces; every type adds at most one short piece
   const int ncu = bl_num_cus();
@@ -292,7 +294,10 @@ int rd_dispatch(const float* gq, int ld_gq, const int* msg_src, const int* msg_t
 
 // 1 if the vector form handles (Dm, K2 = 2 Din): W[t]^T must fit the 128 KB LDS block in one piece
 extern "C" int32_t bl_routed_dgrad_vec_ok(int32_t Dm, int32_t K2) {
-  return (Dm == 64 || Dm == 128) && (K2 == 128 || K2 == 256) && Dm * K2 <= 32768;
+  if (!((Dm == 64 || Dm == 128) && (K2 == 128 || K2 == 256) && Dm * K2 <= 32768)) return 0;
+  // W[t]^T (Dm x K2 floats) + the per-wave non-zero lists must fit what this device lets one workgroup declare
+  const size_t lds = (size_t)Dm * K2 * sizeof(float) + (size_t)RD_WAVES * (Dm + 4) * sizeof(RdPair);
+  return (size_t)bl_max_lds_per_block() >= lds;
 }
 
 extern "C" int bl_routed_dgrad_vec(const float* gq, int32_t ld_gq, const int32_t* msg_tgt, const uint32_t* win_bits, int32_t ld_bits,

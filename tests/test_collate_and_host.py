@@ -485,6 +485,19 @@ def test_trainer_epoch_loop_with_loader_processes_on_cpu(tmp_path, monkeypatch):
     while any(p.is_alive() for p in pool._procs) and _time.monotonic() < deadline:
         _time.sleep(0.05)
     assert not any(p.is_alive() for p in pool._procs)
+    # the order train() really runs: prestart (next epoch) -> validation -> training.  Validation -- over another dataset
+    # object or over the very same one -- must neither consume nor close the pool; the training epoch then reuses it.
+    ds_val = ShardDataset(str(tmp_path), shuffle=False)
+    for val in (ds_val, ds):
+        trainer._prestart_loaders(ds, 3, True)
+        pool = trainer._prestarted[2]
+        trainer.neural_module.graphs = 0
+        trainer._run_validation(val, 2, float("inf"), torch.device("cpu"), True, False)
+        assert trainer.neural_module.graphs == 30
+        assert trainer._prestarted is not None and trainer._prestarted[2] is pool and not pool._closed
+        trainer.neural_module.graphs = 0
+        trainer._run_training(ds, 3, torch.device("cpu"), FakeOpt(), None, True)
+        assert trainer.neural_module.graphs == 30 and trainer._prestarted is None and pool._finished
     trainer._prestart_loaders(ds, 2, True)
     pool = trainer._prestarted[2]
     trainer._drop_prestarted_pool()

@@ -262,6 +262,24 @@ def _bucket_worker(rank, world, port, out_dir):
                         hip_ops._notify_backward_launched(tuple(opt.params[1:3]))
             opt.step_data_parallel(B)
         results[mode] = (opt.flat_param.clone(), opt.flat_grad.clone(), opt.tail.clone(), opt.step_count)
+        if mode == "buckets":
+            # rank 0's backward "raises" after one layer has reported: abort_data_parallel_step disarms the callback and
+            # completes the step's plan, so rank 1 (which steps normally) is not left hanging; the next step runs as usual
+            from buglab.models import hip_ops
+
+            opt.zero_grad()
+            opt.begin_data_parallel_step(2)
+            hip_ops._notify_backward_launched(tuple(opt.params[3:5]))
+            if rank == 0:
+                opt.abort_data_parallel_step()
+                assert hip_ops.GRAD_READY_CALLBACK is None and opt._armed_B is None and opt._works == []
+                hip_ops._notify_backward_launched(tuple(opt.params[1:3]))  # a later backward: no collective is issued
+            else:
+                hip_ops._notify_backward_launched(tuple(opt.params[1:3]))
+                opt.step_data_parallel(2)
+            opt.zero_grad()
+            opt.begin_data_parallel_step(1)
+            opt.step_data_parallel(1)
     assert torch.equal(results["plain"][0], results["buckets"][0]), "bucketed reduction must give bit-identical parameters"
     assert torch.equal(results["plain"][1], results["buckets"][1]) and torch.equal(results["plain"][2], results["buckets"][2])
     torch.save(results["buckets"][0], os.path.join(out_dir, f"b{rank}.pt"))
