@@ -159,6 +159,13 @@ int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_pa
                             int32_t G, int32_t M, int32_t N, int32_t K, float* gw, int64_t gw_group_stride, int32_t ld_gw,
                             void* stream);
 
+/* Tile of the two bf16x6 weight-gradient GEMMs above.  256 (default): a 256 x 128 output tile per 8-wave workgroup with
+ * double-buffered stages wherever K is a multiple of 256 and every source width a multiple of 128 -- the routed operand is
+ * staged once per message instead of once per 128-feature half; 128: the 128 x 128 tile everywhere.  Same results either
+ * way (same products, same per-tile accumulation order); a measurement switch (tools/gemm_bench.py).  Returns the
+ * previous setting. */
+int32_t bl_set_wgrad_tile(int32_t rows);
+
 /* bf16x6 form of bl_gemm_wgrad (below), no routing: gw[g] += rows(a)^T . g_packed[g_idx[r] or r, 0:N] -- the weight
  * gradient of a plain Linear (the dense node update) from packed operands */
 int bl_gemm_wgrad_x6(const bl_rows_packed_t* a, const uint16_t* g_packed, const int32_t* g_idx, const int32_t* group_ptr,

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "bl_version": ([], ctypes.c_int),
     "bl_set_deterministic": ([c_int32], None),
     "bl_get_deterministic": ([], c_int32),
+    "bl_set_wgrad_tile": ([c_int32], c_int32),
     "bl_last_error": ([], ctypes.c_char_p),
     "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
@@ -848,6 +849,11 @@ def set_deterministic(on: bool = True) -> None:
     occurrences in one chunk); this call only reaches the collators of this process."""
     load_library().bl_set_deterministic(1 if on else 0)
     os.environ["BL_DETERMINISTIC"] = "1" if on else "0"
+
+
+def set_wgrad_tile(rows: int) -> int:
+    """256 (default): wide weight-gradient tile where it applies; 128: the 128 x 128 tile everywhere.  -> previous value."""
+    return int(load_library().bl_set_wgrad_tile(int(rows)))
 
 
 def deterministic() -> bool:

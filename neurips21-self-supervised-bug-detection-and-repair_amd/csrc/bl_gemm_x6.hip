@@ -533,6 +533,310 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
   bl_ordered_leave(ctr, turn);
 }
 
+// ---- weight-gradient GEMM, wide tile ---------------------------------------------------------------
+// Same contraction, 256 (features of A) x 128 (channels) per workgroup: 8 waves, each the 64 x 64 block of the kernel above.
+// What the PMC counters of the 128 x 128 kernel say (profiles/r04b_wgrad_pmc.json): its matrix pipe is 39 % busy with every
+// operand L2-resident or not (0.254 vs 0.269 ms), its waves spend a quarter of their cycles issuing ~6 non-MFMA instructions
+// per MFMA (staging: address arithmetic, routing masks, zero-selects, LDS stores) and half of them stalled -- the two waves
+// of a SIMD run their staging phases and their MFMA phases at the same time more often than not.  So this kernel
+//  * stages the routed operand -- the packed node gradient of the messages' targets -- ONCE per message instead of once
+//    per 128-feature half (a quarter less staging work per MFMA),
+//  * owns the CU (one 512-thread workgroup, 2 x 72 KB of LDS: double-buffered stages, ONE barrier per 32-message stage),
+//  * and runs its two wave groups in opposite phases: waves 0-3 do the stage's 48 MFMAs first and their share of the
+//    staging (LDS stores of stage k+1, global loads of stage k+2) after them, waves 4-7 -- the SIMDs' second waves -- do
+//    their staging first and the MFMAs after it, so that a SIMD's matrix pipe sees one wave's MFMA stream while the other
+//    wave stages.
+// LDS image of a stage: [operand: A half 0, A half 1, B][plane][message (32)][128 features], rows of 256 B without padding;
+// the four 64-byte granules of a row are XOR-swizzled with (message & 3), which puts the four message rows of a
+// transposing read's [4 messages][32 features] block on four different bank groups (conflict-free, SQ_LDS_BANK_CONFLICT 0)
+// and keeps the 16-byte stores of 8 consecutive lanes on 32 different banks.
+// Used when K is a multiple of 256, every source's width a multiple of 128 and the operands are either all gathered or
+// all direct (the message weight gradients of every shipped configuration); everything else runs on the kernel above.
+// A rows past the end of the chunk are NOT zeroed: their B rows are (the keep mask), and the clamped row they load is a
+// real message of the chunk, so a non-finite value there is in the exact result as well.
+#define WW_ROW 128                      // shorts per LDS message row
+#define WW_PLANE (32 * WW_ROW)          // shorts per plane (32 messages)
+#define WW_OPER (3 * WW_PLANE)          // shorts per operand image
+#define WW_STAGE (3 * WW_OPER)          // shorts per stage (A half 0, A half 1, B): 36 864 shorts = 72 KB
+
+__device__ __forceinline__ bf16x8 tr_frag_w(const short* p) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * WW_ROW));  // messages +4: same (message & 3)
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// routing byte -> AND-masks, three VALU per dword (two sign-extending bit-field extracts + one bit-field insert)
+__device__ __forceinline__ uint4 keep_from_bits_bfi(uint32_t b) {
+  uint4 k;
+#define KB_(i_) (uint32_t)__builtin_amdgcn_sbfe(b, i_, 1)
+  k.x = (KB_(0) & 0x0000FFFFu) | (KB_(1) & 0xFFFF0000u);
+  k.y = (KB_(2) & 0x0000FFFFu) | (KB_(3) & 0xFFFF0000u);
+  k.z = (KB_(4) & 0x0000FFFFu) | (KB_(5) & 0xFFFF0000u);
+  k.w = (KB_(6) & 0x0000FFFFu) | (KB_(7) & 0xFFFF0000u);
+#undef KB_
+  return k;
+}
+
+#ifdef BL_TRACE_WGRAD
+// experiment build only (tools/experiments/wgrad_trace.py): shader-clock stamps of one workgroup's waves
+__device__ unsigned long long* g_ww_trace = nullptr;
+__device__ int g_ww_trace_wg = -1;
+extern "C" int bl_debug_wgrad_trace(unsigned long long* buf, int wg) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ww_trace), &buf, sizeof(buf)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ww_trace_wg), &wg, sizeof(wg)) != hipSuccess) return -1;
+  return 0;
+}
+#define WW_TR(kt_, i_)                                                                                          \
+  if (tr_on && (kt_) < 64 && lane == 0) g_ww_trace[((size_t)wave * 64 + (kt_)) * 8 + (i_)] = __builtin_readcyclecounter();
+#else
+#define WW_TR(kt_, i_)
+#endif
+
+// GATHER: every operand row is addressed through an index array (idx0/1/2, g_idx all non-null); otherwise none is
+template <bool ROUTED, bool GATHER>
+__global__ __launch_bounds__(512) void gemm_wgrad_x6_wide_kernel(
+    const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
+    const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
+    int koff1, int koff2, int nsrc, const uint4* __restrict__ gp, const int* __restrict__ g_idx,
+    const uint32_t* __restrict__ win_bits, int ld_bits, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G,
+    int M, int N, int K, int kchunk, float* __restrict__ gw_base, long long strideW, int ldw, int ntiles_n, int xcd_remap,
+    unsigned* __restrict__ order_ctr) {
+  __shared__ __attribute__((aligned(16))) short Ls[2 * WW_STAGE];  // the ONE LDS object of this kernel (144 KB)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int g, e0, ne, tile_y;
+  if (!x6_locate(group_ptr, G, M, kchunk, xcd_remap, tile_y, g, e0, ne)) return;
+  const int e1 = e0 + ne;
+  const int i0 = (tile_y / ntiles_n) * 256;
+  const int n0 = (tile_y % ntiles_n) * XBN;
+  const int wsel = group_w ? group_w[g] : g;
+
+  // loader: thread -> (message tid >> 4 of the stage, 16-byte chunk tid & 15 = 8 features) of each of the three operand rows
+  const int fg = tid & 15, msg = tid >> 4;
+  const int nn = n0 + 8 * fg;
+  const bool b_ok = nn < N;
+  const int nnc = b_ok ? nn : 0;
+  // per 128-feature half of the A tile: source (wave-uniform: a half lies inside one source), row length, this thread's chunk.
+  // Row offsets are 32-bit in units of 16 bytes (a packed operand below 64 GB).
+#define WW_HALF(h_, src_, idx_, rowq_, planeq_, colq_)                                                                 \
+  const int fi##h_ = i0 + 128 * h_;                                                                                    \
+  const int aj##h_ = (nsrc > 2 && fi##h_ >= koff2) ? 2 : ((nsrc > 1 && fi##h_ >= koff1) ? 1 : 0);                      \
+  const uint4* __restrict__ src_ = aj##h_ == 0 ? xp0 : (aj##h_ == 1 ? xp1 : xp2);                                      \
+  const int* __restrict__ idx_ = aj##h_ == 0 ? idx0 : (aj##h_ == 1 ? idx1 : idx2);                                     \
+  const uint32_t planeq_ = (uint32_t)((aj##h_ == 0 ? w0 : (aj##h_ == 1 ? w1 : w2)) >> 3); /* uint4 per plane */        \
+  const uint32_t rowq_ = 3u * planeq_;                                                                                 \
+  const uint32_t colq_ = (uint32_t)((fi##h_ - (aj##h_ == 0 ? 0 : (aj##h_ == 1 ? koff1 : koff2))) >> 3) + (uint32_t)fg;
+  WW_HALF(0, asrc0, aidx0, arowq0, aplq0, acolq0)
+  WW_HALF(1, asrc1, aidx1, arowq1, aplq1, acolq1)
+  const uint32_t gplq = (uint32_t)(N >> 3), growq = 3u * gplq, gcolq = (uint32_t)(nnc >> 3);
+  const uint32_t* __restrict__ mbase = ROUTED ? win_bits + (nnc >> 5) : nullptr;
+  const int mshift = nnc & 31;
+  // this thread's slot in an operand plane (shorts): row `msg`, granule (fg >> 2) ^ (msg & 3), chunk fg & 3
+  const int slot = msg * WW_ROW + ((((fg >> 2) ^ (msg & 3)) << 2) | (fg & 3)) * 8;
+
+  // Two register sets (A, B) of staged operands, alternating per stage: set X receives stage k+2 while set Y, loaded one
+  // iteration earlier, is masked and stored to LDS as stage k+1.  (scalars, not arrays: hipcc sends small arrays that are
+  // written under control flow to scratch)
+  uint4 ra00A, ra01A, ra02A, ra10A, ra11A, ra12A, rb0A, rb1A, rb2A, ra00B, ra01B, ra02B, ra10B, ra11B, ra12B, rb0B, rb1B, rb2B;
+  uint32_t mkA = 0u, mkB = 0u;
+  uint32_t ar0A, ar1A, grA, mrA, ar0B, ar1B, grB, mrB;  // gathered rows / message id of a stage still to be loaded
+
+  // rows of the stage that starts at message k0_ -> index set S_   (past the end of the chunk: the chunk's first message --
+  // a valid row whose B row gets a zero keep mask)
+#define WW_IDX(k0_, S_)                                      \
+  {                                                          \
+    const int e_ = (k0_) + msg;                              \
+    const uint32_t ec_ = (uint32_t)(e_ < e1 ? e_ : e0);      \
+    ar0##S_ = GATHER ? (uint32_t)aidx0[ec_] : ec_;           \
+    ar1##S_ = GATHER ? (uint32_t)aidx1[ec_] : ec_;           \
+    gr##S_ = GATHER ? (uint32_t)g_idx[ec_] : ec_;            \
+    mr##S_ = ec_;                                            \
+  }
+#define WW_LOAD_A0(S_)                                       \
+  {                                                          \
+    const uint32_t o_ = ar0##S_ * arowq0 + acolq0;           \
+    ra00##S_ = asrc0[o_];                                    \
+    ra01##S_ = asrc0[o_ + aplq0];                            \
+    ra02##S_ = asrc0[o_ + 2u * aplq0];                       \
+  }
+#define WW_LOAD_A1(S_)                                       \
+  {                                                          \
+    const uint32_t o_ = ar1##S_ * arowq1 + acolq1;           \
+    ra10##S_ = asrc1[o_];                                    \
+    ra11##S_ = asrc1[o_ + aplq1];                            \
+    ra12##S_ = asrc1[o_ + 2u * aplq1];                       \
+  }
+#define WW_LOAD_B(S_)                                                    \
+  {                                                                      \
+    const uint32_t o_ = gr##S_ * growq + gcolq;                          \
+    rb0##S_ = gp[o_];                                                    \
+    rb1##S_ = gp[o_ + gplq];                                             \
+    rb2##S_ = gp[o_ + 2u * gplq];                                        \
+    if (ROUTED) mk##S_ = mbase[(size_t)mr##S_ * (uint32_t)ld_bits];      \
+  }
+#define WW_ST1(off_, v_) *reinterpret_cast<uint4*>(wr_ + (off_)) = (v_);
+#define WW_STB(off_, v_)                                                 \
+  {                                                                      \
+    uint4 b_ = (v_);                                                     \
+    b_.x &= keep_.x; b_.y &= keep_.y; b_.z &= keep_.z; b_.w &= keep_.w;  \
+    *reinterpret_cast<uint4*>(wr_ + 2 * WW_OPER + (off_)) = b_;          \
+  }
+#define WW_KEEP(S_, k0_)                                                                             \
+  uint4 keep_ = ROUTED ? keep_from_bits_bfi(mk##S_ >> mshift) : make_uint4(~0u, ~0u, ~0u, ~0u);      \
+  if (!((k0_) + msg < e1 && b_ok)) keep_ = make_uint4(0u, 0u, 0u, 0u);
+#define WW_STORE_A0(S_) WW_ST1(0, ra00##S_) WW_ST1(WW_PLANE, ra01##S_) WW_ST1(2 * WW_PLANE, ra02##S_)
+#define WW_STORE_A1(S_) WW_ST1(WW_OPER, ra10##S_) WW_ST1(WW_OPER + WW_PLANE, ra11##S_) WW_ST1(WW_OPER + 2 * WW_PLANE, ra12##S_)
+#define WW_STORE_B(S_) WW_STB(0, rb0##S_) WW_STB(WW_PLANE, rb1##S_) WW_STB(2 * WW_PLANE, rb2##S_)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  // wave -> (A half, 64-feature block of the half, 64-channel block of B)
+  const int wq = wave & 3, wn = wave >> 2, li = lane & 31, half = lane >> 5;
+  const int ahalf = wq >> 1, afb = (wq & 1) * 64, bfb = wn * 64;
+  // transposing read of this lane: message (grp >> 1) * 8 + (l16 >> 2) (+ 4, + 16 s), features base + 32 t + 16 (grp & 1) + 4 (l16 & 3)
+  const int l16 = lane & 15, grp = lane >> 4;
+  const int tr_row = ((grp >> 1) * 8 + (l16 >> 2)) * WW_ROW;
+  const int tr_in = (grp & 1) * 16 + 4 * (l16 & 3);  // inside the 32-feature granule
+  const int sw = (l16 >> 2) & 3;                      // (message & 3) of every row this lane reads
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    a_off[t] = ahalf * WW_OPER + tr_row + ((((afb >> 5) + t) ^ sw) << 5) + tr_in;
+    b_off[t] = 2 * WW_OPER + tr_row + ((((bfb >> 5) + t) ^ sw) << 5) + tr_in;
+  }
+  const int nk = (ne + 31) / 32;
+  const int nk2 = (nk + 1) & ~1;  // the loop runs stage pairs; a phantom last stage has an all-zero B image
+
+#define WW_FRAGS(rd_, s_)                                                                              \
+  _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int p = 0; p < 3; ++p) {        \
+    af[t][p] = tr_frag_w((rd_) + (s_) * 16 * WW_ROW + a_off[t] + p * WW_PLANE);                        \
+    bf[t][p] = tr_frag_w((rd_) + (s_) * 16 * WW_ROW + b_off[t] + p * WW_PLANE);                        \
+  }
+  // One loop iteration = one 32-message stage, straight-line (no branch: loads past the chunk's end are clamped to valid
+  // rows, stores past it fill a buffer nobody reads), the staging of the NEXT stages cut in pieces and placed between the
+  // six-MFMA-term groups of this stage, so that a wave never leaves the matrix pipe for a whole staging phase: in the
+  // phase-structured form (profiles/r04c_trace2.log) a stage took ~7 000 cycles of which each wave spent ~3 400 staging
+  // (500-1 000 waiting for its loads, 1 100 on masks + LDS stores, 1 500-1 800 on address arithmetic + issuing 13 loads into
+  // a busy texture path) with the matrix pipe idle for half of the stage.
+  //   X: the register set that receives stage KT + 2 (rows from index set X, loaded one iteration ago)
+  //   Y: the set that holds stage KT + 1 (loaded one iteration ago), masked and stored to the other LDS buffer now;
+  //      index set Y receives the rows of stage KT + 3
+// scheduling fence: VALU, SALU and LDS reads may move across it; MFMAs, global loads and LDS stores may not -- the staging pieces
+// stay where they are written (left alone, hipcc sinks the loads to the end of the iteration and hoists the stores)
+#define WW_PIN() __builtin_amdgcn_sched_barrier(0x106);
+#ifndef BL_WW_ABLATE
+#define BL_WW_ABLATE 0  // experiment builds (tools/experiments/wgrad_trace.py): 1 no staging in the loop, 2 no MFMAs, 4 fragments read once
+#endif
+#if BL_WW_ABLATE & 1
+#define WW_S(x_)
+#else
+#define WW_S(x_) x_
+#endif
+#if BL_WW_ABLATE & 2
+#define WW_T(pa_, pb_) _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) { asm volatile("" ::"v"(af[t_][pa_]), "v"(bf[t_][pb_])); }
+#else
+#define WW_T(pa_, pb_) WX6_TERM(pa_, pb_)
+#endif
+#if BL_WW_ABLATE & 4
+#define WW_F(rd_, s_)
+#else
+#define WW_F(rd_, s_) WW_FRAGS(rd_, s_)
+#endif
+#define WW_ITER(X, Y, KT)                                                                              \
+  {                                                                                                    \
+    const int kt_ = (KT);                                                                              \
+    const short* rd_ = Ls + (kt_ & 1) * WW_STAGE;                                                      \
+    short* wr_ = Ls + ((kt_ + 1) & 1) * WW_STAGE + slot;                                               \
+    WW_TR(kt_, 0)                                                                                      \
+    WW_F(rd_, 0)                                                                                       \
+    WW_S(WW_IDX(e0 + (kt_ + 3) * 32, Y))                                                               \
+    WW_PIN()                                                                                           \
+    WW_T(1, 1)                                                                                         \
+    WW_PIN()                                                                                           \
+    WW_S(WW_LOAD_A0(X))                                                                                \
+    WW_PIN()                                                                                           \
+    WW_T(2, 0)                                                                                         \
+    WW_PIN()                                                                                           \
+    WW_S(WW_LOAD_A1(X))                                                                                \
+    WW_PIN()                                                                                           \
+    WW_T(0, 2)                                                                                         \
+    WW_PIN()                                                                                           \
+    WW_S(WW_LOAD_B(X))                                                                                 \
+    WW_PIN()                                                                                           \
+    WW_T(1, 0)                                                                                         \
+    WW_S(WW_KEEP(Y, e0 + (kt_ + 1) * 32))                                                              \
+    WW_T(0, 1)                                                                                         \
+    WW_PIN()                                                                                           \
+    WW_S(WW_STORE_A0(Y))                                                                               \
+    WW_PIN()                                                                                           \
+    WW_T(0, 0)                                                                                         \
+    WW_TR(kt_, 1)                                                                                      \
+    WW_F(rd_, 1)                                                                                       \
+    WW_T(1, 1)                                                                                         \
+    WW_PIN()                                                                                           \
+    WW_S(WW_STORE_A1(Y))                                                                               \
+    WW_PIN()                                                                                           \
+    WW_T(2, 0)                                                                                         \
+    WW_PIN()                                                                                           \
+    WW_S(WW_STORE_B(Y))                                                                                \
+    WW_PIN()                                                                                           \
+    WW_T(0, 2) WW_T(1, 0) WW_T(0, 1) WW_T(0, 0)                                                        \
+    WW_TR(kt_, 2)                                                                                      \
+    __syncthreads();                                                                                   \
+    WW_TR(kt_, 5)                                                                                      \
+  }
+
+#ifdef BL_TRACE_WGRAD
+  const bool tr_on = g_ww_trace != nullptr && (int)blockIdx.x == g_ww_trace_wg && blockIdx.y == 0;
+#endif
+  // prologue: stage 0 through set A into buffer 0, stage 1 into set B, rows of stage 2 into index set A
+  WW_IDX(e0, A)
+  WW_LOAD_A0(A) WW_LOAD_A1(A) WW_LOAD_B(A)
+  WW_IDX(e0 + 32, B)
+  {
+    short* wr_ = Ls + slot;
+    WW_KEEP(A, e0)
+    WW_STORE_A0(A) WW_STORE_A1(A) WW_STORE_B(A)
+  }
+  WW_LOAD_A0(B) WW_LOAD_A1(B) WW_LOAD_B(B)
+  WW_IDX(e0 + 64, A)
+  __syncthreads();
+  bf16x8 af[2][3], bf[2][3];
+#if BL_WW_ABLATE & 4
+  WW_FRAGS(Ls, 0)
+#endif
+  for (int kt = 0; kt < nk2; kt += 2) {
+    WW_ITER(A, B, kt)
+    WW_ITER(B, A, kt + 1)
+  }
+
+  float* __restrict__ gw = gw_base + (long long)wsel * strideW;
+  unsigned* ctr = order_ctr ? order_ctr + (size_t)g * gridDim.y + tile_y : nullptr;
+  const unsigned turn = (unsigned)((e0 - (group_ptr ? group_ptr[g] : 0)) / kchunk);
+  bl_ordered_enter(ctr, turn);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int n = n0 + bfb + tj * 32 + li;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = i0 + 128 * ahalf + afb + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        unsafeAtomicAdd(&gw[(size_t)f * ldw + n], acc[ti][tj][r]);  // (K is a multiple of 256: every row of the tile exists)
+      }
+    }
+  bl_ordered_leave(ctr, turn);
+}
+
 // ================================================================================================
 extern "C" int bl_pack_bf16x3(const float* x, int32_t ld, int64_t R, int32_t D, uint16_t* out, void* stream) {
   if (R == 0) return BL_OK;
@@ -635,6 +939,8 @@ int gemm_rows_x6_impl(const char* who, const bl_rows_packed_t* a, const uint32_t
   return BL_OK;
 }
 
+bool g_wgrad_wide = true;  // bl_set_wgrad_tile: A/B switch between the 256 x 128 and the 128 x 128 weight-gradient tile
+
 template <bool ROUTED>
 int wgrad_x6_resident() {
   static int resident = 0;
@@ -664,10 +970,19 @@ int gemm_wgrad_x6_impl(const char* who, const bl_rows_packed_t* a, const uint16_
                "%s: N a multiple of 32 and aligned pointers required", who);
   const bool routed = win_bits != nullptr;
   BL_CHECK_ARG(!routed || (g_idx && ld_bits * 32 >= N), "%s: the routed form needs g_idx and ld_bits >= N / 32", who);
+  // the 256 x 128 tile (8 waves, routed operand staged once per message) when every 128-feature half lies in one source
+  bool wide = g_wgrad_wide && K % 256 == 0;
+  int nidx = g_idx ? 1 : 0;
+  for (int j = 0; j < a->nsrc; ++j) {
+    wide = wide && a->width[j] % 128 == 0;
+    nidx += a->idx[j] ? 1 : 0;
+  }
+  const bool gather = nidx == a->nsrc + 1;
+  wide = wide && (gather || nidx == 0) && (gather || !routed);
   // rows reduced by one workgroup: an integer number of rounds of resident workgroups (see bl_gemm.hip)
-  const int resident = routed ? wgrad_x6_resident<true>() : wgrad_x6_resident<false>();
+  const int resident = wide ? bl_num_cus() : (routed ? wgrad_x6_resident<true>() : wgrad_x6_resident<false>());
   const int ntiles_n = (N + XBN - 1) / XBN;
-  const int ntiles_all = ((K + XBM - 1) / XBM) * ntiles_n;
+  const int ntiles_all = ((K + (wide ? 255 : XBM - 1)) / (wide ? 256 : XBM)) * ntiles_n;
   const int extra = (group_ptr ? G : 0) * ntiles_all;
   int kchunk = 256;
   for (int rounds = 1; rounds <= 64; ++rounds) {
@@ -689,7 +1004,13 @@ int gemm_wgrad_x6_impl(const char* who, const bl_rows_packed_t* a, const uint16_
       a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0], a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1],   \
       koff[2], a->nsrc, reinterpret_cast<const uint4*>(g_packed), g_idx, win_bits, ld_bits, group_ptr, group_w, G, M, N, K,     \
       kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n, xcd, order_ctr
-  if (routed)
+  if (wide && routed)
+    hipLaunchKernelGGL((gemm_wgrad_x6_wide_kernel<true, true>), grid, dim3(512), 0, (hipStream_t)stream, WX6_ARGS);
+  else if (wide && gather)
+    hipLaunchKernelGGL((gemm_wgrad_x6_wide_kernel<false, true>), grid, dim3(512), 0, (hipStream_t)stream, WX6_ARGS);
+  else if (wide)
+    hipLaunchKernelGGL((gemm_wgrad_x6_wide_kernel<false, false>), grid, dim3(512), 0, (hipStream_t)stream, WX6_ARGS);
+  else if (routed)
     hipLaunchKernelGGL((gemm_wgrad_x6_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, WX6_ARGS);
   else
     hipLaunchKernelGGL((gemm_wgrad_x6_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, WX6_ARGS);
@@ -697,6 +1018,14 @@ int gemm_wgrad_x6_impl(const char* who, const bl_rows_packed_t* a, const uint16_
   return BL_OK;
 }
 }  // namespace
+
+// 256: the wide (256 x 128, 8-wave) weight-gradient tile where it applies (default); 128: the 128 x 128 tile everywhere.
+// A measurement switch (tools/gemm_bench.py); returns the previous setting.
+extern "C" int32_t bl_set_wgrad_tile(int32_t rows) {
+  const int32_t prev = g_wgrad_wide ? 256 : 128;
+  g_wgrad_wide = rows != 128;
+  return prev;
+}
 
 extern "C" int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                                int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G,

@@ -371,7 +371,7 @@ def test_gemm_rows_bf16x6_is_fp32_accurate(ops, Din, Dm, sizes):
     assert err < 2e-5 and err < 4 * err32 + 1e-6, (float(err), float(err32))
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 256, 64), (130, 64, 96)])
+@pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 256, 64), (130, 64, 96), (2500, 256, 160)])
 def test_dense_bf16x6_gemms_match_fp64(ops, M, K, N):
     """The dense node update on the bf16 matrix cores: bl_gemm_rows_x6_epi (bias + tanh + counter-hash dropout epilogue, the
     SAME dropout counter as the exact-fp32 row GEMM), the plain input-gradient form and bl_gemm_wgrad_x6 (no routing)."""
@@ -427,7 +427,8 @@ def test_segment_max_and_act_bwd_packed_outputs(ops):
         assert float((g - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-7, k  # (routing near-ties may flip: see test_hip_parity)
 
 
-@pytest.mark.parametrize("Din,Dm,sizes", [(32, 64, [130, 0, 1, 700, 64]), (128, 128, [2100, 5, 300]), (64, 256, [129, 128, 1500])])
+@pytest.mark.parametrize("Din,Dm,sizes", [(32, 64, [130, 0, 1, 700, 64]), (128, 128, [2100, 5, 300]), (64, 256, [129, 128, 1500]),
+                                           (256, 256, [700, 33, 0, 1]), (128, 96, [31, 2000])])
 def test_routed_gemms_bf16x6_match_fp64(ops, Din, Dm, sizes):
     """bf16x6 input-gradient and weight-gradient GEMMs of the max-aggregated messages (winner-masked
     operand, transposing LDS reads in the weight gradient) against an fp64 reference."""
@@ -468,6 +469,17 @@ def test_routed_gemms_bf16x6_match_fp64(ops, Din, Dm, sizes):
     scale = float(ref_dW.abs().max())
     err, err32 = float((gw.cpu().double() - ref_dW).abs().max()), float((gw32.cpu().double() - ref_dW).abs().max())
     assert err < 2e-6 * max(scale, 1.0) * 4 and err < 4 * err32 + 1e-6 * scale, (err, err32, scale)
+    # the 128 x 128 tile and the wide 256 x 128 tile (taken above when 2 Din is a multiple of 256 and Din of 128) do the same
+    # products in the same order per tile: equal up to the order of the chunks' atomic adds
+    prev = ops.set_wgrad_tile(128)
+    try:
+        gw128 = torch.zeros_like(gw)
+        ops.gemm_wgrad_routed_x6([(hp, d_src, Din), (hp, d_tgt, Din)], gqp, d_tgt, d_bits, E, Dm, gw128, gw_group_stride=2 * Din * Dm,
+                                 group_ptr=d_ptr, G=T)
+    finally:
+        ops.set_wgrad_tile(prev)
+    assert prev == 256 and float((gw128 - gw).abs().max()) < 1e-5 * max(scale, 1.0)
+    assert float((gw128.cpu().double() - ref_dW).abs().max()) < 2e-6 * max(scale, 1.0) * 4
     dA = ops.gemm_rows_x6([(gqp, d_tgt, Dm)], ops.pack_weights_x6(_dev(W), False), E, 2 * Din, group_ptr=d_ptr, G=T, win_bits=d_bits)
     assert float((dA.cpu().double() - ref_dA).abs().max()) < 2e-5
 
@@ -533,7 +545,8 @@ def test_routed_input_gradient_from_the_nonzeros_matches_fp64(ops, Din, Dm, size
         order = np.argsort(src, kind="stable").astype(np.int32)
         sptr = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=N))]).astype(np.int32)
         lib = ops.load_library()
-        ops._check(lib.bl_mp_scatter_grad(rows.data_ptr(), rows.stride(0), _dev(sptr).data_ptr(), _dev(order).data_ptr(), None, None, N, Din,
+        d_sptr, d_order = _dev(sptr), _dev(order)  # (named: a temporary's memory may be handed to the next allocation before the launch)
+        ops._check(lib.bl_mp_scatter_grad(rows.data_ptr(), rows.stride(0), d_sptr.data_ptr(), d_order.data_ptr(), None, None, N, Din,
                                           1, lo.data_ptr(), lo.stride(0), None, ops._stream()), "bl_mp_scatter_grad")
         assert float((lo.cpu().double() - ref_h).abs().max()) < tol
 

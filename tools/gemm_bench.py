@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--dm", type=int, default=128)
     ap.add_argument("--types", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=5, help="interleaved measurement rounds per variant")
     ap.add_argument("--which", default="fwd,nk,wgrad")
     ap.add_argument("--order", default="type", help="type: type-major; chunk: (graph chunk, type)-major")
     ap.add_argument("--chunk", type=int, default=1, help="graphs per chunk")
@@ -89,22 +90,37 @@ def main():
     gw6 = torch.zeros_like(W)
     fns["wgrad_routed"] = lambda: ops.gemm_wgrad_routed([(h, src), (h, tgt)], gq, tgt, arg_real, E, Dm, gw, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T)
     fns["wgrad_x6"] = lambda: ops.gemm_wgrad_routed_x6([(hp, src, Din), (hp, tgt, Din)], gqp, tgt, bits_real, E, Dm, gw6, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t)
+    def wgrad_x6_tile128():
+        prev = ops.set_wgrad_tile(128)
+        try:
+            fns["wgrad_x6"]()
+        finally:
+            ops.set_wgrad_tile(prev)
+
+    fns["wgrad_x6_t128"] = wgrad_x6_tile128  # A/B: the 128 x 128 tile (wgrad_x6 = the default, wide where it applies)
     fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, group_ptr=ptr, G=T_groups, group_w=gw_t, win_bits=bits_real)
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
     fns["pack_wt"] = lambda: ops.pack_weights_x6(W, True)
-    for name in a.which.split(","):
-        f = fns[name]
-        for _ in range(2):
-            f()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            f()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.iters
-        print(f"{name:6s} E={E} Din={Din} Dm={Dm}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s  ({flop / ms / 1e9 / 157.3:.1%} of fp32 MFMA peak)", flush=True)
+    names = a.which.split(",")
+    times = {n: [] for n in names}
+    for rnd in range(a.rounds):  # interleaved rounds in ONE process: report median and min per variant
+        for name in names:
+            f = fns[name]
+            for _ in range(2 if rnd == 0 else 1):
+                f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            times[name].append(e0.elapsed_time(e1) / a.iters)
+    for name in names:
+        ts = sorted(times[name])
+        ms, mn = ts[len(ts) // 2], ts[0]
+        print(f"{name:14s} E={E} Din={Din} Dm={Dm}: median {ms:.3f} ms (min {mn:.3f})  {flop / ms / 1e9:.1f} TFLOP/s  "
+              f"({flop / ms / 1e9 / 416.7:.1%} of the bf16x6 peak, {flop / ms / 1e9 / 157.3:.1%} of fp32 MFMA peak)", flush=True)
 
 
 if __name__ == "__main__":
