@@ -290,6 +290,8 @@ def main():
     ap.add_argument("--serial", action="store_true", help="weight-gradient GEMMs on the main stream everywhere (no side-stream overlap): the run "
                     "whose rocprofv3 --kernel-trace --stats averages are the exclusive kernel times the roofline quotes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wgrad-kcap", type=int, default=0, help="A/B: rows per workgroup flush of the bf16x6 weight-gradient GEMMs "
+                    "(hip_ops.set_wgrad_kchunk_cap); 0 = the library's default")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce per step instead of layer-wise buckets behind backward")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under `also` (configs[2] shard, seq-great)")
     ap.add_argument("--no-predict", action="store_true", help="skip the forward-only passes after the timed training steps (profiling)")
@@ -326,6 +328,8 @@ def main():
     hip_ops.load_library()  # fail loudly if the HIP extension is missing
     if args.serial:
         hip_ops.USE_SIDE_STREAM = False
+    if args.wgrad_kcap:
+        hip_ops.set_wgrad_kchunk_cap(args.wgrad_kcap)
 
     def build_workload(a):
         """(module, minibatch, optimiser) of one configuration: resident synthetic minibatch, random-init weights."""

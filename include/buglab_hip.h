@@ -166,6 +166,11 @@ int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_pa
  * previous setting. */
 int32_t bl_set_wgrad_tile(int32_t rows);
 
+/* Most rows one workgroup of the two bf16x6 weight-gradient GEMMs above reduces before it adds its output tile into gw
+ * (fp32 atomics: one flush = one tile of them).  The chunk is the smallest one that fills an integer number of rounds of
+ * resident workgroups and stays <= the cap; rows < 256 are ignored.  Returns the previous cap. */
+int32_t bl_set_wgrad_kchunk_cap(int32_t rows);
+
 /* bf16x6 form of bl_gemm_wgrad (below), no routing: gw[g] += rows(a)^T . g_packed[g_idx[r] or r, 0:N] -- the weight
  * gradient of a plain Linear (the dense node update) from packed operands */
 int bl_gemm_wgrad_x6(const bl_rows_packed_t* a, const uint16_t* g_packed, const int32_t* g_idx, const int32_t* group_ptr,

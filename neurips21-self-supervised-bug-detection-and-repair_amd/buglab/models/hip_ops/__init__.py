@@ -65,6 +65,7 @@ _SIGNATURES = {
     "bl_set_deterministic": ([c_int32], None),
     "bl_get_deterministic": ([], c_int32),
     "bl_set_wgrad_tile": ([c_int32], c_int32),
+    "bl_set_wgrad_kchunk_cap": ([c_int32], c_int32),
     "bl_last_error": ([], ctypes.c_char_p),
     "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
@@ -854,6 +855,11 @@ def set_deterministic(on: bool = True) -> None:
 def set_wgrad_tile(rows: int) -> int:
     """256 (default): wide weight-gradient tile where it applies; 128: the 128 x 128 tile everywhere.  -> previous value."""
     return int(load_library().bl_set_wgrad_tile(int(rows)))
+
+
+def set_wgrad_kchunk_cap(rows: int) -> int:
+    """Most rows a workgroup of the bf16x6 weight-gradient GEMMs reduces per output-tile flush.  -> previous value."""
+    return int(load_library().bl_set_wgrad_kchunk_cap(int(rows)))
 
 
 def deterministic() -> bool:

@@ -940,6 +940,13 @@ int gemm_rows_x6_impl(const char* who, const bl_rows_packed_t* a, const uint32_t
 }
 
 bool g_wgrad_wide = true;  // bl_set_wgrad_tile: A/B switch between the 256 x 128 and the 128 x 128 weight-gradient tile
+// Largest number of rows one workgroup reduces before it flushes its output tile (bl_set_wgrad_kchunk_cap).  Every flush is
+// tile-size fp32 atomics, and the chip retires ~312 G of those per second whatever the addresses (tools/atomic_bench.py):
+// at c2's layer shape (E = 640 000, K = 256, N = 128) the 864-row chunks of the old cap (1024) were 97 MB = 24 M atomics per
+// launch, ~0.08 ms of a 0.25-ms kernel; the cap trades that against the balance of the last round of workgroups.  Measured
+// (profiles/r04e_kcap_*.log, same box): H = 128 layer 0.254 / 0.232 / 0.210 / 0.220 / 0.217 ms at 1024 / 2048 / 3072 / 4096 /
+// 8192, concat layer 0.921 / 0.863 / 0.824 / 0.829 / 0.908 ms at 1024 / 2048 / 4096 / 8192 / 16384.
+int g_wgrad_kchunk_cap = 4096;
 
 template <bool ROUTED>
 int wgrad_x6_resident() {
@@ -989,7 +996,7 @@ int gemm_wgrad_x6_impl(const char* who, const bl_rows_packed_t* a, const uint16_
     const long long slots = (long long)resident * rounds - extra;
     if (slots <= 0) continue;
     const long long kc = ((long long)M * ntiles_all + slots - 1) / slots;
-    if (kc <= 1024 || rounds == 64) {
+    if (kc <= g_wgrad_kchunk_cap || rounds == 64) {
       kchunk = (int)((kc + 31) / 32 * 32);
       break;
     }
@@ -1024,6 +1031,14 @@ int gemm_wgrad_x6_impl(const char* who, const bl_rows_packed_t* a, const uint16_
 extern "C" int32_t bl_set_wgrad_tile(int32_t rows) {
   const int32_t prev = g_wgrad_wide ? 256 : 128;
   g_wgrad_wide = rows != 128;
+  return prev;
+}
+
+// Rows per workgroup of the bf16x6 weight-gradient GEMMs: the chunk is the smallest one that fills an integer number of rounds
+// of resident workgroups and is <= cap rows.  Returns the previous cap.
+extern "C" int32_t bl_set_wgrad_kchunk_cap(int32_t rows) {
+  const int32_t prev = g_wgrad_kchunk_cap;
+  if (rows >= 256) g_wgrad_kchunk_cap = rows;
   return prev;
 }
 

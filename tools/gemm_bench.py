@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--which", default="fwd,nk,wgrad")
     ap.add_argument("--order", default="type", help="type: type-major; chunk: (graph chunk, type)-major")
     ap.add_argument("--chunk", type=int, default=1, help="graphs per chunk")
+    ap.add_argument("--kcaps", default="", help="comma list: also time wgrad_x6 with these row caps per workgroup (bl_set_wgrad_kchunk_cap)")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
     N, E, Din, Dm, T = a.nodes, a.msgs, a.din, a.dm, a.types
@@ -98,10 +99,29 @@ def main():
             ops.set_wgrad_tile(prev)
 
     fns["wgrad_x6_t128"] = wgrad_x6_tile128  # A/B: the 128 x 128 tile (wgrad_x6 = the default, wide where it applies)
+    def with_cap(cap):
+        def run():
+            prev = ops.set_wgrad_kchunk_cap(cap)
+            try:
+                fns["wgrad_x6"]()
+            finally:
+                ops.set_wgrad_kchunk_cap(prev)
+        return run
+
+    caps = [int(c) for c in a.kcaps.split(",") if c]
+    for cap in caps:
+        fns[f"wgrad_x6_cap{cap}"] = with_cap(cap)
+    if caps:  # same sums whatever the chunking (up to the order of the fp32 additions)
+        gw6.zero_(); fns["wgrad_x6"](); ref = gw6.clone()
+        for cap in caps:
+            gw6.zero_(); fns[f"wgrad_x6_cap{cap}"]()
+            err = ((gw6 - ref).abs().max() / ref.abs().max()).item()
+            print(f"cap {cap}: max |diff| / max |ref| = {err:.2e}", flush=True)
+            assert err < 1e-5
     fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, group_ptr=ptr, G=T_groups, group_w=gw_t, win_bits=bits_real)
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
     fns["pack_wt"] = lambda: ops.pack_weights_x6(W, True)
-    names = a.which.split(",")
+    names = a.which.split(",") + [f"wgrad_x6_cap{cap}" for cap in caps]
     times = {n: [] for n in names}
     for rnd in range(a.rounds):  # interleaved rounds in ONE process: report median and min per variant
         for name in names:
