@@ -290,6 +290,8 @@ def main():
     ap.add_argument("--serial", action="store_true", help="weight-gradient GEMMs on the main stream everywhere (no side-stream overlap): the run "
                     "whose rocprofv3 --kernel-trace --stats averages are the exclusive kernel times the roofline quotes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused-node-bwd", action="store_true", help="A/B: the node update's backward chain as three kernels "
+                    "(act backward, dense input gradient, LayerNorm backward) instead of bl_node_update_bwd")
     ap.add_argument("--wgrad-kcap", type=int, default=0, help="A/B: rows per workgroup flush of the bf16x6 weight-gradient GEMMs "
                     "(hip_ops.set_wgrad_kchunk_cap); 0 = the library's default")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce per step instead of layer-wise buckets behind backward")
@@ -330,6 +332,8 @@ def main():
         hip_ops.USE_SIDE_STREAM = False
     if args.wgrad_kcap:
         hip_ops.set_wgrad_kchunk_cap(args.wgrad_kcap)
+    if args.unfused_node_bwd:
+        hip_ops.set_fused_node_bwd(False)
 
     def build_workload(a):
         """(module, minibatch, optimiser) of one configuration: resident synthetic minibatch, random-init weights."""

@@ -321,7 +321,9 @@ typedef struct {
 
 /* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call.
  * backward: 0 = forward call, 1 = backward call, 2 = backward call that will take the bl_routed_dgrad_nodes_rows path (Wt
- * given, shape supported, deterministic mode off): [E, Din] source-half rows instead of the [E, 2 Din] per-message gradient */
+ * given, shape supported, deterministic mode off): [E, Din] source-half rows instead of the [E, 2 Din] per-message gradient,
+ * 3 = forward-only call (bl_mp_layer_fwd with saved == NULL: the workspace then also holds the packed input and the
+ * LayerNorm output) */
 int64_t bl_mp_layer_saved_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t msg_act);
 int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t Dout, int32_t backward);
 /* uint16 elements of the packed weights a layer call takes: bl_pack_weights_x6(W, T, 2 Din, Dm, w_is_kn = 1) for
@@ -330,7 +332,9 @@ int64_t bl_mp_layer_packed_weight_elems(int32_t T, int32_t Din, int32_t Dm, int3
 
 /* forward.  The layer input is h_lo [N, width_lo] alone (h_hi NULL, width_lo == Din) or the virtual concatenation
  * [h_lo ; h_hi] of a ConcatResidual layer (gnnlayerdefs.py:24-38), never materialised.  winner_out (optional,
- * int32 [N, Dm]): the arg-max message per (node, channel), -1 = none. */
+ * int32 [N, Dm]): the arg-max message per (node, channel), -1 = none.  saved == NULL: forward-only call (the reference's
+ * predict / evaluate path, buglab/models/gnn.py:606-645) -- nothing is stored for a backward pass (no routing bitmask,
+ * activation derivative, aggregate, LayerNorm statistics), ws is sized by bl_mp_layer_workspace_bytes(..., 3). */
 int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_t ld_lo, int32_t width_lo, const float* h_hi,
                     int32_t ld_hi, const uint16_t* w_packed, float* h_out, int32_t* winner_out, void* saved, void* ws,
                     void* stream);
@@ -342,6 +346,26 @@ int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const float* g_o
                     const void* saved, void* ws, float* g_h_lo, int32_t ld_lo, int32_t width_lo, float* g_h_hi,
                     int32_t ld_hi, float* g_W, float* g_ln_g, float* g_ln_b, float* g_Wd, float* g_bd, void* stream,
                     void* side_stream, int32_t join_side);
+
+/* Backward of the layer's node update  h_out = drop(tanh(LayerNorm(agg) . Wd + bd))  from g_out, in one kernel per 64-node
+ * tile (ptgnn MlpMessagePassingLayer's LayerNorm -> Linear -> tanh -> Dropout tail; call site
+ * buglab/models/gnnlayerdefs.py:6-23):
+ *   g_z = g_out . dropout mask . (1 - tanh^2)      -> g_z_packed [nrows, 3 Dout] (bl_pack_bf16x3 form; the operand of the dense
+ *                                                     weight-gradient GEMM), g_bias [Dout] += its column sums (may be NULL)
+ *   g_ln = g_z . Wd^T                              (bf16x6; wd_packed_bwd = bl_pack_weights_x6(Wd, 1, Dm, Dout, w_is_kn = 0))
+ *   gq = LayerNorm backward(g_ln; agg, mean, rstd, ln_g) x dact   -> gq [nrows, Dm] fp32 and / or gq_packed [nrows, 3 Dm]
+ *   g_ln_g, g_ln_b [Dm] += the gamma / beta gradients
+ * = bl_act_bwd_packed + bl_gemm_rows_x6_epi + bl_layernorm_bwd without the g_z / g_ln round trips.  dact (the message
+ * activation's derivative at the winners) may be NULL (= 1).  Shapes: bl_node_update_bwd_ok(Dm, Dout) -- Dm 128 or 256,
+ * Dout a multiple of 32 up to 256, deterministic mode off (the column sums are flushed by unordered atomics). */
+int32_t bl_node_update_bwd_ok(int32_t Dm, int32_t Dout);
+int bl_node_update_bwd(const float* g_out, const float* h_out, int32_t nrows, int32_t Dout, bl_dropout_t drop,
+                       const uint16_t* wd_packed_bwd, const float* agg, const float* mean, const float* rstd, const float* ln_g,
+                       const float* dact, int32_t Dm, uint16_t* g_z_packed, float* g_bias, float* gq, uint16_t* gq_packed,
+                       float* g_ln_g, float* g_ln_b, void* stream);
+/* A/B switch: 1 (default) = bl_mp_layer_bwd uses bl_node_update_bwd where it applies, 0 = the three kernels it replaces.
+ * Returns the previous value. */
+int32_t bl_set_fused_node_bwd(int32_t on);
 
 /* optional per-kernel timing of the launches made inside bl_mp_layer_fwd / _bwd (HIP events on the stream each
  * kernel is launched on); read after a device synchronisation.  bench.py's roofline numbers come from here. */

@@ -66,6 +66,10 @@ _SIGNATURES = {
     "bl_get_deterministic": ([], c_int32),
     "bl_set_wgrad_tile": ([c_int32], c_int32),
     "bl_set_wgrad_kchunk_cap": ([c_int32], c_int32),
+    "bl_node_update_bwd_ok": ([c_int32, c_int32], c_int32),
+    "bl_node_update_bwd": ([c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_set_fused_node_bwd": ([c_int32], c_int32),
     "bl_last_error": ([], ctypes.c_char_p),
     "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
@@ -862,6 +866,26 @@ def set_wgrad_kchunk_cap(rows: int) -> int:
     return int(load_library().bl_set_wgrad_kchunk_cap(int(rows)))
 
 
+def set_fused_node_bwd(on: bool) -> bool:
+    """A/B switch: the node update's backward chain of the fused layer call as one kernel (default) or three.  -> previous."""
+    return bool(load_library().bl_set_fused_node_bwd(1 if on else 0))
+
+
+def node_update_bwd(g_out, h_out, drop: "Dropout", wd_packed_bwd, agg, mean, rstd, ln_g, dact, g_bias, g_ln_g, g_ln_b, want_f32=True):
+    """bl_node_update_bwd (csrc/bl_node_bwd.hip) -> (packed g_z [N, 3 Dout] int16, gq fp32 [N, Dm] or None, packed gq [N, 3 Dm])."""
+    N, Dout = g_out.shape
+    Dm = agg.shape[1]
+    dev = g_out.device
+    gz = torch.empty((N, 3 * Dout), dtype=torch.int16, device=dev)
+    gq = torch.empty((N, Dm), dtype=torch.float32, device=dev) if want_f32 else None
+    gqp = torch.empty((N, 3 * Dm), dtype=torch.int16, device=dev)
+    _check(load_library().bl_node_update_bwd(_f32(g_out).data_ptr(), _f32(h_out).data_ptr(), N, Dout, drop.c(), wd_packed_bwd.data_ptr(),
+                                             _f32(agg).data_ptr(), mean.data_ptr(), rstd.data_ptr(), ln_g.data_ptr(), _p(dact), Dm,
+                                             gz.data_ptr(), _p(g_bias), _p(gq), gqp.data_ptr(), g_ln_g.data_ptr(), g_ln_b.data_ptr(),
+                                             _stream()), "bl_node_update_bwd")
+    return gz, gq, gqp
+
+
 def deterministic() -> bool:
     return bool(load_library().bl_get_deterministic())
 
@@ -986,6 +1010,9 @@ def _layer_desc(g: "GraphIndex", W, ln_g, ln_b, Wd, bd, Din, msg_act, drop: Drop
     return L
 
 
+INFERENCE_MODE = True  # forward-only form of the fused layer call when no input needs a gradient (A/B switch for tests)
+
+
 class _MpLayerFused(torch.autograd.Function):
     """One MlpMessagePassingLayer = one C call forward, one backward.  The layer input is `h_lo` alone or the
     virtual concatenation [h_lo ; h_hi] of a ConcatResidual layer (never materialised).  What forward keeps for
@@ -1016,13 +1043,16 @@ class _MpLayerFused(torch.autograd.Function):
         if dense_x6:
             wd_kn, wd_nk = _packed_layer_weights(Wd, need_bwd)
             L.Wd_packed = wd_kn.data_ptr()
-        saved = torch.empty((lib.bl_mp_layer_saved_bytes(N, E, Din, Dm, msg_act),), dtype=torch.uint8, device=dev)
-        ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, 0),), dtype=torch.uint8, device=dev)
+        # no backward pass will follow (predict / evaluate under no_grad): nothing is saved, the call skips every store that
+        # only a backward pass reads (routing bitmask, activation derivative, aggregate, LayerNorm statistics)
+        infer = not need_bwd and INFERENCE_MODE
+        saved = None if infer else torch.empty((lib.bl_mp_layer_saved_bytes(N, E, Din, Dm, msg_act),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, 3 if infer else 0),), dtype=torch.uint8, device=dev)
         out = torch.empty((N, Dout), dtype=torch.float32, device=dev)
         winner = torch.empty((N, Dm), dtype=torch.int32, device=dev) if WINNER_SINK is not None else None
         _check(lib.bl_mp_layer_fwd(ctypes.byref(L), h_lo.data_ptr(), h_lo.stride(0), h_lo.shape[1], _p(h_hi),
                                    h_hi.stride(0) if h_hi is not None else 0, wkn.data_ptr(), out.data_ptr(), _p(winner),
-                                   saved.data_ptr(), ws.data_ptr() if E > 0 else None, _stream()), "bl_mp_layer_fwd")
+                                   _p(saved), ws.data_ptr() if (E > 0 or infer) else None, _stream()), "bl_mp_layer_fwd")
         if winner is not None:
             WINNER_SINK.append(winner)
         if need_bwd:

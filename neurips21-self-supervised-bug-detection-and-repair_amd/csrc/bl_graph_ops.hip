@@ -252,7 +252,7 @@ __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int l
     const int d = lane + 64 * j;
     if (barg[j] < 0) best[j] = 0.f;  // empty segment (torch_scatter leaves 0) or padding lane
     if (d < D) {
-      out[(size_t)seg * D + d] = best[j];
+      if (out) out[(size_t)seg * D + d] = best[j];  // (forward-only layer calls keep nothing but the LayerNorm output)
       if (arg) arg[(size_t)seg * D + d] = barg[j];
       s += best[j];
       if (dact) {  // d act / d pre at the winner, so that backward never needs the [E, D] messages again
@@ -298,7 +298,7 @@ __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int l
         }
       }
     }
-    if (lane == 0) { mean_out[seg] = mean; rstd_out[seg] = rstd; }
+    if (lane == 0 && mean_out) { mean_out[seg] = mean; rstd_out[seg] = rstd; }
   }
 }
 
@@ -784,11 +784,12 @@ int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr,
                             float* mean, float* rstd, float* dact, uint32_t* winbits, const int32_t* seg_order,
                             uint16_t* ln_out_packed, int32_t num_hub_slots, void* stream) {
   if (nseg == 0) return BL_OK;
-  BL_CHECK_ARG(seg_ptr && out, "bl_segment_max_fwd: null pointer");  // arg (the winner table) is optional
+  // arg (the winner table) is optional; so are out / mean / rstd when only the LayerNorm output is wanted (forward-only calls)
+  BL_CHECK_ARG(seg_ptr && (out || ln_g), "bl_segment_max_fwd: null pointer");
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
   BL_CHECK_ARG(act == BL_ACT_NONE || act == BL_ACT_GELU, "bl_segment_max_fwd: act must be NONE or GELU");
   const bool has_ln = ln_g != nullptr;
-  BL_CHECK_ARG(!has_ln || (ln_b && (ln_out || ln_out_packed) && mean && rstd), "bl_segment_max_fwd: LayerNorm outputs missing");
+  BL_CHECK_ARG(!has_ln || (ln_b && (ln_out || ln_out_packed) && (mean == nullptr) == (rstd == nullptr)), "bl_segment_max_fwd: LayerNorm outputs missing");
   BL_CHECK_ARG(ln_out_packed == nullptr || (has_ln && D % 8 == 0), "bl_segment_max_fwd: the packed LayerNorm output needs D %% 8 == 0");
   dim3 grid((nseg + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;

@@ -28,7 +28,8 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
 const char* kProfNames[] = {"pack_rows",      "msg_gemm_x6",  "segment_max_ln", "dense_fwd",    "act_bwd",       "dense_wgrad",
-                            "dense_dgrad",    "layernorm_bwd", "msg_wgrad_x6",   "msg_dgrad_x6", "node_grad_sums", "msg_dgrad_nodes"};
+                            "dense_dgrad",    "layernorm_bwd", "msg_wgrad_x6",   "msg_dgrad_x6", "node_grad_sums", "msg_dgrad_nodes",
+                            "node_update_bwd"};
 constexpr int kProfKinds = sizeof(kProfNames) / sizeof(kProfNames[0]);
 
 hipEvent_t prof_event() {
@@ -126,6 +127,23 @@ Saved carve_saved(void* base, int N, int E, int Din, int Dm, int msg_act) {
   s.bytes = o;
   return s;
 }
+struct WsInfer {  // forward-only call (saved == NULL): the three buffers a forward pass cannot do without
+  float* pre;      // [E, Dm]     pre-activations of the messages
+  uint16_t* hp;    // [N, 3 Din]  packed layer input
+  float* ln_out;   // [N, Dm] fp32 or its packed form [N, 3 Dm]
+  size_t bytes;
+};
+WsInfer carve_infer(void* base, int N, int E, int Din, int Dm) {
+  WsInfer w;
+  char* p = (char*)base;
+  size_t o = 0;
+  auto take = [&](size_t b) { char* q = p ? p + o : nullptr; o += al(b); return q; };
+  w.pre = (float*)take((size_t)E * Dm * 4);
+  w.hp = (uint16_t*)take((size_t)N * 3 * Din * 2);
+  w.ln_out = (float*)take((size_t)N * Dm * 6);
+  w.bytes = o;
+  return w;
+}
 struct WsBwd {
   float* g_z;      // [N, Dout] fp32, or its bf16x3-packed form [N, 3 Dout] (same region)
   float* g_ln;     // [N, Dm]
@@ -146,6 +164,8 @@ WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool full_g
   return w;
 }
 
+bool g_fused_node_bwd = true;  // bl_set_fused_node_bwd: act backward -> dense input gradient -> LayerNorm backward in one kernel
+
 hipEvent_t g_fork1 = nullptr, g_fork2 = nullptr, g_join = nullptr;
 bool ensure_events() {
   if (g_join) return true;
@@ -158,7 +178,8 @@ int check_layer(const bl_mp_layer_t* L, const char* who) {
   BL_CHECK_ARG(L && L->N > 0 && L->E >= 0 && L->T > 0, "%s: bad sizes", who);
   BL_CHECK_ARG(L->Din % 32 == 0 && L->Dm % 32 == 0 && L->Dout % 4 == 0 && L->Din > 0 && L->Dm > 0 && L->Dm <= 512 && L->Dout > 0,
                "%s: the fused layer needs Din, Dm multiples of 32 (bf16x6 GEMMs), Dm <= 512", who);
-  BL_CHECK_ARG(L->msg_src && L->msg_tgt && L->type_ptr && L->tgt_ptr && L->tgt_msgs && L->src_ptr && L->src_msgs,
+  // (a minibatch without messages has empty per-message arrays: PyTorch hands out NULL for those)
+  BL_CHECK_ARG(L->type_ptr && L->tgt_ptr && L->src_ptr && (L->E == 0 || (L->msg_src && L->msg_tgt && L->tgt_msgs && L->src_msgs)),
                "%s: null graph index array", who);
   BL_CHECK_ARG(L->W && L->ln_g && L->ln_b && L->Wd && L->bd, "%s: null parameter", who);
   BL_CHECK_ARG(L->msg_act == BL_ACT_NONE || L->msg_act == BL_ACT_GELU, "%s: message activation must be none or gelu", who);
@@ -166,11 +187,20 @@ int check_layer(const bl_mp_layer_t* L, const char* who) {
 }
 }  // namespace
 
+// A/B switch (tests, bench): 1 (default) = the node update's backward chain runs as bl_node_update_bwd where the shapes allow
+// (Dm 128 / 256, dense node update on the bf16x6 path, deterministic mode off); 0 = three kernels.  Returns the previous value.
+extern "C" int32_t bl_set_fused_node_bwd(int32_t on) {
+  const int32_t prev = g_fused_node_bwd ? 1 : 0;
+  g_fused_node_bwd = on != 0;
+  return prev;
+}
+
 extern "C" int64_t bl_mp_layer_saved_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t msg_act) {
   return (int64_t)carve_saved(nullptr, N, E, Din, Dm, msg_act).bytes;
 }
 // forward scratch: the [E, Dm] pre-activations; backward scratch: g_z, g_ln, packed node gradient, [E, 2 Din] input gradients
 extern "C" int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t Dout, int32_t backward) {
+  if (backward == 3) return (int64_t)carve_infer(nullptr, N, E, Din, Dm).bytes;
   if (backward) return (int64_t)carve_bwd(nullptr, N, E, Din, Dm, Dout, backward != 2).bytes;
   return (int64_t)al((size_t)E * Dm * 4);
 }
@@ -189,12 +219,22 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
                                void* ws, void* stream) {
   BL_TRY(check_layer(L, "bl_mp_layer_fwd"));
   const int N = L->N, E = L->E, T = L->T, Din = L->Din, Dm = L->Dm, Dout = L->Dout;
-  BL_CHECK_ARG(h_lo && w_packed && h_out && saved && (ws || E == 0), "bl_mp_layer_fwd: null buffer");
+  // saved == NULL: forward-only call (model.predict, evaluate.py) -- nothing is kept for a backward pass: no routing bitmask, no
+  // activation derivative, no aggregate / mean / rstd stores; the packed input and the LayerNorm output live in `ws`
+  const bool infer = saved == nullptr;
+  BL_CHECK_ARG(h_lo && w_packed && h_out && (ws || (E == 0 && !infer)), "bl_mp_layer_fwd: null buffer");
   BL_CHECK_ARG((h_hi == nullptr && width_lo == Din) || (h_hi != nullptr && width_lo > 0 && width_lo < Din && width_lo % 32 == 0),
                "bl_mp_layer_fwd: width_lo must be Din (one source) or a multiple of 32 below Din (two sources)");
   hipStream_t st = (hipStream_t)stream;
   Saved S = carve_saved(saved, N, E, Din, Dm, L->msg_act);
   float* pre = (float*)ws;
+  if (infer) {
+    const WsInfer I = carve_infer(ws, N, E, Din, Dm);
+    pre = I.pre;
+    S.hp = I.hp;
+    S.ln_out = I.ln_out;
+    S.dact = nullptr; S.bits = nullptr; S.agg = nullptr; S.mean = nullptr; S.rstd = nullptr;
+  }
   {
     ProfScope ps(0, 0.0, st, false);
     if (h_hi == nullptr) {
@@ -265,7 +305,13 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   // dense node update on the bf16x6 path: forward must have run with Wd_packed too (it decides the form of `saved`)
   const bool dense_x6 = L->Wd_packed != nullptr && L->Wd_packed_bwd != nullptr && Dm % 32 == 0 && Dout % 32 == 0;
   BL_CHECK_ARG(dense_x6 || L->Wd_packed == nullptr, "bl_mp_layer_bwd: Wd_packed given without Wd_packed_bwd");
-  {  // y = drop(tanh(z)): g_z (packed for the bf16x6 GEMMs), bias gradient
+  // act backward -> dense input gradient -> LayerNorm backward x activation derivative in ONE kernel (csrc/bl_node_bwd.hip)
+  const bool fused_node = dense_x6 && g_fused_node_bwd && bl_node_update_bwd_ok(Dm, Dout);
+  if (fused_node) {
+    ProfScope ps(12, 2.0 * N * (double)Dm * Dout, st, false);
+    BL_TRY(bl_node_update_bwd(g_out, h_out, N, Dout, L->drop, L->Wd_packed_bwd, S.agg, S.mean, S.rstd, L->ln_g, S.dact, Dm,
+                              (uint16_t*)B.g_z, g_bd, vec_dgrad ? B.g_ln : nullptr, B.gqp, g_ln_g, g_ln_b, st));
+  } else {  // y = drop(tanh(z)): g_z (packed for the bf16x6 GEMMs), bias gradient
     ProfScope ps(4, 0.0, st, false);
     BL_TRY(bl_act_bwd_impl(g_out, h_out, N, Dout, Dout, BL_ACT_TANH, L->drop, dense_x6 ? nullptr : B.g_z, g_bd,
                            dense_x6 ? (uint16_t*)B.g_z : nullptr, st));
@@ -288,7 +334,7 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
       BL_TRY(bl_gemm_wgrad(&r1, B.g_z, Dout, nullptr, nullptr, 1, N, Dout, Dm, g_Wd, 0, Dout, side));
     }
   }
-  {
+  if (!fused_node) {
     ProfScope ps(6, 2.0 * N * (double)Dm * Dout, st, two);
     if (dense_x6) {
       p1.xp[0] = (const uint16_t*)B.g_z; p1.width[0] = Dout;
@@ -302,7 +348,7 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
       BL_TRY(bl_gemm_rows(&r1, L->Wd, 0, Dout, 1, nullptr, nullptr, nullptr, 1, N, Dm, Dout, BL_ACT_NONE, nodrop, B.g_ln, Dm, st));
     }
   }
-  {  // LayerNorm backward x activation derivative at the winners -> packed d loss / d (winning pre-activation)
+  if (!fused_node) {  // LayerNorm backward x activation derivative at the winners -> packed d loss / d (winning pre-activation)
     ProfScope ps(7, 0.0, st, two);
     // (the fp32 form of the result, for the vector input gradient, overwrites g_ln in place: the kernel is row-local)
     BL_TRY(bl_layernorm_bwd(B.g_ln, S.agg, S.mean, S.rstd, L->ln_g, N, Dm, vec_dgrad ? B.g_ln : nullptr, g_ln_g, g_ln_b, S.dact, B.gqp, st));

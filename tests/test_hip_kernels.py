@@ -595,6 +595,147 @@ def test_fused_layer_call_equals_kernel_by_kernel_path():
         assert float((g - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-7, k  # atomics reorder sums
 
 
+def _unpack_bf16x3(p, D):
+    """fp64 value of a bl_pack_bf16x3 row-packed int16 tensor [R, 3 D]: hi + mid + lo."""
+    u = p.cpu().numpy().view(np.uint16).astype(np.uint32) << 16
+    f = torch.from_numpy(u.view(np.float32).astype(np.float64)).view(p.shape[0], 3, D)
+    return f.sum(1)
+
+
+@pytest.mark.parametrize("N,Dm,Dout,p,with_dact,want_f32", [(1000, 128, 128, 0.2, True, True), (777, 256, 128, 0.0, True, False),
+                                                             (300, 256, 256, 0.1, False, True), (64, 128, 256, 0.2, True, True),
+                                                             (65, 128, 64, 0.0, True, True), (1, 256, 32, 0.3, True, True)])
+def test_node_update_bwd_matches_fp64(ops, N, Dm, Dout, p, with_dact, want_f32):
+    """bl_node_update_bwd (act backward -> dense input gradient -> LayerNorm backward x activation derivative, one kernel) against
+    the same chain in fp64: packed g_z, the bias gradient, gq in both forms, the gamma / beta gradients (accumulated on top of
+    what is there).  Partial last tile, one row, Dout below one 128-wide tile, no activation derivative."""
+    torch.manual_seed(N + Dm)
+    drop = ops.Dropout(p, 123, 5) if p > 0 else ops.NO_DROPOUT
+    keep = torch.from_numpy(O.dropout_keep_mask(123, 5, N * Dout, p)).view(N, Dout).double() if p > 0 else torch.ones(N, Dout, dtype=torch.float64)
+    t = torch.tanh(torch.randn(N, Dout).double())
+    y = (t * keep / (1 - p)).float()
+    g = torch.randn(N, Dout)
+    Wd = torch.randn(Dm, Dout) / math.sqrt(Dm)  # forward weight [Dm, Dout]: z = ln_out @ Wd
+    agg = torch.randn(N, Dm) * 1.5 + 0.3
+    gamma = torch.rand(Dm) + 0.5
+    dact = torch.rand(N, Dm) if with_dact else None
+    mean = agg.double().mean(1)
+    var = agg.double().var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    # fp64 chain
+    gz = g.double() * keep / (1 - p) * (1 - t * t)
+    gln = gz @ Wd.double().t()
+    xh = (agg.double() - mean[:, None]) * rstd[:, None]
+    gg = gln * gamma.double()
+    a, b = gg.mean(1, keepdim=True), (gg * xh).mean(1, keepdim=True)
+    gq_ref = rstd[:, None] * (gg - a - xh * b) * (dact.double() if with_dact else 1.0)
+    # device
+    wnk = ops.pack_weights_x6(_dev(Wd).unsqueeze(0), False)
+    g_bias = torch.full((Dout,), 2.0, device="cuda")
+    g_lng, g_lnb = torch.full((Dm,), -1.0, device="cuda"), torch.full((Dm,), 0.5, device="cuda")
+    assert ops.load_library().bl_node_update_bwd_ok(Dm, Dout)
+    gzp, gq, gqp = ops.node_update_bwd(_dev(g), _dev(y), drop, wnk, _dev(agg), _dev(mean.float()), _dev(rstd.float()), _dev(gamma),
+                                       _dev(dact) if with_dact else None, g_bias, g_lng, g_lnb, want_f32=want_f32)
+    torch.cuda.synchronize()
+    scale = float(gq_ref.abs().max())
+    assert float((_unpack_bf16x3(gzp, Dout) - gz).abs().max()) < 1e-6 * max(1.0, float(gz.abs().max()))
+    assert float((g_bias.cpu().double() - (2.0 + gz.sum(0))).abs().max()) < 1e-4 * max(1.0, float(gz.sum(0).abs().max()))
+    if want_f32:
+        assert float((gq.cpu().double() - gq_ref).abs().max()) < 2e-5 * max(1.0, scale)
+    else:
+        assert gq is None
+    assert float((_unpack_bf16x3(gqp, Dm) - gq_ref).abs().max()) < 2e-5 * max(1.0, scale)
+    want_g, want_b = -1.0 + (gln * xh).sum(0), 0.5 + gln.sum(0)
+    assert float((g_lng.cpu().double() - want_g).abs().max()) < 1e-4 * max(1.0, float(want_g.abs().max()))
+    assert float((g_lnb.cpu().double() - want_b).abs().max()) < 1e-4 * max(1.0, float(want_b.abs().max()))
+
+
+@pytest.mark.parametrize("hidden", [128, 64])
+def test_fused_node_update_backward_equals_the_three_kernel_chain(hidden):
+    """bl_mp_layer_bwd with bl_node_update_bwd (default) against the same call with the three kernels it replaces
+    (bl_set_fused_node_bwd(0)): same loss, gradients equal up to the order of fp32 sums.  hidden 128: layers with Dm = 128 and
+    the ConcatResidual layers' Dm = 256 both take the fused kernel; hidden 64: Dm = 64 does not qualify, Dm = 128 does."""
+    from buglab.data.collate import collate_samples, to_device
+    from buglab.data.synthetic import make_samples
+    from buglab.models import hip_ops
+    from buglab.models.gnn import build_gnn_mlp_module
+
+    mb = to_device(collate_samples(make_samples(3, seed=5, num_nodes=300, num_messages=1500, num_edge_types=6, vocab_size=500), 6), "cuda")
+    torch.manual_seed(0)
+    module = build_gnn_mlp_module(hidden, 8, 6, vocabulary_size=500, dropout_rate=0.1).cuda().train()
+    res = {}
+    for fused in (True, False):
+        prev = hip_ops.set_fused_node_bwd(fused)
+        try:
+            module.zero_grad(set_to_none=True)
+            loss = module(**mb, dropout_seed=11)
+            loss.backward()
+            hip_ops.join_side_stream()
+            torch.cuda.synchronize()
+            res[fused] = (float(loss.detach()), {k: p.grad.clone() for k, p in module.named_parameters()})
+        finally:
+            hip_ops.set_fused_node_bwd(prev)
+    assert res[True][0] == res[False][0]
+    for k, g in res[True][1].items():
+        ref = res[False][1][k]
+        assert float((g - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7, k
+
+
+@pytest.mark.parametrize("degree", ["uniform", "powerlaw"])
+def test_forward_only_layer_call_equals_the_training_forward(degree):
+    """bl_mp_layer_fwd with saved == NULL (what model.predict / evaluate.py run under no_grad: reference
+    buglab/models/gnn.py:606-645) keeps nothing for a backward pass; its outputs are those of the training-form call, bit
+    for bit -- hubs (4-wave segmented max) and a ConcatResidual input included."""
+    from buglab.data.collate import collate_samples, to_device
+    from buglab.data.synthetic import make_samples
+    from buglab.models import hip_ops
+    from buglab.models.gnn import build_gnn_mlp_module
+
+    mb = to_device(collate_samples(make_samples(3, seed=9, num_nodes=400, num_messages=2400, num_edge_types=6, vocab_size=500,
+                                                degree=degree, max_degree=200), 6), "cuda")
+    torch.manual_seed(1)
+    module = build_gnn_mlp_module(64, 8, 6, vocabulary_size=500, dropout_rate=0.1).cuda().eval()
+    res = {}
+    for infer in (True, False):
+        hip_ops.INFERENCE_MODE = infer
+        try:
+            with torch.no_grad():
+                ids, logp, gout, _ = module.compute_localization_logprobs(mb["graph_data"])
+            torch.cuda.synchronize()
+            res[infer] = (logp.clone(), gout.output_node_representations.clone())
+        finally:
+            hip_ops.INFERENCE_MODE = True
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert torch.isfinite(res[True][0]).all()
+
+
+def test_forward_only_layer_call_without_edges():
+    """saved == NULL and E == 0: the workspace still holds the packed input and the LayerNorm output."""
+    from buglab.models import hip_ops
+
+    N, H, T = 37, 64, 3
+    torch.manual_seed(0)
+    h = torch.randn(N, H, device="cuda")
+    W = torch.randn(T, 2 * H, H, device="cuda") * 0.1
+    ln_g, ln_b = torch.rand(H, device="cuda") + 0.5, torch.randn(H, device="cuda") * 0.1
+    Wd, bd = torch.randn(H, H, device="cuda") * 0.1, torch.randn(H, device="cuda") * 0.1
+    z = torch.zeros(0, dtype=torch.int32, device="cuda")
+    zp = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
+    g = hip_ops.GraphIndex(z, z, torch.zeros(T + 1, dtype=torch.int32, device="cuda"), zp, z, zp, z, N, 0, T)
+    outs = []
+    for infer in (True, False):
+        hip_ops.INFERENCE_MODE = infer
+        try:
+            with torch.no_grad():
+                outs.append(hip_ops.mp_layer(h, W, ln_g, ln_b, Wd, bd, g, msg_act="gelu"))
+        finally:
+            hip_ops.INFERENCE_MODE = True
+    torch.cuda.synchronize()
+    # every aggregate is 0: LayerNorm of a zero row is its bias
+    ref = torch.tanh(ln_b[None, :].expand(N, H) @ Wd + bd)
+    assert torch.equal(outs[0], outs[1]) and float((outs[0] - ref).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("w_buggy,abstain", [(1.0, 0.0), (2.5, 0.0), (1.0, 0.35), (0.4, 0.2)])
 def test_fused_loss_assembly_equals_the_op_by_op_path(w_buggy, abstain):
     """hip_ops.bug_loss (one kernel per direction for localizationmodule.py:63-124 + gnn.py:221-251,295-311 + the fixers'
