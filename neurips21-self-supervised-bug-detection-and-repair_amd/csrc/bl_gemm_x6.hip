@@ -207,8 +207,10 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
     int koff1, int koff2, int nsrc, const uint32_t* __restrict__ win_bits, int ld_bits, const uint4* __restrict__ bp,
     long long strideB, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G, int M, int N, int K,
     float* __restrict__ c, int ldc, int xcd_remap, X6Epi epi) {
-  __shared__ uint4 As[XBM * XROW];
-  __shared__ uint4 Bs[XBN * XROW];
+  // one array: after the last stage the four waves' result tiles are staged in it on their way out (see the epilogue)
+  __shared__ uint4 ABs[(XBM + XBN) * XROW];
+  uint4* As = ABs;
+  uint4* Bs = ABs + XBM * XROW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int g, row0, nrows, tile_y;
@@ -331,21 +333,33 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
     }
   }
 
+#ifndef X6_STAGED_STORE
+#define X6_STAGED_STORE 1  // 0 (experiment builds): float4 stores straight from the accumulator layout
+#endif
+  // The accumulator layout gives a lane 4 consecutive columns of one row, a wave-wide store 64 pieces of 16 B on 32 different
+  // rows: 32-byte segments.  The tile goes through LDS instead (per wave [32 rows][64 + 4] fp32, the operand images are dead
+  // after the last stage's barrier) and leaves as whole 256-byte row pieces, 16 lanes per piece: measured on the node
+  // update's backward kernel (same layout, csrc/bl_node_bwd.hip), the direct form cost 2-3x the time of its bytes.
+  float* stage = reinterpret_cast<float*>(ABs) + wave * (32 * 68);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     const int m = wm * 64 + ti * 32 + li;
+#if !X6_STAGED_STORE
     if (m >= nrows) continue;
     float* __restrict__ crow = c + (size_t)(row0 + m) * ldc;
+#endif
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = n0 + wn * 64 + tj * 32 + 8 * gq + 4 * half;
+#if !X6_STAGED_STORE
         if (n >= N) continue;
+#endif
         float v[4] = {acc[ti][tj][4 * gq + 0], acc[ti][tj][4 * gq + 1], acc[ti][tj][4 * gq + 2], acc[ti][tj][4 * gq + 3]};
         if (EPI >= 0) {
           float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (epi.bias) bv = *reinterpret_cast<const float4*>(epi.bias + n);
+          if (epi.bias && n < N) bv = *reinterpret_cast<const float4*>(epi.bias + n);
           v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -356,8 +370,23 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_x6_kernel(
             }
           }
         }
+#if X6_STAGED_STORE
+        *reinterpret_cast<float4*>(stage + li * 68 + tj * 32 + 8 * gq + 4 * half) = make_float4(v[0], v[1], v[2], v[3]);
+#else
         *reinterpret_cast<float4*>(crow + n) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
       }
+#if X6_STAGED_STORE
+    // (a wave reads back only what it wrote itself; its LDS operations execute in order)
+    const int c4 = lane & 15, n = n0 + wn * 64 + 4 * c4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = (lane >> 4) + 4 * j;
+      const int mm = wm * 64 + ti * 32 + r;
+      const float4 v = *reinterpret_cast<const float4*>(stage + r * 68 + 4 * c4);
+      if (mm < nrows && n < N) *reinterpret_cast<float4*>(c + (size_t)(row0 + mm) * ldc + n) = v;
+    }
+#endif
   }
 }
 
