@@ -383,14 +383,12 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
         } else if (hipMemset2DAsync(g_h_hi, (size_t)ld_hi * 4, 0, (size_t)(Din - split) * 4, N, st) != hipSuccess) { bl_set_error("bl_mp_layer_bwd: memset failed"); return BL_EINVAL; }
       }
       // target halves by atomics (one per run of equal targets), source halves as rows + a segmented sum over the source CSR:
-      // all-atomic, the kernel is bound by the L2's one fp32 atomic per channel per clock (0.475 vs 0.404 ms at c2's layer shape)
-      // (BL_DGRAD_ATOMIC_SRC=1 keeps the all-atomic form for A/B measurements)
-      static const bool atomic_src = getenv("BL_DGRAD_ATOMIC_SRC") && atoi(getenv("BL_DGRAD_ATOMIC_SRC")) != 0;
+      // all-atomic, the kernel is bound by the L2's one fp32 atomic per channel per clock (0.475 vs 0.404 ms at c2's layer shape;
+      // tools/dgrad_bench.py times both forms through bl_routed_dgrad_nodes / bl_routed_dgrad_nodes_rows)
       BL_TRY(bl_routed_dgrad_nodes_rows(B.g_ln, Dm, L->msg_src, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, Din, split,
-                                        g_h_lo, ld_lo, g_h_hi, ld_hi, atomic_src ? nullptr : B.g_a, Din, st));
-      if (!atomic_src)
-        BL_TRY(bl_mp_scatter_src_accum_impl(B.g_a, Din, L->src_ptr, L->src_msgs, N, Din, split, g_h_lo, ld_lo, g_h_hi, ld_hi,
-                                            L->node_order, st));
+                                        g_h_lo, ld_lo, g_h_hi, ld_hi, B.g_a, Din, st));
+      BL_TRY(bl_mp_scatter_src_accum_impl(B.g_a, Din, L->src_ptr, L->src_msgs, N, Din, split, g_h_lo, ld_lo, g_h_hi, ld_hi,
+                                          L->node_order, st));
     } else if (vec_dgrad) {
       ProfScope ps(9, 2.0 * N * (2.0 * Din) * Dm, st, two);
       BL_TRY(bl_routed_dgrad_vec(B.g_ln, Dm, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, 2 * Din, B.g_a, 2 * Din, st));

@@ -192,16 +192,18 @@ def test_c3_c4_shapes_hidden_256_match_oracle():
     _check_tie_aware(cfg, mb, seed=5)
 
 
-@pytest.mark.parametrize("H,degree", [(128, "uniform"), (256, "uniform"), (256, "powerlaw")])
-def test_baseline_graph_size_matches_fp64_oracle(H, degree):
+@pytest.mark.parametrize("H,degree,B", [(128, "uniform", 2), (256, "uniform", 2), (256, "powerlaw", 2), (128, "uniform", 8)])
+def test_baseline_graph_size_matches_fp64_oracle(H, degree, B):
     """The BASELINE per-graph size -- 2000 nodes / 10000 messages per graph, 8 layers, 16 edge types -- on a
-    2-graph minibatch (what bench.py's cpu_baseline leg runs): loss, log-probabilities and node states within
-    1e-4 of the fp64 oracle, winner tables equal up to near-ties, every gradient within 1e-4 (routing injected)."""
-    cfg, _, mb = Hh.make_case(B=2, n=2000, E=10000, T=16, H=H, layers=8, vocab=15000, C=40, degree=degree, max_degree=512, seed=21)
+    2-graph minibatch (what bench.py's cpu_baseline leg runs) and, at the headline configuration's width, on an 8-graph
+    one (16 000 nodes / 80 000 messages: several tiles per edge type in every GEMM, 250 tiles in the node kernels): loss,
+    log-probabilities and node states within 1e-4 of the fp64 oracle, winner tables equal up to near-ties, every gradient
+    within 1e-4 (routing injected)."""
+    cfg, _, mb = Hh.make_case(B=B, n=2000, E=10000, T=16, H=H, layers=8, vocab=15000, C=40, degree=degree, max_degree=512, seed=21)
     if degree == "powerlaw":
         assert np.diff(mb["graph_data"]["tgt_ptr"]).max() >= 512
     flips, total = _check_tie_aware(cfg, mb)
-    print(f"H={H} {degree}: {flips} near-tie routing differences out of {total} (node, channel) entries")
+    print(f"H={H} {degree} B={B}: {flips} near-tie routing differences out of {total} (node, channel) entries")
 
 
 def test_no_buggy_graphs_and_empty_edge_types():
