@@ -1220,7 +1220,10 @@ def gated_mp_layer(h, W, Wi, bi, Wh, bh, graph: GraphIndex, drop: Dropout = NO_D
 class _MpLayerFeat(torch.autograd.Function):
     """MlpMessagePassingLayer with edge features (`features_dimension` F > 0, reference gnnlayerdefs.py:13,22): the message
     input is [h_src ; h_tgt ; f_e] with f_e = edge_table[msg_feat[e]] read as a THIRD gathered source of the message GEMM --
-    the [E, F] feature matrix is never materialised.  Non-default configuration: exact-fp32 GEMM kernels, kernel by kernel."""
+    the [E, F] feature matrix is never materialised.  The three message GEMMs (forward, routed weight gradient, routed
+    input gradient) run on the bf16x6 kernels with three packed sources when Din, Dm and F are multiples of 32 (the table
+    is packed once per call like the node states); otherwise on the exact-fp32 kernels.  Kernel by kernel (non-default
+    configuration), dense node update on the exact-fp32 GEMMs."""
 
     @staticmethod
     def forward(ctx, h, W, ln_g, ln_b, Wd, bd, table, msg_feat, g: GraphIndex, msg_act: int, drop: Dropout):
@@ -1231,22 +1234,34 @@ class _MpLayerFeat(torch.autograd.Function):
         Dout = Wd.shape[1]
         E = g.num_messages
         assert K3 == 2 * Din + F and T == g.num_types and N == g.num_nodes and msg_feat.shape[0] == E
-        src3 = [(h, g.msg_src), (h, g.msg_tgt), (_f32(table, "edge table"), msg_feat)]
-        pre = gemm_rows(src3, _f32(W, "W"), E, Dm, b_group_stride=K3 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
-        agg, arg, ln_out, mean, rstd, dact = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)),
-                                                         want_dact=True, seg_order=g.node_order)[:6]
+        use_x6 = x6_ok(Din, Dm, F) and WGRAD_X6
+        hp = tp = bits = None
+        if use_x6:
+            hp, tp = pack_bf16x3(h), pack_bf16x3(_f32(table, "edge table"))
+            pre = gemm_rows_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din), (tp, msg_feat, F)], _packed_layer_weights(W, False)[0], E, Dm,
+                               group_ptr=g.type_ptr, G=T)
+        else:
+            src3 = [(h, g.msg_src), (h, g.msg_tgt), (_f32(table, "edge table"), msg_feat)]
+            pre = gemm_rows(src3, _f32(W, "W"), E, Dm, b_group_stride=K3 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)
+        res = segment_max(pre, g.tgt_ptr, g.tgt_msgs, N, act=msg_act, ln=(_f32(ln_g), _f32(ln_b)), want_dact=True, want_bits=use_x6,
+                          seg_order=g.node_order)
+        agg, arg, ln_out, mean, rstd, dact = res[:6]
+        if use_x6:
+            bits = res[6]
         if WINNER_SINK is not None:
             WINNER_SINK.append(arg.clone())
-        del pre
+        if use_x6:
+            arg = None  # the bf16x6 backward routes with the per-message bitmask only
+        del pre, res
         if msg_act == ACT_NONE:
             dact = None
         out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
-        ctx.saved = (h, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, out, g, drop)
+        ctx.saved = (h, hp, tp, bits, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, out, g, drop)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        h, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, out, g, drop = ctx.saved
+        h, hp, tp, bits, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, out, g, drop = ctx.saved
         ctx.saved = None
         N, Din = h.shape
         T, K3, Dm = W.shape
@@ -1256,10 +1271,19 @@ class _MpLayerFeat(torch.autograd.Function):
         g_z = act_bwd(g_out.contiguous(), out, ACT_TANH, drop, g_bd)
         gemm_wgrad([(ln_out, None)], g_z, N, Dout, g_Wd)
         g_ln = gemm_rows([(g_z, None)], Wd, N, Dm, b_is_nk=True, ldb=Dout)
-        gq = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact)  # d loss / d (winning pre-activation) per node
-        src3 = [(h, g.msg_src), (h, g.msg_tgt), (table, msg_feat)]
-        gemm_wgrad_routed(src3, gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K3 * Dm, group_ptr=g.type_ptr, G=T)
-        g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K3, b_group_stride=K3 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)  # [E, 2 Din + F]
+        if hp is not None:
+            # d loss / d (winning pre-activation) per node, packed for the bf16x6 GEMMs; message e's gradient row is
+            # gq[tgt(e)] masked to the channels e won (the routing bitmask)
+            gqp = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact, want="packed")
+            gemm_wgrad_routed_x6([(hp, g.msg_src, Din), (hp, g.msg_tgt, Din), (tp, msg_feat, F)], gqp, g.msg_tgt, bits, E, Dm, g_W,
+                                 gw_group_stride=K3 * Dm, group_ptr=g.type_ptr, G=T)
+            g_a = gemm_rows_x6([(gqp, g.msg_tgt, Dm)], _packed_layer_weights(W, True)[1], E, K3, group_ptr=g.type_ptr, G=T, win_bits=bits,
+                               kind="gemm_rows_nk_routed_x6")  # [E, 2 Din + F]
+        else:
+            gq = layernorm_bwd(g_ln, agg, mean, rstd, ln_g, g_lng, g_lnb, post_scale=dact)
+            src3 = [(h, g.msg_src), (h, g.msg_tgt), (table, msg_feat)]
+            gemm_wgrad_routed(src3, gq, g.msg_tgt, arg, E, Dm, g_W, gw_group_stride=K3 * Dm, group_ptr=g.type_ptr, G=T)
+            g_a = gemm_rows_routed(gq, g.msg_tgt, arg, W, E, K3, b_group_stride=K3 * Dm, ldb=Dm, group_ptr=g.type_ptr, G=T)  # [E, 2 Din + F]
         g_h = torch.empty((N, Din), dtype=torch.float32, device=dev)
         _check(load_library().bl_mp_scatter_grad(g_a.data_ptr(), g_a.stride(0), g.src_ptr.data_ptr(), g.src_msgs.data_ptr(), g.tgt_ptr.data_ptr(),
                                                  g.tgt_msgs.data_ptr(), N, Din, 0, g_h.data_ptr(), g_h.stride(0), _p(g.node_order), _stream()),

@@ -1015,6 +1015,9 @@ int gemm_wgrad_x6_impl(const char* who, const bl_rows_packed_t* a, const uint16_
   }
   const bool gather = nidx == a->nsrc + 1;
   wide = wide && (gather || nidx == 0) && (gather || !routed);
+  // plain (direct-row) weight gradients with few rows -- the sequence models' Linears, 16 384 token rows -- are faster on the
+  // 128 x 128 tile (two workgroups per CU): 58 vs 64 us per launch at seq-great's shapes (profiles/r03q / r04m seq kernel stats)
+  if (!gather && M < 65536) wide = false;
   // rows reduced by one workgroup: an integer number of rounds of resident workgroups (see bl_gemm.hip)
   const int resident = wide ? bl_num_cus() : (routed ? wgrad_x6_resident<true>() : wgrad_x6_resident<false>());
   const int ntiles_n = (N + XBN - 1) / XBN;

@@ -29,4 +29,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   f=$(find /tmp/pmc_$C -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python $R/tools/pmc_sum.py $f $C > $O/${TAG}_pmc_$C.json
 done
+# SQ counters of the serial run (own passes: MI355X_MICROARCH.md "rocprofv3 PMC slots"): matrix-pipe busy cycles against the
+# kernel's cycle count, L2 hits / misses -> gpurun_out/${TAG}_sq_pmc.json (tools/pmc_table.py)
+cd $R
+bash tools/pmc_passes.sh ${TAG}_sq "python $R/bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-predict --no-also" \
+  "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" > $O/${TAG}_sq_passes.log 2>&1
 ls -la $O | grep $TAG
