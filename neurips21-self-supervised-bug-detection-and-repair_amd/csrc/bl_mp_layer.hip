@@ -11,7 +11,7 @@
 //             folded concat)
 // The caller owns every buffer: `saved` lives from forward to backward, `ws` only during the call
 // (sizes from bl_mp_layer_saved_bytes / bl_mp_layer_workspace_bytes); nothing is allocated here except three
-// HIP events (once per process) used to fork / join the side stream.
+// HIP events per device (created once) used to fork / join the side stream.
 #include <vector>
 
 #include "bl_common.h"
@@ -166,12 +166,20 @@ WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool full_g
 
 bool g_fused_node_bwd = true;  // bl_set_fused_node_bwd: act backward -> dense input gradient -> LayerNorm backward in one kernel
 
-hipEvent_t g_fork1 = nullptr, g_fork2 = nullptr, g_join = nullptr;
-bool ensure_events() {
-  if (g_join) return true;
-  return hipEventCreateWithFlags(&g_fork1, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&g_fork2, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&g_join, hipEventDisableTiming) == hipSuccess;
+// fork / join events of the side stream, one set per device (a process that drives several GPUs -- tests, tools -- must not
+// record an event created on another device)
+constexpr int kMaxDevices = 16;
+struct SideEvents { hipEvent_t fork1 = nullptr, fork2 = nullptr, join = nullptr; };
+SideEvents g_side_events[kMaxDevices];
+SideEvents* ensure_events() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  SideEvents& e = g_side_events[dev];
+  if (e.join) return &e;
+  if (hipEventCreateWithFlags(&e.fork1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e.fork2, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess)
+    return nullptr;
+  return &e;
 }
 
 int check_layer(const bl_mp_layer_t* L, const char* who) {
@@ -294,7 +302,8 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
                "bl_mp_layer_bwd: width_lo must be Din (one output) or below Din (two outputs)");
   hipStream_t st = (hipStream_t)stream, side = side_stream ? (hipStream_t)side_stream : st;
   const bool two = side != st;
-  if (two) BL_CHECK_ARG(ensure_events(), "bl_mp_layer_bwd: cannot create HIP events");
+  SideEvents* ev = two ? ensure_events() : nullptr;
+  if (two) BL_CHECK_ARG(ev != nullptr, "bl_mp_layer_bwd: cannot create HIP events");
   Saved S = carve_saved(const_cast<void*>(saved), N, E, Din, Dm, L->msg_act);
   // the input gradient from the non-zeros of the routed message gradient (vector units) when the caller supplied W^T and
   // W[t]^T fits one LDS block; node sums fused in (atomics) unless the deterministic mode asks for a fixed summation order
@@ -321,8 +330,8 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   bl_rows_packed_t p1;
   p1.xp[1] = p1.xp[2] = nullptr; p1.idx[0] = p1.idx[1] = p1.idx[2] = nullptr; p1.width[1] = p1.width[2] = 0; p1.nsrc = 1;
   if (two) {
-    (void)hipEventRecord(g_fork1, st);
-    (void)hipStreamWaitEvent(side, g_fork1, 0);
+    (void)hipEventRecord(ev->fork1, st);
+    (void)hipStreamWaitEvent(side, ev->fork1, 0);
   }
   {  // dense weight gradient, next to the input-gradient chain
     ProfScope ps(5, 2.0 * N * (double)Dm * Dout, side, two);
@@ -360,8 +369,8 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
     a.width[0] = Din; a.width[1] = Din; a.width[2] = 0;
     a.nsrc = 2;
     if (two) {
-      (void)hipEventRecord(g_fork2, st);
-      (void)hipStreamWaitEvent(side, g_fork2, 0);
+      (void)hipEventRecord(ev->fork2, st);
+      (void)hipStreamWaitEvent(side, ev->fork2, 0);
     }
     {
       ProfScope ps(8, 2.0 * E * (2.0 * Din) * Dm, side, two);
@@ -409,8 +418,8 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
                                       ld_lo, g_h_hi, ld_hi, L->node_order, st));
   }
   if (two && join_side) {
-    (void)hipEventRecord(g_join, side);
-    (void)hipStreamWaitEvent(st, g_join, 0);
+    (void)hipEventRecord(ev->join, side);
+    (void)hipStreamWaitEvent(st, ev->join, 0);
   }
   return BL_OK;
 }
