@@ -308,6 +308,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused-node-bwd", action="store_true", help="A/B: the node update's backward chain as three kernels "
                     "(act backward, dense input gradient, LayerNorm backward) instead of bl_node_update_bwd")
+    ap.add_argument("--default-stream", action="store_true", help="A/B: run the steps on the default stream instead of the trainer's "
+                    "high-priority step stream (hip_ops.use_step_stream)")
     ap.add_argument("--wgrad-kcap", type=int, default=0, help="A/B: rows per workgroup flush of the bf16x6 weight-gradient GEMMs "
                     "(hip_ops.set_wgrad_kchunk_cap); 0 = the library's default")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one gradient all-reduce per step instead of layer-wise buckets behind backward")
@@ -462,6 +464,8 @@ def main():
                 "per_gpu": a.graphs, "n_gpus": world,
                 "roofline": build_roofline(kern_, {}, prof_steps, serial_s_, rate_ / world, *fwd_work(a), brief=True)}
 
+    if not args.default_stream:
+        hip_ops.use_step_stream(device)  # what ModelTrainer.train does before its first step
     module, mb, opt = build_workload(args)
 
     step = make_step(module, mb, opt, args.graphs)

@@ -584,6 +584,41 @@ DIRECT_PARAM_GRAD = os.environ.get("BL_DIRECT_GRAD", "1") != "0"
 _held_for_side_stream: list = []  # tensors the free-running side-stream GEMMs read: kept alive until the join
 
 
+# Priority of the side stream that carries the weight-gradient GEMMs (lower number = higher priority; out-of-range values are
+# mapped to the nearest valid one).  BL_SIDE_STREAM_PRIORITY: A/B knob.
+SIDE_STREAM_PRIORITY = int(os.environ.get("BL_SIDE_STREAM_PRIORITY", "0"))
+
+
+def _new_side_stream():
+    return torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY) if SIDE_STREAM_PRIORITY != 0 else torch.cuda.Stream()
+
+
+# The training step's dependent chain (forward, the backward's input-gradient chain, clip + Adam) runs on a HIGH-priority stream,
+# the weight-gradient GEMMs that run beside it on a normal-priority one (the chip has two levels: 0 and -1): when both have
+# workgroups to place, the chain's kernels get the CUs first and the weight gradients fill what they leave -- 17.50 -> 17.33 ms
+# per step on one box, two A/B pairs (profiles/r04o_*).  BUGLAB_STEP_STREAM_PRIORITY=0 keeps the caller's stream.
+_step_streams = {}
+
+
+def use_step_stream(device=None):
+    """Make a high-priority stream the current stream of this thread (once per device; later calls re-select it).  Work queued on
+    the previous current stream is waited for.  -> the stream, or None when switched off / no GPU."""
+    if not torch.cuda.is_available() or os.environ.get("BUGLAB_STEP_STREAM_PRIORITY", "-1") == "0":
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _step_streams.get(key)
+    if st is None:
+        st = _step_streams[key] = torch.cuda.Stream(dev, priority=int(os.environ.get("BUGLAB_STEP_STREAM_PRIORITY", "-1")))
+    cur = torch.cuda.current_stream(dev)
+    if cur != st:
+        st.wait_stream(cur)
+        torch.cuda.set_stream(st)
+    return st
+
+
 def join_side_stream():
     """Make the current stream wait for every weight-gradient GEMM still running on the side stream.  What those GEMMs
     read is released only now, i.e. behind the wait in this stream's order: the allocator may hand the blocks to the next
@@ -622,7 +657,7 @@ class _on_side_stream:
         if self.enabled:
             key = torch.cuda.current_device()
             if key not in _side_streams:
-                _side_streams[key] = torch.cuda.Stream()
+                _side_streams[key] = _new_side_stream()
             self.side = _side_streams[key]
             self.main = torch.cuda.current_stream()
 
@@ -1096,7 +1131,7 @@ class _MpLayerFused(torch.autograd.Function):
         if USE_SIDE_STREAM:
             key = torch.cuda.current_device()
             if key not in _side_streams:
-                _side_streams[key] = torch.cuda.Stream()
+                _side_streams[key] = _new_side_stream()
             side = _side_streams[key]
         free_running = side is not None and direct[3] is not None and direct[4] is not None
         _check(lib.bl_mp_layer_bwd(ctypes.byref(L), out.data_ptr(), g_out.data_ptr(), _p(wnk), saved.data_ptr(), ws.data_ptr(),

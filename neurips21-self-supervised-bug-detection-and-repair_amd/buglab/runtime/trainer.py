@@ -450,6 +450,9 @@ class ModelTrainer:
         scheduler = self._scheduler_creator(optimizer) if self._scheduler_creator is not None else None
         for hook in self._training_start_hooks:
             hook(self.model, self._nn, optimizer)
+        from buglab.models import hip_ops
+
+        hip_ops.use_step_stream(device)  # the step's chain on a high-priority stream, the weight-gradient GEMMs behind it on a normal one
         rank, _ = self._world()
         best = float("-inf") if (self._target_metric is not None and self._target_higher_better) else float("inf")
         bad_epochs = 0
