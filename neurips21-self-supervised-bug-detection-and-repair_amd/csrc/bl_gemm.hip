@@ -479,7 +479,16 @@ static int gemm_rows_impl(const bl_rows_t* a, const int32_t* mask_arg, int32_t m
   dim3 grid((M + BM - 1) / BM + (group_ptr ? G : 0), (N + BN - 1) / BN);
   hipStream_t st = (hipStream_t)stream;
 #define ROWS_LAUNCH ROWS_ARGS(d), mask_arg, mask_ld, b, (long long)b_group_stride, ldb, bias, group_ptr, group_w, G, M, N, K, dd.key, dd.thresh, dd.scale, c, ldc
-#define ROWS_GO(NK_, ACT_) hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, ROWS_CFG_DEFAULT, false, BM>), grid, dim3(256), 0, st, ROWS_LAUNCH)
+  // Few row tiles (the scoring heads: 10^2 - 10^3 candidate rows): a handful of workgroups walk K in 32-wide stages, each a full
+  // global-load round trip -- the kernel's time is stages x latency (40 - 70 us for 0.1 GFLOP).  Those launches take 64-row
+  // tiles and 128-wide stages instead (one workgroup per CU, 100 KB of LDS): K = 128 ... 384 in 1 - 3 round trips.
+  const bool small = !mask_arg && (long long)grid.x * grid.y * 2 <= bl_num_cus();
+  if (small) grid.x = (M + 63) / 64 + (group_ptr ? G : 0);
+#define ROWS_GO(NK_, ACT_)                                                                                                          \
+  do {                                                                                                                              \
+    if (small) hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, 128, 1, 1, false, 64>), grid, dim3(256), 0, st, ROWS_LAUNCH);        \
+    else hipLaunchKernelGGL((gemm_rows_kernel<NK_, ACT_, ROWS_CFG_DEFAULT, false, BM>), grid, dim3(256), 0, st, ROWS_LAUNCH);       \
+  } while (0)
   if (b_is_nk) {
     BL_CHECK_ARG(act == BL_ACT_NONE, "bl_gemm_rows: the transposed-B (input gradient) form takes no activation");
     if (mask_arg)
@@ -572,6 +581,8 @@ static int gemm_wgrad_impl(const bl_rows_t* a, const float* g_c, int32_t ld_g, c
                          g_c, ld_g, g_idx, g_mask, ld_mask, group_ptr, group_w, G, M, N, K, kchunk, gw,                      \
                          (long long)gw_group_stride, ld_gw, ntiles_n, order_ctr);                                            \
   }
+  // (128-row stages for launches with few rows, as in bl_gemm_rows, were measured slower here: 37 - 45 vs 28 - 43 us per launch
+  // at the heads' shapes, profiles/r04r_trace.csv)
   WGRAD_GO(32, 1, 2)
   BL_LAUNCH_CHECK("bl_gemm_wgrad");
   return BL_OK;

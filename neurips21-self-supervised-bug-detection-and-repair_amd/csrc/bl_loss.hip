@@ -40,16 +40,27 @@ __global__ __launch_bounds__(LOSS_THREADS) void bug_loss_fwd_kernel(bl_bug_loss_
   // ---- localization: one wave per graph ------------------------------------------------------------------------------
   for (int b = wave; b < d.B; b += LOSS_WAVES) {
     const int beg = d.loc_group_ptr[b], end = d.loc_group_ptr[b + 1];
-    float m = NEG_INF_F;
-    for (int i = beg + lane; i < end; i += 64) m = fmaxf(m, loc_value(d, d.loc_group_items[i]));
-    m = bl_wave_max(m);
-    float s = 0.f;
-    for (int i = beg + lane; i < end; i += 64) s += expf(loc_value(d, d.loc_group_items[i]) - m);
-    s = bl_wave_sum(s);
-    const float lz = logf(s + LSM_EPS);
-    for (int i = beg + lane; i < end; i += 64) {
-      const int it = d.loc_group_items[i];
-      loc_lp[it] = (loc_value(d, it) - m) - lz;
+    float m = NEG_INF_F, lz;
+    if (end - beg <= 64) {
+      // the usual case (tens of candidate locations per graph): every lane keeps its one item and value -- one dependent
+      // round of loads instead of three (same arithmetic in the same order: a lane of the loops below has one term too)
+      const int it = beg + lane < end ? d.loc_group_items[beg + lane] : -1;
+      const float v = it >= 0 ? loc_value(d, it) : NEG_INF_F;
+      m = bl_wave_max(v);
+      const float s = bl_wave_sum(it >= 0 ? expf(v - m) : 0.f);
+      lz = logf(s + LSM_EPS);
+      if (it >= 0) loc_lp[it] = (v - m) - lz;
+    } else {
+      for (int i = beg + lane; i < end; i += 64) m = fmaxf(m, loc_value(d, d.loc_group_items[i]));
+      m = bl_wave_max(m);
+      float s = 0.f;
+      for (int i = beg + lane; i < end; i += 64) s += expf(loc_value(d, d.loc_group_items[i]) - m);
+      s = bl_wave_sum(s);
+      lz = logf(s + LSM_EPS);
+      for (int i = beg + lane; i < end; i += 64) {
+        const int it = d.loc_group_items[i];
+        loc_lp[it] = (loc_value(d, it) - m) - lz;
+      }
     }
     // arg-max over the graph's candidate rows (contiguous rows candidate_ptr[b] .. candidate_ptr[b+1]); ties -> first row
     const int c0 = d.candidate_ptr[b], c1 = d.candidate_ptr[b + 1];
@@ -82,15 +93,24 @@ __global__ __launch_bounds__(LOSS_THREADS) void bug_loss_fwd_kernel(bl_bug_loss_
     const int beg = d.repair_group_ptr[g], end = d.repair_group_ptr[g + 1];
     if (beg == end) { if (lane == 0) gmax[g] = NEG_INF_F; continue; }
     float m = NEG_INF_F;
-    for (int i = beg + lane; i < end; i += 64) m = fmaxf(m, d.repair_logits[d.repair_group_items[i]]);
-    m = bl_wave_max(m);
-    float s = 0.f;
-    for (int i = beg + lane; i < end; i += 64) s += expf(d.repair_logits[d.repair_group_items[i]] - m);
-    s = bl_wave_sum(s);
-    const float lz = logf(s + LSM_EPS);
-    for (int i = beg + lane; i < end; i += 64) {
-      const int it = d.repair_group_items[i];
-      rep_lp[it] = (d.repair_logits[it] - m) - lz;
+    if (end - beg <= 64) {  // (one item per lane, as above)
+      const int it = beg + lane < end ? d.repair_group_items[beg + lane] : -1;
+      const float v = it >= 0 ? d.repair_logits[it] : NEG_INF_F;
+      m = bl_wave_max(v);
+      const float s = bl_wave_sum(it >= 0 ? expf(v - m) : 0.f);
+      const float lz = logf(s + LSM_EPS);
+      if (it >= 0) rep_lp[it] = (v - m) - lz;
+    } else {
+      for (int i = beg + lane; i < end; i += 64) m = fmaxf(m, d.repair_logits[d.repair_group_items[i]]);
+      m = bl_wave_max(m);
+      float s = 0.f;
+      for (int i = beg + lane; i < end; i += 64) s += expf(d.repair_logits[d.repair_group_items[i]] - m);
+      s = bl_wave_sum(s);
+      const float lz = logf(s + LSM_EPS);
+      for (int i = beg + lane; i < end; i += 64) {
+        const int it = d.repair_group_items[i];
+        rep_lp[it] = (d.repair_logits[it] - m) - lz;
+      }
     }
     if (lane == 0) gmax[g] = m;
   }
@@ -169,6 +189,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void bug_loss_bwd_kernel(bl_bug_loss_
   // log-softmax backward per segment: g_x = g_y - exp(y) * sum_seg g_y   (the NO_BUG logit is a constant: no output)
   for (int b = wave; b < d.B; b += LOSS_WAVES) {
     const int beg = d.loc_group_ptr[b], end = d.loc_group_ptr[b + 1];
+    if (end - beg <= 64) {  // one item per lane: its index, gradient and log-probability are loaded once
+      const int it = beg + lane < end ? d.loc_group_items[beg + lane] : -1;
+      const float gy = it >= 0 ? gy_loc[it] : 0.f;
+      const float lp = (it >= 0 && it < d.C) ? loc_lp[it] : 0.f;
+      const float s = bl_wave_sum(gy);
+      if (it >= 0 && it < d.C) g_scores[it] = gy - expf(lp) * s;
+      continue;
+    }
     float s = 0.f;
     for (int i = beg + lane; i < end; i += 64) s += gy_loc[d.loc_group_items[i]];
     s = bl_wave_sum(s);
@@ -179,6 +207,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void bug_loss_bwd_kernel(bl_bug_loss_
   }
   for (int g = wave; g < d.G; g += LOSS_WAVES) {
     const int beg = d.repair_group_ptr[g], end = d.repair_group_ptr[g + 1];
+    if (end - beg <= 64) {
+      const int it = beg + lane < end ? d.repair_group_items[beg + lane] : -1;
+      const float gy = it >= 0 ? gy_rep[it] : 0.f;
+      const float lp = it >= 0 ? rep_lp[it] : 0.f;
+      const float s = bl_wave_sum(gy);
+      if (it >= 0) g_logits[it] = gy - expf(lp) * s;
+      continue;
+    }
     float s = 0.f;
     for (int i = beg + lane; i < end; i += 64) s += gy_rep[d.repair_group_items[i]];
     s = bl_wave_sum(s);

@@ -736,8 +736,8 @@ def test_forward_only_layer_call_without_edges():
     assert torch.equal(outs[0], outs[1]) and float((outs[0] - ref).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("w_buggy,abstain", [(1.0, 0.0), (2.5, 0.0), (1.0, 0.35), (0.4, 0.2)])
-def test_fused_loss_assembly_equals_the_op_by_op_path(w_buggy, abstain):
+@pytest.mark.parametrize("w_buggy,abstain,ncand", [(1.0, 0.0, 9), (2.5, 0.0, 9), (1.0, 0.35, 9), (0.4, 0.2, 9), (2.5, 0.35, 90)])
+def test_fused_loss_assembly_equals_the_op_by_op_path(w_buggy, abstain, ncand):
     """hip_ops.bug_loss (one kernel per direction for localizationmodule.py:63-124 + gnn.py:221-251,295-311 + the fixers'
     forward()s) against the same arithmetic done op by op (which the reference-generated goldens pin): loss, every
     parameter gradient, and every metric -- for a buggy-sample weight != 1 and an abstain weight too."""
@@ -748,7 +748,9 @@ def test_fused_loss_assembly_equals_the_op_by_op_path(w_buggy, abstain):
     from buglab.models import hip_ops
     from buglab.models.gnn import build_gnn_mlp_module, const_weight_schedule
 
-    mb = to_device(collate_samples(make_samples(7, seed=21, num_nodes=90, num_messages=400, num_edge_types=5, vocab_size=300, num_candidates=9), 5), "cuda")
+    # (ncand = 90: location groups of more than 64 entries take the loss kernels' looping path, the others their one-item-per-lane path)
+    mb = to_device(collate_samples(make_samples(7, seed=21, num_nodes=max(90, 2 * ncand), num_messages=400, num_edge_types=5, vocab_size=300,
+                                                num_candidates=ncand), 5), "cuda")
     res = {}
     for fused in (True, False):
         torch.manual_seed(4)
