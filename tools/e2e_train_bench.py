@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--no-prestart", action="store_true", help="do not fork the next epoch's loaders ahead of time (what train() does "
                     "before it runs validation); the stand-in for the validation pass here is a --validation-s pause")
     ap.add_argument("--validation-s", type=float, default=1.0)
+    ap.add_argument("--real-validation", type=int, default=0, help="run ModelTrainer._run_validation on a separate dataset of this many "
+                    "shards between the epochs (what train() does) instead of the --validation-s pause")
     a = ap.parse_args()
     os.environ["BUGLAB_LOADER_WORKERS"] = str(a.workers)
 
@@ -49,6 +51,12 @@ def main():
     for i in range(a.shards):
         save_msgpack_l_gz(base, os.path.join(d, f"s{i:03d}.msgpack.l.gz"))  # the same graphs in every shard: only rates matter here
     ds = ShardDataset(d, shuffle=True)
+    val_ds = None
+    if a.real_validation > 0:
+        dv = tempfile.mkdtemp()
+        for i in range(a.real_validation):
+            save_msgpack_l_gz(base, os.path.join(dv, f"v{i:03d}.msgpack.l.gz"))
+        val_ds = ShardDataset(dv, shuffle=False)  # a different dataset object, as train.py passes one
     # minibatches as large as the headline config's (64 graphs / ~128k nodes) instead of the registry's 30k-node cap
     model, _, _ = load_model({"modelName": "gnn-mlp", "stop_extending_minibatch_after_num_nodes": 64 * a.nodes * 2}, Path(d) / "m.pkl.gz")
     for x in list(ds)[:per]:
@@ -111,7 +119,13 @@ def main():
         if epoch > 0:
             if not a.no_prestart:
                 trainer._prestart_loaders(ds, epoch, True)
-            time.sleep(a.validation_s)  # (stand-in for the validation pass between two training epochs)
+            if val_ds is not None:
+                tv = time.perf_counter()
+                trainer._run_validation(val_ds, epoch, float("inf"), device, True, False)
+                torch.cuda.synchronize()
+                print(f"         validation on {a.real_validation} shards ({a.real_validation * per} graphs): {time.perf_counter() - tv:.2f} s")
+            else:
+                time.sleep(a.validation_s)  # (stand-in for the validation pass between two training epochs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if a.profile and epoch == 1:
