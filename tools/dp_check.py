@@ -36,6 +36,7 @@ def main():
     rank, world, device = D.init_from_env("cuda")
     assert world == 2
     hip_ops.load_library()
+    hip_ops.use_step_stream(device)  # what ModelTrainer.train does: the step's chain on the high-priority stream
     sizes = (5, 3)
     samples = make_samples(sum(sizes), seed=7, num_nodes=300, num_messages=1500, num_edge_types=8, vocab_size=2000)
     lo = sum(sizes[:rank])
