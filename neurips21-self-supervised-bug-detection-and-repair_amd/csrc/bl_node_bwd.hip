@@ -24,9 +24,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef NB_ABLATE
-#define NB_ABLATE 0  // experiment builds (tools/experiments/node_bwd_variants.sh): 1 no bias sums, 2 no gamma / beta sums, 4 no gq stores,
-#endif               // 8 no packed g_z store, 16 no MFMAs, 32 no dact load
 #define NB_ROWS 64   // nodes per tile
 #define NB_XROW 13   // uint4 per LDS row: 4 k-groups x 3 planes + 1 pad (bl_gemm_x6.hip's stage layout)
 #define NB_PK(a_, b_) ((uint32_t)(a_) | ((uint32_t)(b_) << 16))
@@ -168,13 +165,11 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
     As[p_row * NB_XROW + 8 + p_kg] = pl_;                                                    \
     if (a_ok) {                                                                              \
       uint4* o_ = gz_packed + a_row * 3 * kq + (c0_ >> 3);                                   \
-      if (!(NB_ABLATE & 8)) {                                                                \
-        o_[0] = ph_;                                                                         \
-        o_[kq] = pm_;                                                                        \
-        o_[2 * kq] = pl_;                                                                    \
-      }                                                                                      \
+      o_[0] = ph_;                                                                           \
+      o_[kq] = pm_;                                                                          \
+      o_[2 * kq] = pl_;                                                                      \
     }                                                                                        \
-    if (g_bias && !(NB_ABLATE & 1)) { /* column sums of the wave's 16 rows (rows past the end hold zeros), then one LDS add */ \
+    if (g_bias) { /* column sums of the wave's 16 rows (rows past the end hold zeros), then one LDS add */ \
       const float tot_ = rowgroup_reduce8(gg_, lane);                                        \
       if (lane < 32) atomicAdd(&bias_s[c0_ + ((lane >> 2) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1)], tot_); \
     }                                                                                        \
@@ -201,7 +196,6 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
       const bf16x8 bm = __builtin_bit_cast(bf16x8, pb[4]);                                   \
       const bf16x8 bl = __builtin_bit_cast(bf16x8, pb[8]);                                   \
       f32x16 a = acc[f]; /* B fragment in the A slot: transposed accumulator; small terms first (bl_gemm_x6.hip) */ \
-      if (NB_ABLATE & 16) { asm volatile("" ::"v"(bh), "v"(bm), "v"(bl), "v"(ah), "v"(am), "v"(al)); continue; } \
       a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm, am, a, 0, 0, 0);                       \
       a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, a, 0, 0, 0);                       \
       a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, a, 0, 0, 0);                       \
@@ -272,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
       for (int gq = 0; gq < 4; ++gq) {
         const float4 g4 = *reinterpret_cast<const float4*>(gam_r + 32 * f + 8 * gq);
         float4 p4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (dact && !(NB_ABLATE & 32)) p4 = *reinterpret_cast<const float4*>(dact_r + 32 * f + 8 * gq);
+        if (dact) p4 = *reinterpret_cast<const float4*>(dact_r + 32 * f + 8 * gq);
         const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, pv[4] = {p4.x, p4.y, p4.z, p4.w};
         float xv[4] = {0.f, 0.f, 0.f, 0.f};
         if (!KEEP_X) {
@@ -291,9 +285,8 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
         *reinterpret_cast<float4*>(stage + li * ST_LD + 32 * f + 8 * gq + 4 * half) = make_float4(gx[0], gx[1], gx[2], gx[3]);
       }
       // column sums of this fragment over the wave's 32 rows -> LDS (the two row halves of the tile add into the same cells)
-      float tg = dg[0], tb = db[0];
-      if (!(NB_ABLATE & 2)) { tg = colreduce16(dg, li); tb = colreduce16(db, li); }
-      if (!(li & 16) && !(NB_ABLATE & 2)) {
+      const float tg = colreduce16(dg, li), tb = colreduce16(db, li);
+      if (!(li & 16)) {
         const int slot = colreduce16_slot(li);  // = 4 gq + u
         const int c = cbase + 32 * f + 8 * (slot >> 2) + (slot & 3);
         atomicAdd(&cs_s[0][c], tg);
@@ -303,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
     }
     // ---- write-out: whole row pieces (Dm/2 columns = 256 / 512 B in fp32, 128 / 256 B per packed plane) per group of lanes ----
     __syncthreads();
-    if (!(NB_ABLATE & 4)) {
+    {
       constexpr int LPR = Dm / 8, RP = 64 / LPR;  // lanes per row piece, rows per pass
       const int c4 = lane % LPR, rsub = lane / LPR;
       const int col = wn * (Dm / 2) + 4 * c4;
