@@ -204,7 +204,10 @@ template <bool MASKED, int EPI>
 #ifndef X6_MASKED_WGS
 #define X6_MASKED_WGS 2  // workgroups per CU the routed form is compiled for (3: 168 registers with 11 of them in scratch)
 #endif
-__global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : 3) void gemm_rows_x6_kernel(
+#ifndef X6_PLAIN_WGS
+#define X6_PLAIN_WGS 3
+#endif
+__global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void gemm_rows_x6_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
     int koff1, int koff2, int nsrc, const uint32_t* __restrict__ win_bits, int ld_bits, const uint4* __restrict__ bp,
