@@ -207,6 +207,10 @@ template <bool MASKED, int EPI>
 #ifndef X6_PLAIN_WGS
 #define X6_PLAIN_WGS 3
 #endif
+#ifndef X6_ABLATE
+#define X6_ABLATE 0  // experiment builds (tools/experiments/variant_lib.sh): 1 A rows not gathered (tile-local rows: L2 hits), 2 no MFMAs,
+#endif               // 4 no result stores
+
 __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void gemm_rows_x6_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
     gr0[i] = idx0 ? idx0[r] : r;
     gr1[i] = nsrc > 1 ? (idx1 ? idx1[r] : r) : 0;
     gr2[i] = nsrc > 2 ? (idx2 ? idx2[r] : r) : 0;
+    if (X6_ABLATE & 1) { gr0[i] = gr1[i] = gr2[i] = p_row0 + 64 * i; }
   }
   uint4 ra[2][3], rb[2][3];
   uint32_t ma[2];
@@ -317,12 +322,27 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
         bl[tj] = __builtin_bit_cast(bf16x8, p[8]);
       }
       // swapped operands (B fragment in the A slot): the accumulator holds the transposed tile, so
-      // a lane owns 4 consecutive columns of one row -> float4 epilogue stores.  Small terms first.
+      // a lane owns 4 consecutive columns of one row.  Small terms first.  The six terms of one accumulator are written back to
+      // back (hipcc alternates between two accumulators); X6_TERM_MAJOR=1 lets the four accumulators take turns instead --
+      // measured equal (profiles/r04y_term_major.log): a dependent MFMA two issue slots later does not stall
+#ifndef X6_TERM_MAJOR
+#define X6_TERM_MAJOR 0
+#endif
+#if X6_TERM_MAJOR
+#define X6_TERM(bx_, ax_)                                                                              \
+  _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) {  \
+    if (X6_ABLATE & 2) { asm volatile("" ::"v"(bx_[tj]), "v"(ax_[ti])); continue; }                    \
+    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_[tj], ax_[ti], acc[ti][tj], 0, 0, 0);      \
+  }
+      X6_TERM(bm, am) X6_TERM(bl, ah) X6_TERM(bh, al) X6_TERM(bm, ah) X6_TERM(bh, am) X6_TERM(bh, ah)
+#undef X6_TERM
+#else
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
           f32x16 a = acc[ti][tj];
+          if (X6_ABLATE & 2) { asm volatile("" ::"v"(bm[tj]), "v"(am[ti]), "v"(bl[tj]), "v"(ah[ti]), "v"(bh[tj]), "v"(al[ti])); continue; }
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[tj], am[ti], a, 0, 0, 0);
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[tj], ah[ti], a, 0, 0, 0);
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], al[ti], a, 0, 0, 0);
@@ -331,6 +351,7 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], ah[ti], a, 0, 0, 0);
           acc[ti][tj] = a;
         }
+#endif
     }
     __syncthreads();
     if (kt + 1 < nk) {
@@ -390,7 +411,7 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
       const int r = (lane >> 4) + 4 * j;
       const int mm = wm * 64 + ti * 32 + r;
       const float4 v = *reinterpret_cast<const float4*>(stage + r * 68 + 4 * c4);
-      if (mm < nrows && n < N) *reinterpret_cast<float4*>(c + (size_t)(row0 + mm) * ldc + n) = v;
+      if (mm < nrows && n < N && !(X6_ABLATE & 4)) *reinterpret_cast<float4*>(c + (size_t)(row0 + mm) * ldc + n) = v;
     }
 #endif
   }
