@@ -5,10 +5,12 @@
 //   forward   pack h (one or two sources: a ConcatResidual input [stash ; current] is packed in place, no
 //             concatenated copy) -> bf16x6 message GEMM -> segmented max + GELU + LayerNorm (+ routing bitmask,
 //             activation derivative at the winners) -> dense + tanh + dropout
-//   backward  act/dropout backward (+ bias gradient) -> dense weight gradient (side stream) || dense input
-//             gradient -> LayerNorm backward (packed result) -> routed bf16x6 weight gradient (side stream) ||
-//             routed bf16x6 input gradient -> segmented sums over the src / tgt CSRs (two outputs for a
+//   backward  node update's backward in one kernel (bl_node_update_bwd: act/dropout backward + bias gradient, dense input
+//             gradient, LayerNorm backward, packed results; three kernels where its shapes do not apply) -> dense weight
+//             gradient (side stream) || routed bf16x6 weight gradient (side stream) || routed input gradient (vector
+//             units from the non-zeros, or bf16x6 GEMM) -> segmented sums over the src / tgt CSRs (two outputs for a
 //             folded concat)
+//   forward-only (saved == NULL): the same forward without any store that only a backward pass reads
 // The caller owns every buffer: `saved` lives from forward to backward, `ws` only during the call
 // (sizes from bl_mp_layer_saved_bytes / bl_mp_layer_workspace_bytes); nothing is allocated here except three
 // HIP events per device (created once) used to fork / join the side stream.
