@@ -31,7 +31,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define XBM 128
 #define XBN 128
-#define XROW 13  // uint4 per LDS row: 4 k-groups x 3 planes + 1 pad
+// LDS row of a stage image: [plane (3)][k-group slot (4)] x 16 B, in one of two layouts:
+//   padded    208-byte rows (13 uint4): fragment reads conflict-free, the staging stores' 16-lane groups overlap in 4 of 64 banks
+//             (SQ_LDS_BANK_CONFLICT a third of SQ_LDS_IDX_ACTIVE, profiles/r04z_fwd_gemm_pmc.json);
+//   swizzled  192-byte rows, k-group kg of a row in slot kg ^ ((row >> 2) & 3): four consecutive rows' 64-byte plane segments tile
+//             the 64 banks and the reads of 16 consecutive rows hit 16 different (segment, slot) pairs -- conflict-free both ways.
+// Measured (profiles/r04y_swizzle.log): the routed form gains 2 % (H = 128 layer) / 4.3 % (concat layer), the plain form loses 2 %
+// at the H = 128 layer (equal at the concat layer).  So: swizzled for the routed form, padded for the plain one (X6_SWZ: 0 = padded
+// everywhere, 1 = swizzled everywhere, 2 = as measured).
+#ifndef X6_SWZ
+#define X6_SWZ 2
+#endif
+#define X6_SWIZZLED(masked_) (X6_SWZ == 1 || (X6_SWZ == 2 && (masked_)))
+#define XROW_MAX 13
 
 
 // ---- packing ------------------------------------------------------------------------------------
@@ -218,6 +230,9 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
     long long strideB, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G, int M, int N, int K,
     float* __restrict__ c, int ldc, int xcd_remap, X6Epi epi) {
   // one array: after the last stage the four waves' result tiles are staged in it on their way out (see the epilogue)
+  constexpr bool SWZ = X6_SWIZZLED(MASKED);
+  constexpr int XROW = SWZ ? 12 : 13;
+#define XSLOT(row_, kg_) (SWZ ? ((kg_) ^ (((row_) >> 2) & 3)) : (kg_))
   __shared__ uint4 ABs[(XBM + XBN) * XROW];
   uint4* As = ABs;
   uint4* Bs = ABs + XBM * XROW;
@@ -282,8 +297,8 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
       _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                         \
         uint4 a_ = ra[i][p];                                                                                  \
         a_.x &= keep_.x; a_.y &= keep_.y; a_.z &= keep_.z; a_.w &= keep_.w;                                   \
-        As[row_ * XROW + p * 4 + p_kg] = a_;                                                                  \
-        Bs[row_ * XROW + p * 4 + p_kg] = nok_ ? rb[i][p] : make_uint4(0u, 0u, 0u, 0u);                        \
+        As[row_ * XROW + p * 4 + XSLOT(row_, p_kg)] = a_;                                                     \
+        Bs[row_ * XROW + p * 4 + XSLOT(row_, p_kg)] = nok_ ? rb[i][p] : make_uint4(0u, 0u, 0u, 0u);           \
       }                                                                                                       \
     }                                                                                                         \
   }
@@ -309,14 +324,14 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
       bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti) {
-        const uint4* p = &As[(wm * 64 + ti * 32 + li) * XROW + kg];
+        const uint4* p = &As[(wm * 64 + ti * 32 + li) * XROW + XSLOT(li, kg)];
         ah[ti] = __builtin_bit_cast(bf16x8, p[0]);
         am[ti] = __builtin_bit_cast(bf16x8, p[4]);
         al[ti] = __builtin_bit_cast(bf16x8, p[8]);
       }
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
-        const uint4* p = &Bs[(wn * 64 + tj * 32 + li) * XROW + kg];
+        const uint4* p = &Bs[(wn * 64 + tj * 32 + li) * XROW + XSLOT(li, kg)];
         bh[tj] = __builtin_bit_cast(bf16x8, p[0]);
         bm[tj] = __builtin_bit_cast(bf16x8, p[4]);
         bl[tj] = __builtin_bit_cast(bf16x8, p[8]);
@@ -416,6 +431,8 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
 #endif
   }
 }
+
+#undef XSLOT
 
 // ---- weight-gradient GEMM -------------------------------------------------------------------------
 // gW_g[i, n] += sum_{e in group g} A[e, i] * Gr[e, n]     A = gathered packed rows (h[src] | h[tgt]),
