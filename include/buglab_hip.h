@@ -133,7 +133,8 @@ int bl_pack_bf16x3_cols(const float* x, int32_t ld, int64_t R, int32_t D, int32_
 int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t N, int32_t w_is_kn, uint16_t* out, void* stream);
 /* All the operand copies of the weights a training step needs, in ONE launch (they are re-made after every optimiser
  * step): a table of jobs in DEVICE memory, built once per model.  kind 0 / 1 = bl_pack_weights_x6 with w_is_kn = kind
- * (w [G][N][K] / [G][K][N]); kind 2 = the fp32 transpose out[g][n][k] = w[g][k][n] (the W^T of bl_routed_dgrad_nodes).
+ * (w [G][N][K] / [G][K][N]); kind 2 = the fp32 transpose out[g][n][k] = w[g][k][n] (the W^T of bl_routed_dgrad_nodes);
+ * kind 3 / 4 = bl_pack_weights_x6w (the wide row GEMM's image) with w_is_kn = kind - 3.
  * first_block = sum of bl_pack_job_blocks(...) of the jobs before; total_blocks = that sum over all jobs. */
 typedef struct {
   const float* w;
@@ -146,6 +147,20 @@ int bl_pack_weights_multi(const bl_pack_job_t* jobs_device, int32_t njobs, int32
 int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                     int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
                     int32_t N, int32_t K, float* c, int32_t ldc, void* stream);
+/* Wide form of bl_gemm_rows_x6 (csrc/bl_gemm_x6w.hip): 128 x 256 output tile, 8 waves, operands DMA'd into a double-buffered
+ * LDS image (global_load_lds), ping-pong schedule.  Same contract, same summation order per element -- results are bit-identical
+ * to bl_gemm_rows_x6 -- for the message GEMMs with >= 256 output columns and long K (ptgnn MlpMessagePassingLayer's per-type
+ * Linear and its input gradient, call site buglab/models/gnnlayerdefs.py:6-23: the ConcatResidual layers of the hidden-128
+ * model, every layer at hidden 256).  Shapes: bl_gemm_rows_x6w_ok(N, K) -- N a multiple of 256, K a multiple of 64.  The
+ * weights come in their own image, bl_pack_weights_x6w (a 48 KB block per group, 256-column tile and 32-k stage in the exact
+ * LDS layout; bl_packed_weight_elems_x6w uint16 elements; kinds 3 / 4 of bl_pack_weights_multi).  bl_set_rows_tile(128) makes bl_gemm_rows_x6w_ok return 0 (measurement switch; returns the previous tile). */
+int32_t bl_gemm_rows_x6w_ok(int32_t N, int32_t K);
+int32_t bl_set_rows_tile(int32_t cols);
+int64_t bl_packed_weight_elems_x6w(int32_t G, int32_t K, int32_t N);
+int bl_pack_weights_x6w(const float* w, int32_t G, int32_t K, int32_t N, int32_t w_is_kn, uint16_t* out, void* stream);
+int bl_gemm_rows_x6w(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
+                     int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
+                     int32_t N, int32_t K, float* c, int32_t ldc, void* stream);
 /* the same with bl_gemm_rows' epilogue, C = drop(act(A . B_g + bias)): ptgnn MlpMessagePassingLayer's dense node update
  * Linear -> tanh -> Dropout (call site buglab/models/gnnlayerdefs.py:6-23) on the bf16 matrix cores */
 int bl_gemm_rows_x6_epi(const bl_rows_packed_t* a, const uint16_t* bp, int64_t b_group_stride, const int32_t* group_ptr,
@@ -327,7 +342,11 @@ typedef struct {
 int64_t bl_mp_layer_saved_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t msg_act);
 int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din, int32_t Dm, int32_t Dout, int32_t backward);
 /* uint16 elements of the packed weights a layer call takes: bl_pack_weights_x6(W, T, 2 Din, Dm, w_is_kn = 1) for
- * forward, bl_pack_weights_x6(W, T, Dm, 2 Din, w_is_kn = 0) for backward (pack once per optimiser step) */
+ * forward, bl_pack_weights_x6(W, T, Dm, 2 Din, w_is_kn = 0) for backward (pack once per optimiser step) -- or, where
+ * bl_mp_layer_weight_image(Din, Dm, for_backward) returns 1 (the layer's GEMM of that direction has a multiple of 256
+ * output columns: the wide row GEMM runs it), bl_pack_weights_x6w with the same arguments.  The answer depends on the shape
+ * and on bl_set_rows_tile only: choose the tile before packing. */
+int32_t bl_mp_layer_weight_image(int32_t Din, int32_t Dm, int32_t for_backward);
 int64_t bl_mp_layer_packed_weight_elems(int32_t T, int32_t Din, int32_t Dm, int32_t for_backward);
 
 /* forward.  The layer input is h_lo [N, width_lo] alone (h_hi NULL, width_lo == Din) or the virtual concatenation

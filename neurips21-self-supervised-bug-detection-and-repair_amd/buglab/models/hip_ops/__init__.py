@@ -81,6 +81,11 @@ _SIGNATURES = {
     "bl_pack_job_blocks": ([c_int32, c_int32, c_int32, c_int32], c_int64),
     "bl_pack_weights_multi": ([c_void_p, c_int32, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gemm_rows_x6w_ok": ([c_int32, c_int32], c_int32),
+    "bl_set_rows_tile": ([c_int32], c_int32),
+    "bl_packed_weight_elems_x6w": ([c_int32, c_int32, c_int32], c_int64),
+    "bl_pack_weights_x6w": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gemm_rows_x6w": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6_epi": ([POINTER(bl_rows_packed_t), c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32,
                              bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
@@ -99,6 +104,7 @@ _SIGNATURES = {
     "bl_mp_layer_saved_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
     "bl_mp_layer_workspace_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
     "bl_mp_layer_packed_weight_elems": ([c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_mp_layer_weight_image": ([c_int32, c_int32, c_int32], c_int32),
     "bl_mp_layer_fwd": ([POINTER(bl_mp_layer_t), c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_mp_layer_bwd": ([POINTER(bl_mp_layer_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32], ctypes.c_int),
@@ -368,8 +374,23 @@ def pack_weights_x6(w: torch.Tensor, w_is_kn: bool) -> torch.Tensor:
     return out
 
 
+def rows_x6w_ok(N: int, K: int) -> bool:
+    """Shapes the wide row GEMM takes (bl_gemm_rows_x6w_ok: N a multiple of 256, K of 64)."""
+    return bool(load_library().bl_gemm_rows_x6w_ok(int(N), int(K)))
+
+
+def pack_weights_x6w(w: torch.Tensor, w_is_kn: bool) -> torch.Tensor:
+    """fp32 weights -> the weight image of gemm_rows_x6(..., wide=True) (bl_pack_weights_x6w; same shapes as pack_weights_x6)."""
+    _f32(w, "w")
+    G, K, N = (w.shape[0], w.shape[1], w.shape[2]) if w_is_kn else (w.shape[0], w.shape[2], w.shape[1])
+    lib = load_library()
+    out = torch.empty((G, int(lib.bl_packed_weight_elems_x6w(1, K, N))), dtype=torch.int16, device=w.device)
+    _check(lib.bl_pack_weights_x6w(w.data_ptr(), G, K, N, 1 if w_is_kn else 0, out.data_ptr(), _stream()), "bl_pack_weights_x6w")
+    return out
+
+
 def gemm_rows_x6(sources, bp, M, N, *, group_ptr=None, group_w=None, G=1, win_bits=None, kind="gemm_rows_x6", bias=None, act=None,
-                 drop: "Dropout" = None):
+                 drop: "Dropout" = None, wide: bool = False):
     """sources: [(packed int16 [*, 3*width], row index or None, width)]; bp: pack_weights_x6 output [G, *];
     win_bits: segment_max's per-row routing bitmask -> the routed (winner-masked) left operand;
     bias / act / drop: the epilogue drop(act(. + bias)) of bl_gemm_rows_x6_epi."""
@@ -392,6 +413,14 @@ def gemm_rows_x6(sources, bp, M, N, *, group_ptr=None, group_w=None, G=1, win_bi
                                                    _p(group_w), int(G), int(M), int(N), int(K), _p(bias), int(act or ACT_NONE),
                                                    (drop or NO_DROPOUT).c(), out.data_ptr(), out.stride(0), _stream()),
                 "bl_gemm_rows_x6_epi")
+        return out
+    if wide:  # bp = pack_weights_x6w(...): the 128 x 256-tile kernel (bit-identical results)
+        with _timed(kind + ("_grouped" if group_ptr is not None else ""), 2.0 * M * N * K):
+            _check(
+                load_library().bl_gemm_rows_x6w(ctypes.byref(r), _p(win_bits), win_bits.stride(0) if win_bits is not None else 0,
+                                                _req(bp, torch.int16, "bp").data_ptr(), int(bp.stride(0)), _p(group_ptr), _p(group_w),
+                                                int(G), int(M), int(N), int(K), out.data_ptr(), out.stride(0), _stream()),
+                "bl_gemm_rows_x6w")
         return out
     with _timed(kind + ("_grouped" if group_ptr is not None else ""), 2.0 * M * N * K):
         _check(
@@ -945,7 +974,7 @@ def _as_groups(w: torch.Tensor) -> torch.Tensor:
 # step -- in ONE launch (bl_pack_weights_multi) over a table of every copy any layer has asked for so far, instead of one
 # launch per layer and form.  Validity = (parameter object, its autograd version, the epoch bumped by whoever writes
 # parameters behind autograd's back, its storage address).
-_KIND = {"nk": 0, "kn": 1, "t": 2}
+_KIND = {"nk": 0, "kn": 1, "t": 2, "nkw": 3, "knw": 4}  # ..w: the wide row GEMM's image (bl_pack_weights_x6w)
 
 
 class _WeightCopies:
@@ -974,8 +1003,10 @@ class _WeightCopies:
                 if nm == "t":
                     ent["forms"][nm] = torch.empty((G, N, K), dtype=torch.float32, device=W.device)
                 else:  # "kn": C = A . W (K x N) ; "nk": C = G . W^T, i.e. bl_pack_weights_x6 of [G][N'][K'] with N' = K, K' = N
-                    n_out, k_in = (N, K) if nm == "kn" else (K, N)
-                    ent["forms"][nm] = torch.empty((G, ((n_out + 127) // 128) * (k_in // 32) * 12288), dtype=torch.int16, device=W.device)
+                    n_out, k_in = (N, K) if nm.startswith("kn") else (K, N)
+                    per = (int(load_library().bl_packed_weight_elems_x6w(1, k_in, n_out)) if nm.endswith("w")
+                           else ((n_out + 127) // 128) * (k_in // 32) * 12288)
+                    ent["forms"][nm] = torch.empty((G, per), dtype=torch.int16, device=W.device)
                 ent["version"] = -1  # (a new form has to be filled)
                 self.plan = None
         if not self._fresh(ent, W):
@@ -999,7 +1030,7 @@ class _WeightCopies:
                     j.w, j.out, j.kind = W.data_ptr(), out.data_ptr(), _KIND[nm]
                     # kind 1 (kn): w [G][K][N]; kind 0 (nk): bl_pack_weights_x6(w_is_kn = 0) reads w as [G][N'][K'] = [G][K][N]
                     # with output columns N' = K and contraction K' = N; kind 2: transpose of [G][K][N]
-                    j.G, j.K, j.N = (G, K, N) if nm != "nk" else (G, N, K)
+                    j.G, j.K, j.N = (G, K, N) if not nm.startswith("nk") else (G, N, K)
                     j.first_block = blocks
                     blocks += int(lib.bl_pack_job_blocks(j.kind, j.G, j.K, j.N))
                     jobs.append(j)
@@ -1021,6 +1052,19 @@ def _packed_layer_weights(W: torch.Tensor, need_bwd: bool):
     input-gradient GEMM (C = G . W[t]^T).  A 2-D weight (the dense node update's Wd [Dm, Dout]) is one group."""
     got = _weight_copies.get(W, ("kn", "nk") if need_bwd else ("kn",))
     return got[0], (got[1] if need_bwd else None)
+
+
+def _packed_message_weights(W: torch.Tensor, Din: int, need_bwd: bool):
+    """The per-type message weights W [T, 2 Din, Dm] in the images the fused layer calls expect (bl_mp_layer_weight_image): the wide
+    row GEMM's image where that kernel takes the shape, the tiled one otherwise."""
+    lib = load_library()
+    Dm = W.shape[2]
+    fwd = "knw" if lib.bl_mp_layer_weight_image(int(Din), int(Dm), 0) else "kn"
+    if not need_bwd:
+        return _weight_copies.get(W, (fwd,))[0], None
+    bwd = "nkw" if lib.bl_mp_layer_weight_image(int(Din), int(Dm), 1) else "nk"
+    got = _weight_copies.get(W, (fwd, bwd))
+    return got[0], got[1]
 
 
 # The routed input gradient of a message-passing layer from the NON-ZEROS of the message gradient, on the vector units, node
@@ -1069,7 +1113,7 @@ class _MpLayerFused(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad[:7])
         # which form of W the input gradient will read: its fp32 transpose (vector-unit path) or the packed C = G . W^T form
         use_vec = DGRAD_VEC and E > 0 and bool(lib.bl_routed_dgrad_vec_ok(Dm, K2))
-        wkn, wnk = _packed_layer_weights(W, need_bwd and not use_vec)
+        wkn, wnk = _packed_message_weights(W, Din, need_bwd and not use_vec)
         wt = _transposed_layer_weights(W) if (need_bwd and use_vec) else None
         dev = h_lo.device
         L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
@@ -1110,7 +1154,7 @@ class _MpLayerFused(torch.autograd.Function):
         if use_vec and wt is None:
             wt = _transposed_layer_weights(W)
         if wnk is None and not use_vec:  # forward ran without grad mode knowing a backward would follow
-            wnk = _packed_layer_weights(W, True)[1]
+            wnk = _packed_message_weights(W, Din, True)[1]
         direct = [_direct_small(bd), _direct_small(ln_g), _direct_small(ln_b), _direct_grad_target(Wd), _direct_grad_target(W)]
         tgt = [d if d is not None else torch.zeros_like(p) for d, p in zip(direct, (bd, ln_g, ln_b, Wd, W))]
         g_bd, g_lng, g_lnb, g_Wd, g_W = tgt

@@ -25,6 +25,8 @@
 #include <stdlib.h>
 
 #include "bl_common.h"
+#include "bl_x6_locate.h"
+#include "bl_x6w_image.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // Every operand copy a training step needs of the (just updated) weights in ONE launch: a table of jobs in device memory
 // (built once per model by the caller), job j owning the workgroups first_block[j] .. first_block[j+1].
 //   kind 0 / 1: bl_pack_weights_x6 with w_is_kn = kind;  kind 2: out[g][n][k] = w[g][k][n] in fp32 (W transposed, the
-//   operand of bl_routed_dgrad_nodes).
+//   operand of bl_routed_dgrad_nodes);  kind 3 / 4: bl_pack_weights_x6w (the wide row GEMM's image) with w_is_kn = kind - 3.
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_job_t* __restrict__ jobs, int njobs) {
   int j = 0;
   while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;  // (a few dozen jobs: a linear walk of a cached table)
@@ -121,6 +123,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_j
   const long long t = (long long)((int)blockIdx.x - job.first_block) * 256 + threadIdx.x;
   if (job.kind <= 1) {
     pack_weights_thread(job.w, job.G, job.K, job.N, job.kind, reinterpret_cast<uint4*>(job.out), t);
+  } else if (job.kind >= 3) {
+    pack_weights_wide_thread(job.w, job.G, job.K, job.N, job.kind - 3, reinterpret_cast<uint4*>(job.out), t);
   } else {
     const long long per = (long long)job.K * job.N;
     if (t >= per * job.G) return;
@@ -132,73 +136,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_j
 }
 
 // ---- GEMM -----------------------------------------------------------------------------------------
-__device__ __forceinline__ bool x6_find_piece(const int* __restrict__ group_ptr, int G, int M, int piece, int t,
-                                              int& g, int& row0, int& nrows) {
-  if (group_ptr == nullptr) {
-    g = 0;
-    row0 = t * piece;
-    if (row0 >= M) return false;
-    nrows = min(piece, M - row0);
-    return true;
-  }
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  for (int g0 = 0; g0 < G; g0 += 64) {
-    const int gi = g0 + lane;
-    const int lo = gi < G ? group_ptr[gi] : 0;
-    const int hi = gi < G ? group_ptr[gi + 1] : 0;
-    const int nt = (hi - lo + piece - 1) / piece;
-    int incl = nt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    const int excl = base + incl - nt;
-    const unsigned long long hit = __ballot(t >= excl && t < excl + nt);
-    if (hit) {
-      const int src = __ffsll((long long)hit) - 1;
-      g = g0 + src;
-      const int lo_s = __shfl(lo, src, 64), hi_s = __shfl(hi, src, 64), ex_s = __shfl(excl, src, 64);
-      row0 = lo_s + (t - ex_s) * piece;
-      nrows = min(piece, hi_s - row0);
-      return true;
-    }
-    base += __shfl(incl, 63, 64);
-  }
-  return false;
-}
-
-// routing byte (8 channels, bit c = keep channel c) -> AND-masks for the 8 packed bf16 of a plane
-// Work-item of a workgroup.  Workgroups are dealt round-robin to the 8 XCDs in linear-id order; with
-// xcd_remap every XCD gets one CONTIGUOUS range of (tile, y) work items, so its private 4 MB L2 sees
-// consecutive tiles: they share the edge type's weights, the target-sorted node rows, and -- when the
-// output has several column tiles -- the whole row tile.  Measured at c2 shapes: weight-gradient GEMM
-// 0.314 -> 0.287 ms (H=128), 1.34 -> 1.00 ms (concat layer), input-gradient GEMM 1.36 -> 1.16 ms.
-__device__ __forceinline__ bool x6_locate(const int* __restrict__ group_ptr, int G, int M, int piece, int xcd_remap,
-                                          int& tile_y, int& g, int& row0, int& nrows) {
-  int tx = blockIdx.x;
-  tile_y = blockIdx.y;
-  if (xcd_remap) {
-    // XCD c owns the work items [c q + min(c, r), ...): a bijection of [0, total) for any total
-    const int lin = blockIdx.x + blockIdx.y * gridDim.x, total = gridDim.x * gridDim.y;
-    const int q = total >> 3, r = total & 7, c = lin & 7;
-    const int v = c * q + min(c, r) + (lin >> 3);
-    tx = v / gridDim.y;
-    tile_y = v - tx * gridDim.y;
-  }
-  return x6_find_piece(group_ptr, G, M, piece, tx, g, row0, nrows);
-}
-
-__device__ __forceinline__ uint4 keep_from_bits(uint32_t b) {
-  uint4 k;
-  k.x = (__builtin_amdgcn_sbfe(b, 0, 1) & 0x0000FFFFu) | (__builtin_amdgcn_sbfe(b, 1, 1) & 0xFFFF0000u);
-  k.y = (__builtin_amdgcn_sbfe(b, 2, 1) & 0x0000FFFFu) | (__builtin_amdgcn_sbfe(b, 3, 1) & 0xFFFF0000u);
-  k.z = (__builtin_amdgcn_sbfe(b, 4, 1) & 0x0000FFFFu) | (__builtin_amdgcn_sbfe(b, 5, 1) & 0xFFFF0000u);
-  k.w = (__builtin_amdgcn_sbfe(b, 6, 1) & 0x0000FFFFu) | (__builtin_amdgcn_sbfe(b, 7, 1) & 0xFFFF0000u);
-  return k;
-}
-
+// (work-item lookup x6_find_piece / x6_locate, XCD-contiguous tile order, routing masks: bl_x6_locate.h)
 // optional epilogue of the row GEMM: C = drop(act(A . B + bias)) -- the dense node update of the message-passing layer
 // (ptgnn MlpMessagePassingLayer's Linear -> tanh -> Dropout tail; call site buglab/models/gnnlayerdefs.py:6-23)
 struct X6Epi {
@@ -949,6 +887,7 @@ extern "C" int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t 
 
 extern "C" int64_t bl_pack_job_blocks(int32_t kind, int32_t G, int32_t K, int32_t N) {
   if (kind <= 1) return ((int64_t)G * ((N + 127) / 128) * (K / 32) * 512 + 255) / 256;
+  if (kind >= 3) return ((int64_t)G * ((N + WBN - 1) / WBN) * (K / 32) * (WBN * 4) + 255) / 256;
   return ((int64_t)G * K * N + 255) / 256;
 }
 

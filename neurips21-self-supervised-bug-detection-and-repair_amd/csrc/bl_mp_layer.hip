@@ -214,7 +214,15 @@ extern "C" int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din
   if (backward) return (int64_t)carve_bwd(nullptr, N, E, Din, Dm, Dout, backward != 2).bytes;
   return (int64_t)al((size_t)E * Dm * 4);
 }
+// Which image of the per-type weights a layer call expects: 1 = bl_pack_weights_x6w (the wide row GEMM takes this shape:
+// message GEMM N = Dm, K = 2 Din; input-gradient GEMM N = 2 Din, K = Dm), 0 = bl_pack_weights_x6.
+extern "C" int32_t bl_mp_layer_weight_image(int32_t Din, int32_t Dm, int32_t for_backward) {
+  return for_backward ? bl_gemm_rows_x6w_ok(2 * Din, Dm) : bl_gemm_rows_x6w_ok(Dm, 2 * Din);
+}
+
 extern "C" int64_t bl_mp_layer_packed_weight_elems(int32_t T, int32_t Din, int32_t Dm, int32_t for_backward) {
+  if (bl_mp_layer_weight_image(Din, Dm, for_backward))
+    return for_backward ? bl_packed_weight_elems_x6w(T, Dm, 2 * Din) : bl_packed_weight_elems_x6w(T, 2 * Din, Dm);
   return (int64_t)(for_backward ? packed_w_elems(T, Dm, 2 * Din) : packed_w_elems(T, 2 * Din, Dm));
 }
 
@@ -259,10 +267,14 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
   a.idx[0] = L->msg_src; a.idx[1] = L->msg_tgt; a.idx[2] = nullptr;
   a.width[0] = Din; a.width[1] = Din; a.width[2] = 0;
   a.nsrc = 2;
-  const int64_t wstride = (int64_t)packed_w_elems(1, 2 * Din, Dm);
   {
     ProfScope ps(1, 2.0 * E * (2.0 * Din) * Dm, st, false);
-    BL_TRY(bl_gemm_rows_x6(&a, nullptr, 0, w_packed, wstride, L->type_ptr, nullptr, T, E, Dm, 2 * Din, pre, Dm, st));
+    if (bl_mp_layer_weight_image(Din, Dm, 0))  // >= 256 output columns: the wide (128 x 256 tile, LDS-DMA) form, bit-identical
+      BL_TRY(bl_gemm_rows_x6w(&a, nullptr, 0, w_packed, bl_packed_weight_elems_x6w(1, 2 * Din, Dm), L->type_ptr, nullptr, T, E, Dm,
+                              2 * Din, pre, Dm, st));
+    else
+      BL_TRY(bl_gemm_rows_x6(&a, nullptr, 0, w_packed, (int64_t)packed_w_elems(1, 2 * Din, Dm), L->type_ptr, nullptr, T, E, Dm,
+                             2 * Din, pre, Dm, st));
   }
   // dense node update on the bf16x6 path when the caller packed Wd (bl_pack_weights_x6(Wd, 1, Dm, Dout, w_is_kn = 1)): the
   // LayerNorm epilogue of the segmented max then emits its result in packed form and no fp32 copy is kept
@@ -405,8 +417,12 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
       BL_TRY(bl_routed_dgrad_vec(B.g_ln, Dm, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, 2 * Din, B.g_a, 2 * Din, st));
     } else {
       ProfScope ps(9, 2.0 * E * (2.0 * Din) * Dm, st, two);
-      BL_TRY(bl_gemm_rows_x6(&g, S.bits, Dm / 32, w_packed_bwd, (int64_t)packed_w_elems(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E,
-                             2 * Din, Dm, B.g_a, 2 * Din, st));
+      if (bl_mp_layer_weight_image(Din, Dm, 1))
+        BL_TRY(bl_gemm_rows_x6w(&g, S.bits, Dm / 32, w_packed_bwd, bl_packed_weight_elems_x6w(1, Dm, 2 * Din), L->type_ptr, nullptr, T,
+                                E, 2 * Din, Dm, B.g_a, 2 * Din, st));
+      else
+        BL_TRY(bl_gemm_rows_x6(&g, S.bits, Dm / 32, w_packed_bwd, (int64_t)packed_w_elems(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E,
+                               2 * Din, Dm, B.g_a, 2 * Din, st));
     }
   }
   if (!fused_sums) {

@@ -484,6 +484,58 @@ def test_routed_gemms_bf16x6_match_fp64(ops, Din, Dm, sizes):
     assert float((dA.cpu().double() - ref_dA).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("widths,N,sizes", [((128, 128), 256, [130, 0, 1, 700, 64]), ((256, 256), 256, [2100, 5, 300]),
+                                            ((32, 32), 512, [129, 128, 127]), ((64, 64, 128), 256, [513, 77]),
+                                            ((256,), 512, [1000])])
+def test_wide_row_gemm_is_bit_identical_to_the_128_tile(ops, widths, N, sizes):
+    """bl_gemm_rows_x6w (128 x 256 tile, LDS-DMA operands, its own weight image) is a second schedule of bl_gemm_rows_x6's
+    computation: same products, same summation order per element -> bit-identical results.  Plain form with 1..3 gathered
+    sources, ragged / empty groups, row tails; routed form (one gathered source, winner-masked) on the same shapes."""
+    rng = np.random.default_rng(5)
+    K, T, E, R = int(sum(widths)), len(sizes), int(sum(sizes)), 301
+    assert ops.rows_x6w_ok(N, K) and not ops.rows_x6w_ok(N + 32, K) and not ops.rows_x6w_ok(N, K + 32)
+    ptr = _dev(_groups(rng, sizes))
+    W = torch.randn(T, K, N) / math.sqrt(K)
+    srcs = []
+    for w in widths:
+        x = torch.randn(R, w)
+        srcs.append((ops.pack_bf16x3(_dev(x)), _dev(rng.integers(0, R, E).astype(np.int32)), w))
+    tiled, wide = ops.pack_weights_x6(_dev(W), True), ops.pack_weights_x6w(_dev(W), True)
+    ref = ops.gemm_rows_x6(srcs, tiled, E, N, group_ptr=ptr, G=T)
+    got = ops.gemm_rows_x6(srcs, wide, E, N, group_ptr=ptr, G=T, wide=True)
+    assert torch.equal(got, ref)
+    # against fp64 once more (the reference kernel has its own test; this guards the harness)
+    A = torch.cat([torch.from_numpy(_unpack3(xp.cpu().numpy(), w))[idx.cpu().long()] for xp, idx, w in srcs], -1).double()
+    want = torch.cat([A[int(ptr[t]):int(ptr[t + 1])] @ W[t].double() for t in range(T)])
+    assert float((got.cpu().double() - want).abs().max()) < 5e-5
+    # no groups at all: plain row tiles, ungathered single source
+    if len(widths) == 1:
+        xp = srcs[0][0]
+        assert torch.equal(ops.gemm_rows_x6([(xp, None, K)], wide[:1], R, N, wide=True), ops.gemm_rows_x6([(xp, None, K)], tiled[:1], R, N))
+    # routed form: C = (G_r masked by the winner bits) . W^T with W stored [T][N][K] (w_is_kn = 0)
+    gq = torch.randn(R, K)
+    bits = _dev(rng.integers(-2 ** 31, 2 ** 31, (E, K // 32)).astype(np.int32))
+    bits[::7] = 0   # messages that won nothing
+    bits[3::11] = -1  # ... or everything
+    gqp, tgt = ops.pack_bf16x3(_dev(gq)), _dev(rng.integers(0, R, E).astype(np.int32))
+    Wnk = torch.randn(T, N, K) / math.sqrt(K)
+    r_ref = ops.gemm_rows_x6([(gqp, tgt, K)], ops.pack_weights_x6(_dev(Wnk), False), E, N, group_ptr=ptr, G=T, win_bits=bits)
+    r_got = ops.gemm_rows_x6([(gqp, tgt, K)], ops.pack_weights_x6w(_dev(Wnk), False), E, N, group_ptr=ptr, G=T, win_bits=bits, wide=True)
+    assert torch.equal(r_got, r_ref)
+    prev = ops.load_library().bl_set_rows_tile(128)  # the measurement switch turns the shape predicate off
+    try:
+        assert prev == 256 and not ops.rows_x6w_ok(N, K)
+    finally:
+        ops.load_library().bl_set_rows_tile(prev)
+
+
+def _unpack3(packed: np.ndarray, width: int) -> np.ndarray:
+    """bl_pack_bf16x3 rows [R, 3 * width] int16 -> fp32 [R, width] (hi + mid + lo)."""
+    u = packed.view(np.uint16).reshape(packed.shape[0], 3, width).astype(np.uint32) << 16
+    f = u.view(np.float32)
+    return (f[:, 0].astype(np.float64) + f[:, 1] + f[:, 2]).astype(np.float32)
+
+
 @pytest.mark.parametrize("Din,Dm,sizes,split", [(64, 64, [130, 0, 1, 700, 64], None), (128, 128, [2100, 5, 300], None),
                                                  (128, 128, [900, 0, 40], 64), (64, 128, [129, 1500], 32), (128, 64, [77, 300], None)])
 def test_routed_input_gradient_from_the_nonzeros_matches_fp64(ops, Din, Dm, sizes, split):

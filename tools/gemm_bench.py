@@ -119,9 +119,21 @@ def main():
             print(f"cap {cap}: max |diff| / max |ref| = {err:.2e}", flush=True)
             assert err < 1e-5
     fns["nk_x6"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp, E, 2 * Din, group_ptr=ptr, G=T_groups, group_w=gw_t, win_bits=bits_real)
+    if ops.rows_x6w_ok(Dm, 2 * Din) and a.order == "type":  # the wide (128 x 256 tile, LDS-DMA) form of the forward GEMM: bit-identical
+        wtp_w = ops.pack_weights_x6w(W, True)
+        fns["fwd_x6w"] = lambda: ops.gemm_rows_x6([(hp, src, Din), (hp, tgt, Din)], wtp_w, E, Dm, group_ptr=ptr, G=T, wide=True)
+        same = torch.equal(fns["fwd_x6w"](), fns["fwd_x6"]())
+        print(f"fwd_x6w == fwd_x6 bit for bit: {same}", flush=True)
+        assert same
+    if ops.rows_x6w_ok(2 * Din, Dm) and a.order == "type":  # ... and of the routed input-gradient GEMM
+        wp_w = ops.pack_weights_x6w(W, False)
+        fns["nk_x6w"] = lambda: ops.gemm_rows_x6([(gqp, tgt, Dm)], wp_w, E, 2 * Din, group_ptr=ptr, G=T, win_bits=bits_real, wide=True)
+        same = torch.equal(fns["nk_x6w"](), fns["nk_x6"]())
+        print(f"nk_x6w == nk_x6 bit for bit: {same}", flush=True)
+        assert same
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
     fns["pack_wt"] = lambda: ops.pack_weights_x6(W, True)
-    names = a.which.split(",") + [f"wgrad_x6_cap{cap}" for cap in caps]
+    names = [n for n in a.which.split(",") if n in fns or print(f"(skipping {n}: shape not supported)")] + [f"wgrad_x6_cap{cap}" for cap in caps]
     times = {n: [] for n in names}
     for rnd in range(a.rounds):  # interleaved rounds in ONE process: report median and min per variant
         for name in names:
