@@ -156,9 +156,6 @@ int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t
  * LDS layout; bl_packed_weight_elems_x6w uint16 elements; kinds 3 / 4 of bl_pack_weights_multi).  bl_set_rows_tile(128) makes bl_gemm_rows_x6w_ok return 0 (measurement switch; returns the previous tile). */
 int32_t bl_gemm_rows_x6w_ok(int32_t N, int32_t K);
 int32_t bl_set_rows_tile(int32_t cols);
-/* schedule of the wide form (measurement switch, returns the previous one): 0 = ping-pong wave pairs, both operands by DMA;
- * 1 = one barrier per stage, the gathered operand through registers two stages ahead */
-int32_t bl_set_rows_schedule(int32_t schedule);
 int64_t bl_packed_weight_elems_x6w(int32_t G, int32_t K, int32_t N);
 int bl_pack_weights_x6w(const float* w, int32_t G, int32_t K, int32_t N, int32_t w_is_kn, uint16_t* out, void* stream);
 int bl_gemm_rows_x6w(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,

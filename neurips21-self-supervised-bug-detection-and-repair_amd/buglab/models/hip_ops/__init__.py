@@ -83,7 +83,6 @@ _SIGNATURES = {
     "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6w_ok": ([c_int32, c_int32], c_int32),
     "bl_set_rows_tile": ([c_int32], c_int32),
-    "bl_set_rows_schedule": ([c_int32], c_int32),
     "bl_packed_weight_elems_x6w": ([c_int32, c_int32, c_int32], c_int64),
     "bl_pack_weights_x6w": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6w": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),

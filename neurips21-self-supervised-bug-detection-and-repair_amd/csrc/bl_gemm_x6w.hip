@@ -28,7 +28,13 @@
 //     tile, 12 MFMAs each); in every phase one of the two issues fragment reads and its share of the next stage's DMA while
 //     the other streams MFMAs; two s_barrier per phase keep them in step.  The fragment reads are inline asm: hipcc orders
 //     every compiler-visible LDS read behind every LDS-DMA in flight (s_waitcnt vmcnt(0)), which serialises the pipeline.
-//   * epilogue: the result tile leaves through LDS as whole 256-byte row pieces, like bl_gemm_rows_x6's.
+//   * epilogue: the result tile leaves through LDS as whole 256-byte row pieces, like bl_gemm_rows_x6's (5 % against stores from
+//     the accumulator layout).
+// Measured and not kept (commit 488c744, profiles/r05h_rows_wide_schedules.log): a schedule with ONE barrier per stage (every
+// wave software-pipelines its own four quadrants with counted lgkmcnt waits, the gathered operand through registers two stages
+// ahead) is bit-identical and 1 - 4 % slower in the plain form, 7 - 9 % in the routed one (254 - 256 registers).  Under these
+// GEMMs the chip sits at its 1 400 W package limit at 1.80 - 1.82 GHz (profiles/r05i_clock_probe.log): the schedules converge
+// because the limit is energy per product, not issue slots -- at that clock the bf16x6 ceiling is 316 TF/s, not 416.7.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -284,163 +290,6 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_x6w_kernel(
 }
 
 
-// ---- second schedule: ONE barrier per stage ----------------------------------------------------------------------------
-// No ping-pong lock step: every wave runs its own software pipeline through the four quadrants of a stage (fragment reads of
-// the next quadrant in flight behind the current quadrant's MFMAs, counted lgkmcnt waits -- LDS operations of a wave complete
-// in order), and the two waves of a SIMD interleave as the hardware arbitrates.  The gathered operand goes through REGISTERS
-// in both forms, requested TWO stages ahead (the gathers take 2 - 4 us under load, a stage ~1.5 us; the LDS has room for two
-// stage images, the register file for one more A piece: 12 registers), written to the other buffer in the middle of the
-// stage before its own; the weights stay on the DMA, one stage ahead.  vmcnt retires in order: the DMA is issued BEFORE the
-// new gathers, so that "all but the latest gathers have landed" (vmcnt(NA)) is the wait for it.
-#undef W_DMA_B
-#define LDS_WR(addr_, off_, v_) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr_), "v"(v_), "n"(off_) : "memory")
-#define LGKM_WAIT6(n_, a_, b_, c_, d_, e_, f_) \
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_), "+v"(e_), "+v"(f_) : "n"(n_) : "memory")
-#define WAIT_FRAG_N(n_, F_) LGKM_WAIT6(n_, F_[0][0], F_[0][1], F_[0][2], F_[1][0], F_[1][1], F_[1][2])
-
-template <bool MASKED>
-__global__ __launch_bounds__(512, 2) void gemm_rows_x6w1_kernel(
-    const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2, const int* __restrict__ idx0,
-    const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2, int koff1, int koff2, int nsrc,
-    const uint32_t* __restrict__ win_bits, int ld_bits, const uint4* __restrict__ bp, long long strideB,
-    const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G, int M, int N, int K, float* __restrict__ c,
-    int ldc) {
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];  // [2 buffers][A: 3 x 128 x 4 | B: 3 x 256 x 4]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int g, row0, nrows, tile_y;
-  if (!x6_locate(group_ptr, G, M, WBM, 1, tile_y, g, row0, nrows)) return;
-  const int n0 = tile_y * WBN;
-  const int wsel = group_w ? group_w[g] : g;
-  const int nk = K >> 5;
-  const uint4* __restrict__ Bt = bp + (long long)wsel * strideB + (size_t)tile_y * nk * W_BLK + lane;
-
-  // A piece of this thread: row tid >> 2, k-group tid & 3 of every stage
-  const int a_row = tid >> 2, a_kg = tid & 3;
-  const int a_grow = row0 + min(a_row, nrows - 1);
-  const int gr0 = idx0 ? idx0[a_grow] : a_grow;
-  const int gr1 = nsrc > 1 ? (idx1 ? idx1[a_grow] : a_grow) : 0;
-  const int gr2 = nsrc > 2 ? (idx2 ? idx2[a_grow] : a_grow) : 0;
-  const int wq0 = w0 >> 3, wq1 = w1 >> 3, wq2 = w2 >> 3;
-  const uint4* __restrict__ ap0 = xp0 + (size_t)gr0 * 3 * wq0 + a_kg;
-  const uint4* __restrict__ ap1 = nsrc > 1 ? xp1 + (size_t)gr1 * 3 * wq1 + a_kg : ap0;
-  const uint4* __restrict__ ap2 = nsrc > 2 ? xp2 + (size_t)gr2 * 3 * wq2 + a_kg : ap0;
-  const uint32_t* __restrict__ mrow = MASKED ? win_bits + (size_t)a_grow * ld_bits : nullptr;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t a_wr = lds0 + (a_row * 4 + (a_kg ^ ((a_row >> 2) & 3))) * 16;  // buffer 0, plane 0
-
-  uint4 pE0, pE1, pE2, pO0, pO1, pO2;  // A pieces in flight: of the even / odd stages
-  uint32_t mE = 0, mO = 0;
-#define W1_LOAD_A(kt_, r0_, r1_, r2_, m_)   \
-  {                                         \
-    W_A_SRC(kt_, src_, wq_)                 \
-    r0_ = src_[0];                          \
-    r1_ = src_[wq_];                        \
-    r2_ = src_[2 * wq_];                    \
-    if constexpr (MASKED) m_ = mrow[kt_];   \
-  }
-#define W1_WRITE_A(BUF_, r0_, r1_, r2_, m_)                                                              \
-  {                                                                                                      \
-    uint4 k_ = make_uint4(~0u, ~0u, ~0u, ~0u);                                                           \
-    if constexpr (MASKED) k_ = keep_from_bits(m_ >> (8 * a_kg));                                         \
-    const u32x4 v0_ = {r0_.x & k_.x, r0_.y & k_.y, r0_.z & k_.z, r0_.w & k_.w};                          \
-    const u32x4 v1_ = {r1_.x & k_.x, r1_.y & k_.y, r1_.z & k_.z, r1_.w & k_.w};                          \
-    const u32x4 v2_ = {r2_.x & k_.x, r2_.y & k_.y, r2_.z & k_.z, r2_.w & k_.w};                          \
-    const uint32_t wa_ = a_wr + (BUF_) * W_STAGE_BYTES;                                                  \
-    LDS_WR(wa_, 0, v0_);                                                                                 \
-    LDS_WR(wa_, W_A_PLANE_BYTES, v1_);                                                                   \
-    LDS_WR(wa_, 2 * W_A_PLANE_BYTES, v2_);                                                               \
-  }
-#define W1_DMA_B(kt_, BUF_) /* this wave's 6 pieces of the 48 KB weight block */                          \
-  {                                                                                                      \
-    const uint4* bsrc_ = Bt + (size_t)(kt_) * W_BLK;                                                     \
-    uint4* Bs_ = smem + (BUF_) * W_STAGE_UINT4 + WBM * 12;                                               \
-    _Pragma("unroll") for (int q = 0; q < 6; ++q) glds16(bsrc_ + (wave * 6 + q) * 64, Bs_ + (wave * 6 + q) * 64); \
-  }
-
-  const int wm = wave & 1, wn = wave >> 1;
-  const int li = lane & 31, half = lane >> 5, swz = (li >> 2) & 3;
-  uint32_t aa[2][2][2], ab[2][2][2];  // [buffer][tile][k-step] byte addresses of this lane's fragments
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int kg = (2 * s + half) ^ swz;
-      aa[0][t][s] = lds0 + ((wm * 64 + t * 32 + li) * 4 + kg) * 16;
-      ab[0][t][s] = lds0 + W_B_OFF_BYTES + ((wn * 64 + t * 32 + li) * 4 + kg) * 16;
-      aa[1][t][s] = aa[0][t][s] + W_STAGE_BYTES;
-      ab[1][t][s] = ab[0][t][s] + W_STAGE_BYTES;
-    }
-
-  f32x16 acc00, acc01, acc10, acc11;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
-
-  // prologue: stage 0 in LDS, the A piece of stage 1 in flight
-  W1_LOAD_A(0, pE0, pE1, pE2, mE)
-  W1_DMA_B(0, 0)
-  W1_LOAD_A(1, pO0, pO1, pO2, mO)  // (nk >= 2)
-  W1_WRITE_A(0, pE0, pE1, pE2, mE)
-  if constexpr (MASKED) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  u32x4 A0[2][3], A1[2][3], B0[2][3], B1[2][3];  // [k-step][plane]
-#define SEG1(acc_, A_, B_)           \
-  __builtin_amdgcn_sched_barrier(0); \
-  SIX(acc_, A_, B_, 0)               \
-  SIX(acc_, A_, B_, 1)               \
-  __builtin_amdgcn_sched_barrier(0);
-
-  // stage kt_ reads buffer BUF_; HAS1_ / HAS2_: stages kt_ + 1 / kt_ + 2 exist.  (rN*_, mN_) = the register set that holds the A
-  // piece of stage kt_ + 1 (written to LDS here), (rF*_, mF_) = the free one (takes the piece of stage kt_ + 2)
-#define STAGE1(kt_, BUF_, HAS1_, HAS2_, rN0_, rN1_, rN2_, mN_, rF0_, rF1_, rF2_, mF_)                        \
-  {                                                                                                        \
-    if (HAS1_) W1_DMA_B((kt_) + 1, 1 - (BUF_))                                                             \
-    if (HAS2_) W1_LOAD_A((kt_) + 2, rF0_, rF1_, rF2_, mF_)                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    RD_A(A0, 0, BUF_)                                                                                      \
-    RD_B(B0, 0, BUF_)                                                                                      \
-    RD_B(B1, 1, BUF_)                                                                                      \
-    WAIT_FRAG_N(6, A0);                                                                                    \
-    WAIT_FRAG_N(6, B0);                                                                                    \
-    SEG1(acc00, A0, B0)                                                                                    \
-    RD_A(A1, 1, BUF_)                                                                                      \
-    WAIT_FRAG_N(6, B1);                                                                                    \
-    SEG1(acc01, A0, B1)                                                                                    \
-    if (HAS1_) {                                                                                           \
-      W1_WRITE_A(1 - (BUF_), rN0_, rN1_, rN2_, mN_)                                                        \
-      WAIT_FRAG_N(3, A1);                                                                                  \
-    } else {                                                                                               \
-      WAIT_FRAG_N(0, A1);                                                                                  \
-    }                                                                                                      \
-    SEG1(acc11, A1, B1)                                                                                    \
-    SEG1(acc10, A1, B0)                                                                                    \
-    if (HAS1_) {                                                                                           \
-      /* the DMA of the next stage's weights has landed (everything but the gathers issued behind it), my A piece too */ \
-      if (HAS2_) {                                                                                         \
-        if constexpr (MASKED) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); \
-      } else {                                                                                             \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-      }                                                                                                    \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
-      __builtin_amdgcn_s_barrier();                                                                        \
-    }                                                                                                      \
-  }
-
-  int kt = 0;
-  for (; kt + 4 <= nk; kt += 2) {  // both stages of the pair have a stage two ahead
-    STAGE1(kt, 0, true, true, pO0, pO1, pO2, mO, pE0, pE1, pE2, mE)
-    STAGE1(kt + 1, 1, true, true, pE0, pE1, pE2, mE, pO0, pO1, pO2, mO)
-  }
-  STAGE1(kt, 0, true, false, pO0, pO1, pO2, mO, pE0, pE1, pE2, mE)
-  STAGE1(kt + 1, 1, false, false, pE0, pE1, pE2, mE, pO0, pO1, pO2, mO)
-  __builtin_amdgcn_s_barrier();  // every wave has read its last fragments: the stage buffers are dead
-
-  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  W_STORE_HALF(0, acc00, acc01)
-  W_STORE_HALF(1, acc10, acc11)
-}
-
 // ================================================================================================
 extern "C" int bl_pack_weights_x6w(const float* w, int32_t G, int32_t K, int32_t N, int32_t w_is_kn, uint16_t* out, void* stream) {
   if (G == 0) return BL_OK;
@@ -459,12 +308,6 @@ extern "C" int64_t bl_packed_weight_elems_x6w(int32_t G, int32_t K, int32_t N) {
 
 // Shapes the wide form takes.  The switch (bl_set_rows_tile) is a measurement aid like bl_set_wgrad_tile.
 static bool g_rows_wide = true;
-static int g_rows_sched = 0;  // 0: ping-pong, operands by DMA; 1: one barrier per stage, gathered operand through registers
-extern "C" int32_t bl_set_rows_schedule(int32_t s) {
-  const int32_t prev = g_rows_sched;
-  if (s == 0 || s == 1) g_rows_sched = s;
-  return prev;
-}
 extern "C" int32_t bl_set_rows_tile(int32_t cols) {
   const int32_t prev = g_rows_wide ? 256 : 128;
   g_rows_wide = cols != 128;
@@ -501,8 +344,6 @@ extern "C" int bl_gemm_rows_x6w(const bl_rows_packed_t* a, const uint32_t* win_b
                  bl_max_lds_per_block(), (int)lds);
     hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_x6w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_x6w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_x6w1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_x6w1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       bl_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
       return (int)e;
@@ -516,11 +357,7 @@ extern "C" int bl_gemm_rows_x6w(const bl_rows_packed_t* a, const uint32_t* win_b
       a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0], a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1],    \
       koff[2], a->nsrc, win_bits, ld_bits, reinterpret_cast<const uint4*>(bp), (long long)(b_group_stride / 8), group_ptr,      \
       group_w, G, M, N, K, c, ldc
-  if (g_rows_sched == 1 && win_bits)
-    hipLaunchKernelGGL((gemm_rows_x6w1_kernel<true>), grid, dim3(512), lds, (hipStream_t)stream, X6W_ARGS);
-  else if (g_rows_sched == 1)
-    hipLaunchKernelGGL((gemm_rows_x6w1_kernel<false>), grid, dim3(512), lds, (hipStream_t)stream, X6W_ARGS);
-  else if (win_bits)
+  if (win_bits)
     hipLaunchKernelGGL((gemm_rows_x6w_kernel<true>), grid, dim3(512), lds, (hipStream_t)stream, X6W_ARGS);
   else
     hipLaunchKernelGGL((gemm_rows_x6w_kernel<false>), grid, dim3(512), lds, (hipStream_t)stream, X6W_ARGS);

@@ -131,20 +131,6 @@ def main():
         same = torch.equal(fns["nk_x6w"](), fns["nk_x6"]())
         print(f"nk_x6w == nk_x6 bit for bit: {same}", flush=True)
         assert same
-    def with_sched(name, sched):  # A/B of the wide form's two schedules (bl_set_rows_schedule)
-        def run():
-            prev = ops.load_library().bl_set_rows_schedule(sched)
-            try:
-                return fns[name]()
-            finally:
-                ops.load_library().bl_set_rows_schedule(prev)
-        return run
-    for nm, ref in (("fwd_x6w", "fwd_x6"), ("nk_x6w", "nk_x6")):
-        if nm in fns:
-            fns[nm + "1"] = with_sched(nm, 1)
-            same = torch.equal(fns[nm + "1"](), fns[ref]())
-            print(f"{nm}1 (one barrier per stage) == {ref} bit for bit: {same}", flush=True)
-            assert same
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
     fns["pack_wt"] = lambda: ops.pack_weights_x6(W, True)
     names = [n for n in a.which.split(",") if n in fns or print(f"(skipping {n}: shape not supported)")] + [f"wgrad_x6_cap{cap}" for cap in caps]
