@@ -1452,27 +1452,29 @@ class _GatherLinear(torch.autograd.Function):
             xp = pack_bf16x3(xs[0])
             wkn, wnk = _packed_layer_weights(_f32(W, "W"), need_bwd)
             out = gemm_rows_x6([(xp, None, K)], wkn, R, N, bias=bias, act=act, drop=drop, kind="linear_x6")
-            ctx.saved = (W, bias is not None, act, sources, out, drop, xp if need_bwd else None, wnk)
+            ctx.saved = (W, bias, act, sources, out, drop, xp if need_bwd else None, wnk)
             return out
         out = gemm_rows(sources, _f32(W, "W"), R, W.shape[1], bias=bias, act=act, drop=drop)
-        ctx.saved = (W, bias is not None, act, sources, out, drop, None, None)
+        ctx.saved = (W, bias, act, sources, out, drop, None, None)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        W, has_bias, act, sources, out, drop, xp, wnk = ctx.saved
+        W, bias_p, act, sources, out, drop, xp, wnk = ctx.saved
+        has_bias = bias_p is not None
         R, N = out.shape
         K = W.shape[0]
         dev = W.device
-        g_bias = torch.zeros((N,), dtype=torch.float32, device=dev) if has_bias else None
+        # weight / bias gradients are accumulated by the kernels: straight into .grad where the optimiser opted in (FlatAdam's flat
+        # buffer: no zero fill, no autograd accumulation kernel -- 20 Linears per step in seq-great), into fresh zeros otherwise
+        g_W, r_W = _grad_target(W)
+        g_bias, r_bias = _grad_target(bias_p) if has_bias else (None, None)
         if xp is not None:  # bf16x6 path
             gzp = act_bwd_packed(g_out.contiguous(), out, act, drop, g_bias)
-            g_W = torch.zeros_like(W)
             gemm_wgrad_x6([(xp, None, K)], gzp, R, N, g_W)
             g_x = gemm_rows_x6([(gzp, None, N)], wnk, R, K, kind="linear_dgrad_x6") if ctx.needs_input_grad[4] else None
-            return (g_W, g_bias, None, None, g_x, None) + ((None,) if drop is not NO_DROPOUT else ())
+            return (r_W, r_bias, None, None, g_x, None) + ((None,) if drop is not NO_DROPOUT else ())
         g_z = act_bwd(g_out.contiguous(), out, act, drop, g_bias)
-        g_W = torch.zeros_like(W)
         gemm_wgrad(sources, g_z, R, N, g_W)
         g_a = gemm_rows([(g_z, None)], W, R, K, b_is_nk=True, ldb=N)
         g_xs, off = [], 0
@@ -1487,7 +1489,7 @@ class _GatherLinear(torch.autograd.Function):
                 scatter_add_rows(g_a, off, w, idx, g_x)
                 g_xs.append(g_x)
             off += w
-        return (g_W, g_bias, None, None) + tuple(g_xs) + (None,) * (len(sources) + (1 if drop is not NO_DROPOUT else 0))
+        return (r_W, r_bias, None, None) + tuple(g_xs) + (None,) * (len(sources) + (1 if drop is not NO_DROPOUT else 0))
 
 
 def gather_linear(sources: Sequence[RowSource], W, bias, act: str = "none", drop: Dropout = NO_DROPOUT):
