@@ -34,23 +34,34 @@ HBM_PEAK_GBS = 8000.0
 
 # rocprofv3 kernel names of the timed GEMM kinds (for the committed PMC traffic file)
 _KIND_TO_KERNEL = {
-    "gemm_rows_x6_grouped": ["void gemm_rows_x6_kernel<false, -1>"],
-    "gemm_rows_nk_routed_x6_grouped": ["void gemm_rows_x6_kernel<true, -1>"],
+    "gemm_rows_x6_grouped": ["void gemm_rows_x6_kernel<false, -1>", "void gemm_rows_x6w_kernel<false>"],
+    "gemm_rows_nk_routed_x6_grouped": ["void gemm_rows_x6_kernel<true, -1>", "void gemm_rows_x6w_kernel<true>"],
     "gemm_wgrad_routed_x6": ["void gemm_wgrad_x6_wide_kernel<true, true>", "void gemm_wgrad_x6_kernel<true>"],
-    "msg_gemm_x6": ["void gemm_rows_x6_kernel<false, -1>"],
-    "msg_dgrad_x6": ["void gemm_rows_x6_kernel<true, -1>"],
+    # the message GEMM / routed input gradient run as the 128 x 128 kernel (hidden-128 layers) or the wide 128 x 256 one
+    # (>= 256 output columns: csrc/bl_gemm_x6w.hip) -- one kind, two kernels
+    "msg_gemm_x6": ["void gemm_rows_x6_kernel<false, -1>", "void gemm_rows_x6w_kernel<false>"],
+    "msg_dgrad_x6": ["void gemm_rows_x6_kernel<true, -1>", "void gemm_rows_x6w_kernel<true>"],
     "msg_wgrad_x6": ["void gemm_wgrad_x6_wide_kernel<true, true>", "void gemm_wgrad_x6_kernel<true>"],
 }
 
 
 def _pmc_record(path, kind):
-    """The per-kernel record of `kind` in a committed PMC summary (first of the kind's kernel names that the file holds)."""
+    """The record of `kind` in a committed PMC summary: the launch-weighted mean over the kind's kernels that the file holds
+    (counters are per-launch averages per kernel name)."""
     with open(path) as f:
         kernels = json.load(f).get("kernels", {})
-    for name in _KIND_TO_KERNEL.get(kind, []):
-        if name in kernels:
-            return kernels[name]
-    return None
+    recs = [kernels[name] for name in _KIND_TO_KERNEL.get(kind, []) if name in kernels]
+    if not recs:
+        return None
+    n = sum(r.get("launches", 1) for r in recs)
+    out = {"launches": n}
+    for key in set().union(*recs) - {"launches", "mfma_busy_frac", "l2_hit_rate"}:
+        out[key] = sum(r.get(key, 0.0) * r.get("launches", 1) for r in recs) / n
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in out and out.get("GRBM_GUI_ACTIVE"):
+        out["mfma_busy_frac"] = out["SQ_VALU_MFMA_BUSY_CYCLES"] / (out["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    elif len(recs) == 1 and "mfma_busy_frac" in recs[0]:
+        out["mfma_busy_frac"] = recs[0]["mfma_busy_frac"]
+    return out
 
 
 def measured_traffic(kind):
