@@ -151,7 +151,8 @@ int bl_gemm_rows_x6(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t
  * LDS image (global_load_lds), ping-pong schedule.  Same contract, same summation order per element -- results are bit-identical
  * to bl_gemm_rows_x6 -- for the message GEMMs with >= 256 output columns and long K (ptgnn MlpMessagePassingLayer's per-type
  * Linear and its input gradient, call site buglab/models/gnnlayerdefs.py:6-23: the ConcatResidual layers of the hidden-128
- * model, every layer at hidden 256).  Shapes: bl_gemm_rows_x6w_ok(N, K) -- N a multiple of 256, K a multiple of 64.  The
+ * model, every layer at hidden 256).  Shapes the layer calls send here: bl_gemm_rows_x6w_ok(N, K) -- N a multiple of 256, K a
+ * multiple of 64 and >= 256 (the entry point itself takes any K >= 64 that is a multiple of 64).  The
  * weights come in their own image, bl_pack_weights_x6w (a 48 KB block per group, 256-column tile and 32-k stage in the exact
  * LDS layout; bl_packed_weight_elems_x6w uint16 elements; kinds 3 / 4 of bl_pack_weights_multi).  bl_set_rows_tile(128) makes bl_gemm_rows_x6w_ok return 0 (measurement switch; returns the previous tile). */
 int32_t bl_gemm_rows_x6w_ok(int32_t N, int32_t K);
@@ -331,7 +332,9 @@ typedef struct {
   const uint16_t* Wd_packed_bwd;  /* ... bl_pack_weights_x6(Wd, 1, Dout, Dm, w_is_kn = 0), the form of g_ln = g_z . Wd^T.
                                    * NULL / NULL: exact-fp32 MFMA GEMMs (bl_gemm_rows / bl_gemm_wgrad) */
   int32_t num_hub_slots;          /* how many leading entries of node_order may be hubs (nodes with very long target segments get
-                                   * a whole workgroup in the segmented max); < 0: unknown -- the first 4096 are looked at */
+                                   * a whole workgroup in the segmented max); < 0: unknown -- the first 4096 are looked at;
+                                   * 0: no hubs -- node_order is then not read at all (the collators list the hubs first and every
+                                   * other node in natural order, i.e. the identity; any order gives the same results) */
 } bl_mp_layer_t;
 
 /* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call.

@@ -313,7 +313,9 @@ extern "C" int32_t bl_set_rows_tile(int32_t cols) {
   g_rows_wide = cols != 128;
   return prev;
 }
-extern "C" int32_t bl_gemm_rows_x6w_ok(int32_t N, int32_t K) { return g_rows_wide && N > 0 && N % WBN == 0 && K >= 64 && K % 64 == 0; }
+// (the kernel itself takes any K >= 64 that is a multiple of 64; below 8 stages per tile its prologue and epilogue cost as much as
+// the loop and the 128 x 128 kernel's three workgroups per CU hide them better -- measured equal at K = 256, so the line is there)
+extern "C" int32_t bl_gemm_rows_x6w_ok(int32_t N, int32_t K) { return g_rows_wide && N > 0 && N % WBN == 0 && K >= 256 && K % 64 == 0; }
 
 extern "C" int bl_gemm_rows_x6w(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                                 int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,

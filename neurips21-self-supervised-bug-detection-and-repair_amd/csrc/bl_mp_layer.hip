@@ -244,6 +244,9 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
   BL_CHECK_ARG((h_hi == nullptr && width_lo == Din) || (h_hi != nullptr && width_lo > 0 && width_lo < Din && width_lo % 32 == 0),
                "bl_mp_layer_fwd: width_lo must be Din (one source) or a multiple of 32 below Din (two sources)");
   hipStream_t st = (hipStream_t)stream;
+  // node_order lists the hubs first and the other nodes in natural order: without hubs it is the identity, and the per-node
+  // kernels skip the load (one dependent round trip less per wave)
+  const int32_t* node_order = L->num_hub_slots == 0 ? nullptr : L->node_order;
   Saved S = carve_saved(saved, N, E, Din, Dm, L->msg_act);
   float* pre = (float*)ws;
   if (infer) {
@@ -283,7 +286,7 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
     ProfScope ps(2, 0.0, st, false);
     // (E == 0: every segment is empty and the kernel never dereferences `pre`)
     BL_TRY(bl_segment_max_fwd_impl(pre, Dm, L->tgt_ptr, L->tgt_msgs, N, Dm, L->msg_act, S.agg, winner_out, L->ln_g, L->ln_b,
-                                   L->ln_eps, dense_x6 ? nullptr : S.ln_out, S.mean, S.rstd, S.dact, S.bits, L->node_order,
+                                   L->ln_eps, dense_x6 ? nullptr : S.ln_out, S.mean, S.rstd, S.dact, S.bits, node_order,
                                    dense_x6 ? (uint16_t*)S.ln_out : nullptr, L->num_hub_slots, st));
   }
   {
@@ -315,6 +318,7 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   BL_CHECK_ARG((g_h_hi == nullptr && width_lo == Din) || (g_h_hi != nullptr && width_lo > 0 && width_lo < Din),
                "bl_mp_layer_bwd: width_lo must be Din (one output) or below Din (two outputs)");
   hipStream_t st = (hipStream_t)stream, side = side_stream ? (hipStream_t)side_stream : st;
+  const int32_t* node_order = L->num_hub_slots == 0 ? nullptr : L->node_order;  // (identity without hubs: see bl_mp_layer_fwd)
   const bool two = side != st;
   SideEvents* ev = two ? ensure_events() : nullptr;
   if (two) BL_CHECK_ARG(ev != nullptr, "bl_mp_layer_bwd: cannot create HIP events");
@@ -411,7 +415,7 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
       BL_TRY(bl_routed_dgrad_nodes_rows(B.g_ln, Dm, L->msg_src, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, Din, split,
                                         g_h_lo, ld_lo, g_h_hi, ld_hi, B.g_a, Din, st));
       BL_TRY(bl_mp_scatter_src_accum_impl(B.g_a, Din, L->src_ptr, L->src_msgs, N, Din, split, g_h_lo, ld_lo, g_h_hi, ld_hi,
-                                          L->node_order, st));
+                                          node_order, st));
     } else if (vec_dgrad) {
       ProfScope ps(9, 2.0 * N * (2.0 * Din) * Dm, st, two);
       BL_TRY(bl_routed_dgrad_vec(B.g_ln, Dm, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, 2 * Din, B.g_a, 2 * Din, st));
@@ -430,10 +434,10 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
     // E == 0: both CSRs are empty and g_a is never read
     if (g_h_hi == nullptr)
       BL_TRY(bl_mp_scatter_grad(B.g_a, 2 * Din, L->src_ptr, L->src_msgs, L->tgt_ptr, L->tgt_msgs, N, Din, 0, g_h_lo, ld_lo,
-                                L->node_order, st));
+                                node_order, st));
     else
       BL_TRY(bl_mp_scatter_grad_split(B.g_a, 2 * Din, L->src_ptr, L->src_msgs, L->tgt_ptr, L->tgt_msgs, N, Din, width_lo, g_h_lo,
-                                      ld_lo, g_h_hi, ld_hi, L->node_order, st));
+                                      ld_lo, g_h_hi, ld_hi, node_order, st));
   }
   if (two && join_side) {
     (void)hipEventRecord(ev->join, side);

@@ -20,3 +20,26 @@ def test_cpu_baseline_leg_returns_the_contract_fields():
     assert out["kind"] == "port" and out["unit"] == "graphs/s" and out["value"] > 0
     assert 1 <= out["cores"] <= (os.cpu_count() or 1) and out["host_threads"] == (os.cpu_count() or 8)
     assert "4-graph minibatch" in out["sample"] and out["collate_ms"] >= 0
+
+
+def test_pmc_record_of_a_kind_is_the_launch_weighted_mean_over_its_kernels(tmp_path):
+    """The message GEMM runs as two kernels (128 x 128 tile for the hidden-128 layers, the wide one for >= 256 output columns):
+    bench.py's `traffic` / `mfma_busy_frac` for the kind are launch-weighted means over both records of the PMC summary."""
+    import json
+
+    import bench
+
+    f = tmp_path / "r99_pmc.json"
+    f.write_text(json.dumps({"kernels": {
+        "void gemm_rows_x6_kernel<false, -1>": {"FETCH_SIZE_KB_per_launch": 100.0, "WRITE_SIZE_KB_per_launch": 10.0, "launches": 6,
+                                                 "SQ_VALU_MFMA_BUSY_CYCLES": 512.0, "GRBM_GUI_ACTIVE": 8.0, "mfma_busy_frac": 0.5},
+        "void gemm_rows_x6w_kernel<false>": {"FETCH_SIZE_KB_per_launch": 500.0, "WRITE_SIZE_KB_per_launch": 50.0, "launches": 2,
+                                              "SQ_VALU_MFMA_BUSY_CYCLES": 2048.0, "GRBM_GUI_ACTIVE": 16.0, "mfma_busy_frac": 1.0},
+        "unrelated": {"FETCH_SIZE_KB_per_launch": 1.0, "launches": 1}}}))
+    rec = bench._pmc_record(str(f), "msg_gemm_x6")
+    assert rec["launches"] == 8
+    assert abs(rec["FETCH_SIZE_KB_per_launch"] - (6 * 100.0 + 2 * 500.0) / 8) < 1e-9
+    assert abs(rec["WRITE_SIZE_KB_per_launch"] - (6 * 10.0 + 2 * 50.0) / 8) < 1e-9
+    busy, gui = (6 * 512.0 + 2 * 2048.0) / 8, (6 * 8.0 + 2 * 16.0) / 8
+    assert abs(rec["mfma_busy_frac"] - busy / (gui / 8.0 * 1024.0)) < 1e-12
+    assert bench._pmc_record(str(f), "no_such_kind") is None

@@ -70,3 +70,34 @@ def test_argument_errors_are_reported_without_touching_the_gpu(built_lib):
     assert rc != 0 and b"null" in lib.bl_last_error()
     rc = lib.bl_segment_max_fwd(None, 0, None, None, 5, 1024, 0, None, None, None, None, 1e-5, None, None, None, None, None, None, None)
     assert rc != 0
+
+    # the wide row GEMM rejects the shapes its tile cannot take, with the rule in the message
+    rows.width[0] = 64
+    rc = lib.bl_gemm_rows_x6w(ctypes.byref(rows), None, 0, ctypes.cast(buf, ctypes.c_void_p), 0, None, None, 1, 8, 128, 64,
+                              ctypes.cast(buf, ctypes.c_void_p), 128, None)
+    assert rc != 0 and b"multiple of 256" in lib.bl_last_error()
+
+
+def test_layer_weight_image_rule_is_a_pure_function_of_the_shape(built_lib):
+    """Which weight image a fused layer call expects (bl_mp_layer_weight_image): the wide row GEMM's where the layer's GEMM of
+    that direction has a multiple of 256 output columns and K >= 256, the tiled one otherwise; the size query follows; the
+    measurement switch turns the wide form off.  Host-side only -- no GPU."""
+    from buglab.models import hip_ops
+
+    lib = hip_ops.load_library()
+    assert lib.bl_set_rows_tile(256) in (128, 256)
+    # (Din, Dm): forward GEMM N = Dm, K = 2 Din; input-gradient GEMM N = 2 Din, K = Dm
+    assert [lib.bl_mp_layer_weight_image(128, 128, d) for d in (0, 1)] == [0, 0]   # hidden-128 plain layer: Dm = 128 / K = 128
+    assert [lib.bl_mp_layer_weight_image(256, 256, d) for d in (0, 1)] == [1, 1]   # concat layer at hidden 128, plain layer at 256
+    assert [lib.bl_mp_layer_weight_image(512, 512, d) for d in (0, 1)] == [1, 1]
+    assert [lib.bl_mp_layer_weight_image(96, 160, d) for d in (0, 1)] == [0, 0]
+    T = 16
+    assert lib.bl_mp_layer_packed_weight_elems(T, 256, 256, 0) == lib.bl_packed_weight_elems_x6w(T, 512, 256)
+    assert lib.bl_mp_layer_packed_weight_elems(T, 128, 128, 0) == T * 1 * (256 // 32) * 12288
+    assert lib.bl_packed_weight_elems_x6w(1, 512, 256) == (512 // 32) * 24576   # one 48 KB block per 256 columns and 32-k stage
+    prev = lib.bl_set_rows_tile(128)
+    try:
+        assert prev == 256 and lib.bl_mp_layer_weight_image(256, 256, 0) == 0 and not hip_ops.rows_x6w_ok(256, 512)
+    finally:
+        lib.bl_set_rows_tile(prev)
+    assert hip_ops.rows_x6w_ok(256, 512) and not hip_ops.rows_x6w_ok(256, 128) and not hip_ops.rows_x6w_ok(128, 512)

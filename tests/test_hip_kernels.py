@@ -493,7 +493,9 @@ def test_wide_row_gemm_is_bit_identical_to_the_128_tile(ops, widths, N, sizes):
     sources, ragged / empty groups, row tails; routed form (one gathered source, winner-masked) on the same shapes."""
     rng = np.random.default_rng(5)
     K, T, E, R = int(sum(widths)), len(sizes), int(sum(sizes)), 301
-    assert ops.rows_x6w_ok(N, K) and not ops.rows_x6w_ok(N + 32, K) and not ops.rows_x6w_ok(N, K + 32)
+    # the shape predicate of the layer calls: >= 256 output columns in multiples of 256, K >= 256 in multiples of 64 (the entry
+    # point itself also takes shorter K: the (32, 32) case)
+    assert ops.rows_x6w_ok(N, K) == (K >= 256) and not ops.rows_x6w_ok(N + 32, K) and not ops.rows_x6w_ok(N, K + 32)
     ptr = _dev(_groups(rng, sizes))
     W = torch.randn(T, K, N) / math.sqrt(K)
     srcs = []
@@ -524,7 +526,7 @@ def test_wide_row_gemm_is_bit_identical_to_the_128_tile(ops, widths, N, sizes):
     assert torch.equal(r_got, r_ref)
     prev = ops.load_library().bl_set_rows_tile(128)  # the measurement switch turns the shape predicate off
     try:
-        assert prev == 256 and not ops.rows_x6w_ok(N, K)
+        assert prev == 256 and not ops.rows_x6w_ok(N, 512)
     finally:
         ops.load_library().bl_set_rows_tile(prev)
 

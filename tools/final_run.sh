@@ -4,12 +4,14 @@
 TAG=${1:?tag}
 O=gpurun_out
 mkdir -p $O
-timeout 900 python -m pytest tests -x -q -m gpu > $O/${TAG}_gputest.log 2>&1; tail -2 $O/${TAG}_gputest.log
-python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -2 $O/${TAG}_smoke.log
+# (the bench lines first: run right behind the test-suite, the launch-bound seq-great entry of `also` once measured 766 instead of
+# 3 200 sequences/s -- host contention from processes the tests leave winding down; r05m)
 bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.log 2>&1
 python bench.py --hidden 256 --graphs 32 --no-cpu-baseline --no-also > $O/${TAG}_bench_c3.json 2>/dev/null
 python bench.py --hidden 256 --graphs 32 --degree powerlaw --no-cpu-baseline --no-also > $O/${TAG}_bench_c4.json 2>/dev/null
 python bench.py --graphs 15 --no-cpu-baseline --no-also > $O/${TAG}_bench_30k.json 2>/dev/null
 python tools/dgrad_bench.py > $O/${TAG}_dgrad_bench.log 2>&1
 python tools/hbm_bench.py > $O/${TAG}_hbm_bench.log 2>&1
+timeout 900 python -m pytest tests -x -q -m gpu > $O/${TAG}_gputest.log 2>&1; tail -2 $O/${TAG}_gputest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -2 $O/${TAG}_smoke.log
 ls $O | grep $TAG | wc -l
