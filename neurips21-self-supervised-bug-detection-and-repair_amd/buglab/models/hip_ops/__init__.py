@@ -754,6 +754,7 @@ class _EmbedSubtokenMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         table, ids, argsub, drop, V, H, tok_csr = ctx.saved
+        ctx.saved = None
         g_out = g_out.contiguous()
         N, S = ids.shape
         direct = _direct_small(table)
@@ -1408,6 +1409,7 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         idx, shape = ctx.saved
+        ctx.saved = None
         g_x = torch.zeros(shape, dtype=torch.float32, device=g_out.device)
         scatter_add_rows(g_out.contiguous(), 0, shape[1], idx, g_x)
         return g_x, None
@@ -1452,15 +1454,22 @@ class _GatherLinear(torch.autograd.Function):
             xp = pack_bf16x3(xs[0])
             wkn, wnk = _packed_layer_weights(_f32(W, "W"), need_bwd)
             out = gemm_rows_x6([(xp, None, K)], wkn, R, N, bias=bias, act=act, drop=drop, kind="linear_x6")
-            ctx.saved = (W, bias, act, sources, out, drop, xp if need_bwd else None, wnk)
+            # (the OUTPUT goes through save_for_backward: kept as a plain ctx attribute it forms the cycle output -> grad_fn -> ctx ->
+            # output, which Python's collector cannot see through the C++ node -- every step's activations stayed allocated,
+            # ~1 GiB per seq-great step until the device was full)
+            ctx.save_for_backward(out)
+            ctx.saved = (W, bias, act, sources, drop, xp if need_bwd else None, wnk)
             return out
         out = gemm_rows(sources, _f32(W, "W"), R, W.shape[1], bias=bias, act=act, drop=drop)
-        ctx.saved = (W, bias, act, sources, out, drop, None, None)
+        ctx.save_for_backward(out)
+        ctx.saved = (W, bias, act, sources, drop, None, None)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        W, bias_p, act, sources, out, drop, xp, wnk = ctx.saved
+        W, bias_p, act, sources, drop, xp, wnk = ctx.saved
+        (out,) = ctx.saved_tensors
+        ctx.saved = None
         has_bias = bias_p is not None
         R, N = out.shape
         K = W.shape[0]
@@ -1512,6 +1521,7 @@ class _RowDot(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         x, w, has_b = ctx.saved
+        ctx.saved = None
         R, H = x.shape
         g_x = torch.empty_like(x)
         g_w = torch.zeros_like(w)
@@ -1535,12 +1545,15 @@ class _SegmentLogSoftmax(torch.autograd.Function):
             load_library().bl_segment_log_softmax_fwd(_f32(x).data_ptr(), _i32(seg_ptr).data_ptr(), _p(seg_items), int(nseg),
                                                       float(eps), y.data_ptr(), _stream()),
             "bl_segment_log_softmax_fwd")
-        ctx.saved = (y, seg_ptr, seg_items, nseg)
+        ctx.save_for_backward(y)  # (an output: see _GatherLinear)
+        ctx.saved = (seg_ptr, seg_items, nseg)
         return y
 
     @staticmethod
     def backward(ctx, g_y):
-        y, seg_ptr, seg_items, nseg = ctx.saved
+        seg_ptr, seg_items, nseg = ctx.saved
+        (y,) = ctx.saved_tensors
+        ctx.saved = None
         g_x = torch.zeros_like(y)
         _check(
             load_library().bl_segment_log_softmax_bwd(_f32(g_y.contiguous()).data_ptr(), y.data_ptr(), seg_ptr.data_ptr(),
@@ -1567,6 +1580,7 @@ class _SegmentMaxPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, _g_arg):
         arg, shape, seg_of = ctx.saved
+        ctx.saved = None
         x_like = torch.empty(shape, dtype=torch.float32, device=g_out.device)
         g_x = segment_max_bwd(g_out.contiguous(), arg, x_like, seg_of, out=x_like)
         return g_x, None, None, None
@@ -1611,6 +1625,7 @@ class _MlpScore(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_score):
         W1, b1, w2, b2, xs, idxs, hidden, K = ctx.saved
+        ctx.saved = None
         lib = load_library()
         R, H = hidden.shape
         dev = W1.device
@@ -1665,6 +1680,7 @@ class _LocalizationScores(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_score):
         x, cand, cand_graph, cand_ptr, B, Ws, bs, W1, b1, w, saved = ctx.saved
+        ctx.saved = None
         lib = load_library()
         C, H = cand.shape[0], x.shape[1]
         dev = x.device
@@ -1787,6 +1803,7 @@ class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         z, mean, rstd, gamma, beta, has_r = ctx.saved
+        ctx.saved = None
         (gg, rg), (gb, rb) = _grad_target(gamma), _grad_target(beta)
         g_z = layernorm_bwd(g_y.contiguous(), z, mean, rstd, gamma, gg, gb)
         return g_z, (g_z if has_r else None), rg, rb, None

@@ -339,3 +339,54 @@ def test_seq_model_end_to_end_matches_oracle(model_name):
     for point, loc, rewrites in res:
         assert len(rewrites) == len(point["candidate_rewrites"]) and -1 in loc
         assert set(k for k in loc if k >= 0) == set(point["graph"]["reference_nodes"])
+
+
+@pytest.mark.parametrize("family", ["seq-great", "gnn-mlp"])
+def test_training_steps_do_not_accumulate_device_memory(family):
+    """A custom autograd Function that keeps its own OUTPUT as a plain ctx attribute forms a cycle (output -> grad_fn -> ctx ->
+    output) that crosses into C++ and is never collected: every step's activations stay allocated.  `_GatherLinear` did that
+    until round 5 -- seq-great lost ~1 GiB per step at BASELINE configs[4] and filled a 288 GB device after ~280 steps.  After
+    a warm-up the allocated bytes must be the same after every step, for both model families."""
+    import copy
+    import gc
+    from pathlib import Path
+
+    from buglab.data.collate import to_device
+    from buglab.data.synthetic import make_buglab_dataset, make_buglab_seq_dataset
+    from buglab.models.modelregistry import load_model
+    from buglab.runtime.optim import FlatAdam
+
+    if family == "seq-great":
+        data = make_buglab_seq_dataset(6, seed=11)
+        spec = {"modelName": "seq-great", "hidden_state_size": 64, "num_layers": 2, "num_heads": 4, "intermediate_dimension_size": 96,
+                "dropout_rate": 0.1}
+    else:
+        data = make_buglab_dataset(6, seed=11)
+        spec = {"modelName": "gnn-mlp", "hidden_state_size": 64, "dropout_rate": 0.1}
+    model = load_model(spec, Path(f"/tmp/_bl_leak_{family}.pkl.gz"))[0]
+    model.compute_metadata(copy.deepcopy(data))
+    torch.manual_seed(0)
+    nn_ = model.build_neural_module().cuda().train()
+    samples = [s for s in (model.tensorize(copy.deepcopy(d)) for d in data) if s is not None]
+    mb = to_device(model.collate_minibatch({"samples": samples}), "cuda")
+    opt = FlatAdam(nn_.parameters(), lr=1e-3, num_warmup_steps=0)
+
+    def step():
+        opt.zero_grad()
+        loss = nn_(**mb)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    for _ in range(3):
+        step()
+    gc.collect()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    grown = []
+    for _ in range(6):
+        step()
+        torch.cuda.synchronize()
+        grown.append(torch.cuda.memory_allocated() - base)
+    # (allocations of a step are freed when its graph dies; what may remain is the loss scalar of the last step and the like)
+    assert max(grown) <= 1 << 20 and grown[-1] <= grown[0] + (1 << 16), grown
