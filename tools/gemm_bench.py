@@ -25,6 +25,11 @@ def main():
     ap.add_argument("--which", default="fwd,nk,wgrad")
     ap.add_argument("--order", default="type", help="type: type-major; chunk: (graph chunk, type)-major")
     ap.add_argument("--chunk", type=int, default=1, help="graphs per chunk")
+    ap.add_argument("--mixed", type=float, default=0.0,
+                    help="> 0: every timed launch is followed by an HBM-bound filler (a device copy of that many GB) and only the GEMM's own "
+                         "events are summed.  Back to back, a GEMM holds the package at its 1 400 W limit and the clock at 1.8 GHz; in the "
+                         "training step the kernels alternate and the clock is ~2.2 GHz (tools/experiments/step_power.sh): this mode times "
+                         "a variant under THOSE conditions")
     ap.add_argument("--kcaps", default="", help="comma list: also time wgrad_x6 with these row caps per workgroup (bl_set_wgrad_kchunk_cap)")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
@@ -135,12 +140,26 @@ def main():
     fns["pack_wt"] = lambda: ops.pack_weights_x6(W, True)
     names = [n for n in a.which.split(",") if n in fns or print(f"(skipping {n}: shape not supported)")] + [f"wgrad_x6_cap{cap}" for cap in caps]
     times = {n: [] for n in names}
+    filler_src = torch.empty(int(a.mixed * 2 ** 30) // 4, device="cuda") if a.mixed > 0 else None
+    filler_dst = torch.empty_like(filler_src) if a.mixed > 0 else None
     for rnd in range(a.rounds):  # interleaved rounds in ONE process: report median and min per variant
         for name in names:
             f = fns[name]
             for _ in range(2 if rnd == 0 else 1):
                 f()
             torch.cuda.synchronize()
+            if a.mixed > 0:  # GEMM, filler, GEMM, filler, ...: sum of the GEMM's own event spans
+                for _ in range(10):  # let the power controller settle on the mix
+                    f(); filler_dst.copy_(filler_src)
+                evs = []
+                for _ in range(a.iters):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); f(); e1.record()
+                    filler_dst.copy_(filler_src)
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                times[name].append(sum(x.elapsed_time(y) for x, y in evs) / a.iters)
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
