@@ -341,12 +341,13 @@ def test_seq_model_end_to_end_matches_oracle(model_name):
         assert set(k for k in loc if k >= 0) == set(point["graph"]["reference_nodes"])
 
 
-@pytest.mark.parametrize("family", ["seq-great", "gnn-mlp"])
+@pytest.mark.parametrize("family", ["seq-great", "seq-rat", "gnn-mlp", "gnn-mlp-all-outputs", "gnn-mlp-edge-features", "ggnn"])
 def test_training_steps_do_not_accumulate_device_memory(family):
     """A custom autograd Function that keeps its own OUTPUT as a plain ctx attribute forms a cycle (output -> grad_fn -> ctx ->
     output) that crosses into C++ and is never collected: every step's activations stay allocated.  `_GatherLinear` did that
     until round 5 -- seq-great lost ~1 GiB per step at BASELINE configs[4] and filled a 288 GB device after ~280 steps.  After
-    a warm-up the allocated bytes must be the same after every step, for both model families."""
+    a warm-up the allocated bytes must be the same after every step, for every model family and option that has its own
+    autograd Functions."""
     import copy
     import gc
     from pathlib import Path
@@ -356,14 +357,18 @@ def test_training_steps_do_not_accumulate_device_memory(family):
     from buglab.models.modelregistry import load_model
     from buglab.runtime.optim import FlatAdam
 
-    if family == "seq-great":
+    if family.startswith("seq"):
         data = make_buglab_seq_dataset(6, seed=11)
-        spec = {"modelName": "seq-great", "hidden_state_size": 64, "num_layers": 2, "num_heads": 4, "intermediate_dimension_size": 96,
+        spec = {"modelName": family, "hidden_state_size": 64, "num_layers": 2, "num_heads": 4, "intermediate_dimension_size": 96,
                 "dropout_rate": 0.1}
     else:
         data = make_buglab_dataset(6, seed=11)
-        spec = {"modelName": "gnn-mlp", "hidden_state_size": 64, "dropout_rate": 0.1}
-    model = load_model(spec, Path(f"/tmp/_bl_leak_{family}.pkl.gz"))[0]
+        spec = {"modelName": "ggnn" if family == "ggnn" else "gnn-mlp", "hidden_state_size": 64, "dropout_rate": 0.1}
+        if family == "gnn-mlp-all-outputs":
+            spec["use_all_gnn_layer_outputs"] = True   # the summarisation layer is a plain gather_linear
+        if family == "gnn-mlp-edge-features":
+            spec["edge_feature_size"] = 32
+    model = load_model(spec, Path(f"/tmp/_bl_leak_{family.replace(chr(45), chr(95))}.pkl.gz"))[0]
     model.compute_metadata(copy.deepcopy(data))
     torch.manual_seed(0)
     nn_ = model.build_neural_module().cuda().train()
