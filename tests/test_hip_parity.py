@@ -192,13 +192,14 @@ def test_c3_c4_shapes_hidden_256_match_oracle():
     _check_tie_aware(cfg, mb, seed=5)
 
 
-@pytest.mark.parametrize("H,degree,B", [(128, "uniform", 2), (256, "uniform", 2), (256, "powerlaw", 2), (128, "uniform", 8)])
+@pytest.mark.parametrize("H,degree,B", [(128, "uniform", 2), (256, "uniform", 2), (256, "powerlaw", 2), (128, "uniform", 8), (128, "uniform", 64)])
 def test_baseline_graph_size_matches_fp64_oracle(H, degree, B):
     """The BASELINE per-graph size -- 2000 nodes / 10000 messages per graph, 8 layers, 16 edge types -- on a
     2-graph minibatch (what bench.py's cpu_baseline leg runs) and, at the headline configuration's width, on an 8-graph
-    one (16 000 nodes / 80 000 messages: several tiles per edge type in every GEMM, 250 tiles in the node kernels): loss,
-    log-probabilities and node states within 1e-4 of the fp64 oracle, winner tables equal up to near-ties, every gradient
-    within 1e-4 (routing injected)."""
+    one (16 000 nodes / 80 000 messages: several tiles per edge type in every GEMM, 250 tiles in the node kernels) and on the
+    FULL 64-graph minibatch of BASELINE configs[1] -- the bench's workload, 128 000 nodes / 640 000 messages (the fp64 oracle
+    takes ~3 minutes of host time for it): loss, log-probabilities and node states within 1e-4 of the fp64 oracle, winner
+    tables equal up to near-ties, every gradient within 1e-4 (routing injected)."""
     cfg, _, mb = Hh.make_case(B=B, n=2000, E=10000, T=16, H=H, layers=8, vocab=15000, C=40, degree=degree, max_degree=512, seed=21)
     if degree == "powerlaw":
         assert np.diff(mb["graph_data"]["tgt_ptr"]).max() >= 512

@@ -12,6 +12,6 @@ python bench.py --hidden 256 --graphs 32 --degree powerlaw --no-cpu-baseline --n
 python bench.py --graphs 15 --no-cpu-baseline --no-also > $O/${TAG}_bench_30k.json 2>/dev/null
 python tools/dgrad_bench.py > $O/${TAG}_dgrad_bench.log 2>&1
 python tools/hbm_bench.py > $O/${TAG}_hbm_bench.log 2>&1
-timeout 900 python -m pytest tests -x -q -m gpu > $O/${TAG}_gputest.log 2>&1; tail -2 $O/${TAG}_gputest.log
+timeout 1500 python -m pytest tests -x -q -m gpu > $O/${TAG}_gputest.log 2>&1; tail -2 $O/${TAG}_gputest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -2 $O/${TAG}_smoke.log
 ls $O | grep $TAG | wc -l
