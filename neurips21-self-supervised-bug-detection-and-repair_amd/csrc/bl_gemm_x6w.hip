@@ -33,9 +33,9 @@
 // Measured and not kept (commit 488c744, profiles/r05h_rows_wide_schedules.log): a schedule with ONE barrier per stage (every
 // wave software-pipelines its own four quadrants with counted lgkmcnt waits, the gathered operand through registers two stages
 // ahead) is bit-identical and 1 - 4 % slower in the plain form, 7 - 9 % in the routed one (254 - 256 registers).  Back to back these
-// GEMMs hold the package at its 1 400 W limit at 1.80 - 1.82 GHz (profiles/r05i_clock_probe.log); at the training step's 2.2 GHz
-// they are only 2 - 6 % faster (tools/gemm_bench.py --mixed, profiles/r05t_gemm_mixed.log): neither issue slots nor the core
-// clock bound them -- the gathered operand's delivery does, which is what this tile halves.
+// GEMMs hold the package at its 1 400 W limit at 1.80 - 1.82 GHz (profiles/r05i_clock_probe.log); 7.6 % more clock makes them
+// 2.9 % faster (tools/gemm_bench.py --mixed, profiles/r05x_mixed_clock.log): co-limited by the core and by the gathered
+// operand's delivery -- which is what this tile halves -- not by issue slots.
 #include <stdio.h>
 #include <stdlib.h>
 

@@ -2,9 +2,9 @@
 # GPU box: which clock / power does `gemm_bench.py --mixed 2` actually run at?  (rocm-smi sampled while it loops)
 O=gpurun_out; mkdir -p $O
 for mixed in 0 2; do
-  python tools/gemm_bench.py --nodes 64000 --msgs 320000 --din 512 --dm 512 --which fwd_x6w --rounds 6 --iters 400 --mixed $mixed > /tmp/g.log 2>&1 &
+  python tools/gemm_bench.py --nodes 64000 --msgs 320000 --din 512 --dm 512 --which fwd_x6w --rounds 30 --iters 400 --mixed $mixed > /tmp/g.log 2>&1 &
   pid=$!
-  sleep 14
+  sleep 9
   : > /tmp/smi.txt
   while kill -0 $pid 2>/dev/null; do rocm-smi --showclocks --showpower --json >> /tmp/smi.txt 2>/dev/null; echo >> /tmp/smi.txt; done
   python - $mixed <<'PY'
