@@ -26,7 +26,11 @@ int bl_act_bwd_impl(const float* g_y, const float* y, int32_t nrows, int32_t N, 
                     float* g_z, float* g_bias, uint16_t* g_z_packed, void* stream);
 int bl_mp_scatter_src_accum_impl(const float* g_src, int32_t ld_src, const int32_t* src_ptr, const int32_t* src_msgs, int32_t N,
                                  int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi, int32_t ld_hi,
-                                 const int32_t* node_order, void* stream);
+                                 const int32_t* node_order, int32_t hub_slots, void* stream);
+// bl_mp_scatter_grad / _split with the number of hub entries at the front of node_order (g_h_hi == NULL: one output)
+int bl_mp_scatter_grad_hubs_impl(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs, const int32_t* tgt_ptr,
+                                 const int32_t* tgt_msgs, int32_t N, int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi,
+                                 int32_t ld_hi, const int32_t* node_order, int32_t hub_slots, void* stream);
 
 #define BL_CHECK_ARG(cond, ...)   \
   do {                            \

@@ -606,16 +606,24 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
                                                               const int* __restrict__ tgt_msgs, int N, int Din,
                                                               int accumulate, float* __restrict__ g_h, int ld_gh,
                                                               const int* __restrict__ node_order, int split,
-                                                              float* __restrict__ g_h2, int ld_gh2) {
-  const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+                                                              float* __restrict__ g_h2, int ld_gh2, int hub_slots) {
+  // The first hub_slots entries of node_order are the nodes with many incident messages (the collators put them in front).
+  // One wave walking a 512-row segment eight rows at a time is 64 dependent round trips -- at the power-law configuration
+  // that one wave WAS the kernel's duration (207 vs 152 us at hidden 256).  Workgroups 0 .. hub_slots - 1 therefore take ONE
+  // such node each, its segments cut into four contiguous shares (one per wave), partial sums merged through LDS in wave
+  // order; they are dispatched first and finish inside the time the ordinary workgroups (four nodes each) need anyway.
+  // Same launch, same registers per wave (a separate hub launch, and more rows in flight, were both measured slower).
+  __shared__ float hub_part[3][64 * NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool hub_wg = (int)blockIdx.x < hub_slots;  // (uniform over the workgroup)
+  const int slot = hub_wg ? (int)blockIdx.x : hub_slots + ((int)blockIdx.x - hub_slots) * 4 + wave;
   if (slot >= N) return;
   const int n = node_order ? node_order[slot] : slot;  // hubs first (see segment_max_kernel)
   float acc[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int d = lane + 64 * j;
-    acc[j] = (accumulate && d < Din) ? (d < split ? g_h[(size_t)n * ld_gh + d] : g_h2[(size_t)n * ld_gh2 + d - split]) : 0.f;
+    acc[j] = (accumulate && d < Din && !(hub_wg && wave > 0)) ? (d < split ? g_h[(size_t)n * ld_gh + d] : g_h2[(size_t)n * ld_gh2 + d - split]) : 0.f;
   }
 #pragma unroll
   for (int part = 0; part < 2; ++part) {
@@ -623,7 +631,12 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
     const int* __restrict__ ptr = part == 0 ? src_ptr : tgt_ptr;
     const int* __restrict__ items = part == 0 ? src_msgs : tgt_msgs;
     const int coff = part == 0 ? 0 : Din;
-    const int beg = ptr[n], end = ptr[n + 1];
+    int beg = ptr[n], end = ptr[n + 1];
+    if (hub_wg) {  // this wave's contiguous share of the segment
+      const int share = (end - beg + 3) >> 2;
+      beg = min(end, beg + wave * share);
+      end = min(end, beg + share);
+    }
     for (int base = beg; base < end; base += 64) {
       const int cnt = min(64, end - base);
       const int mine = lane < cnt ? items[base + lane] : 0;
@@ -650,6 +663,18 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
         }
       }
     }
+  }
+  if (hub_wg) {  // partial sums of waves 1..3 -> wave 0, added in wave order (a fixed order: deterministic)
+    if (wave > 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) hub_part[wave - 1][lane + 64 * j] = acc[j];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int j = 0; j < NV; ++j) acc[j] += hub_part[w][lane + 64 * j];
   }
   // columns >= split go to the second output (the two inputs of a folded ConcatResidual: [stash ; current])
 #pragma unroll
@@ -880,34 +905,54 @@ int bl_act_bwd_impl(const float* g_y, const float* y, int32_t nrows, int32_t N, 
   return BL_OK;
 }
 
+// one launch of the segmented sums: hub_slots leading entries of node_order get a workgroup each (see the kernel), the
+// other nodes a wave each
+static int mp_scatter_launch(const char* who, const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
+                             const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din, int32_t accumulate, float* g_h,
+                             int32_t ld_gh, const int32_t* node_order, int32_t split, float* g_h2, int32_t ld_gh2, int32_t hub_slots,
+                             void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int hubs = (node_order && hub_slots > 0) ? min(hub_slots, N) : 0;
+  const dim3 grid(hubs + (N - hubs + 3) / 4);
+  DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), grid, dim3(256), 0, st, g_a, ld_ga, src_ptr, src_msgs, tgt_ptr,
+                                       tgt_msgs, N, Din, accumulate, g_h, ld_gh, node_order, split, g_h2, ld_gh2, hubs))
+  BL_LAUNCH_CHECK(who);
+  return BL_OK;
+}
+
 extern "C" int bl_mp_scatter_grad(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
                                   const int32_t* tgt_ptr, const int32_t* tgt_msgs, int32_t N, int32_t Din,
                                   int32_t accumulate, float* g_h, int32_t ld_gh, const int32_t* node_order, void* stream) {
   if (N == 0) return BL_OK;
   BL_CHECK_ARG(g_a && src_ptr && src_msgs && g_h && (tgt_ptr == nullptr) == (tgt_msgs == nullptr), "bl_mp_scatter_grad: null pointer");
   BL_CHECK_ARG(Din > 0 && Din <= 512 && ld_ga >= (tgt_ptr ? 2 : 1) * Din, "bl_mp_scatter_grad: Din in 1..512, ld_ga >= (1 or 2)*Din");
-  hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_a, ld_ga,
-                                       src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh, node_order, Din,
-                                       (float*)nullptr, 0))
-  BL_LAUNCH_CHECK("bl_mp_scatter_grad");
-  return BL_OK;
+  return mp_scatter_launch("bl_mp_scatter_grad", g_a, ld_ga, src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, accumulate, g_h, ld_gh, node_order,
+                           Din, nullptr, 0, 0, stream);
+}
+
+// The layer calls' form of bl_mp_scatter_grad / _split with the number of hub entries at the front of node_order
+// (bl_mp_layer_t.num_hub_slots): g_h_hi == NULL -> one output of Din columns (split ignored)
+int bl_mp_scatter_grad_hubs_impl(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs, const int32_t* tgt_ptr,
+                                 const int32_t* tgt_msgs, int32_t N, int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi,
+                                 int32_t ld_hi, const int32_t* node_order, int32_t hub_slots, void* stream) {
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(g_a && src_ptr && src_msgs && tgt_ptr && tgt_msgs && g_h_lo && Din > 0 && Din <= 512 && ld_ga >= 2 * Din,
+               "bl_mp_scatter_grad (layer call): bad argument");
+  BL_CHECK_ARG(g_h_hi == nullptr || (split > 0 && split < Din && ld_lo >= split && ld_hi >= Din - split), "bl_mp_scatter_grad (layer call): split");
+  return mp_scatter_launch("bl_mp_scatter_grad", g_a, ld_ga, src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, 0, g_h_lo, ld_lo, node_order,
+                           g_h_hi ? split : Din, g_h_hi, ld_hi, hub_slots, stream);
 }
 
 // g_h (+)= sums of the SOURCE-half rows g_src [E, Din] over the source CSR (the second step of the half-atomic input gradient,
 // bl_routed_dgrad_nodes_rows); split / g_h_hi as in bl_mp_scatter_grad_split, accumulate on top of what the atomics left there
 int bl_mp_scatter_src_accum_impl(const float* g_src, int32_t ld_src, const int32_t* src_ptr, const int32_t* src_msgs, int32_t N,
                                  int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi, int32_t ld_hi,
-                                 const int32_t* node_order, void* stream) {
+                                 const int32_t* node_order, int32_t hub_slots, void* stream) {
   if (N == 0) return BL_OK;
   BL_CHECK_ARG(g_src && src_ptr && src_msgs && g_h_lo && Din > 0 && Din <= 512 && ld_src >= Din, "bl_mp_scatter_src_accum: bad argument");
   BL_CHECK_ARG((split == Din && g_h_hi == nullptr) || (split > 0 && split < Din && g_h_hi), "bl_mp_scatter_src_accum: split");
-  hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_src, ld_src, src_ptr,
-                                       src_msgs, (const int*)nullptr, (const int*)nullptr, N, Din, 1, g_h_lo, ld_lo, node_order,
-                                       split, g_h_hi, ld_hi))
-  BL_LAUNCH_CHECK("bl_mp_scatter_src_accum");
-  return BL_OK;
+  return mp_scatter_launch("bl_mp_scatter_src_accum", g_src, ld_src, src_ptr, src_msgs, nullptr, nullptr, N, Din, 1, g_h_lo, ld_lo, node_order,
+                           split, g_h_hi, ld_hi, hub_slots, stream);
 }
 
 extern "C" int bl_mp_scatter_grad_split(const float* g_a, int32_t ld_ga, const int32_t* src_ptr, const int32_t* src_msgs,
@@ -918,12 +963,8 @@ extern "C" int bl_mp_scatter_grad_split(const float* g_a, int32_t ld_ga, const i
   BL_CHECK_ARG(g_a && src_ptr && src_msgs && tgt_ptr && tgt_msgs && g_h_lo && g_h_hi, "bl_mp_scatter_grad_split: null pointer");
   BL_CHECK_ARG(Din > 0 && Din <= 512 && ld_ga >= 2 * Din && split > 0 && split < Din && ld_lo >= split && ld_hi >= Din - split,
                "bl_mp_scatter_grad_split: Din in 1..512, 0 < split < Din, ld_ga >= 2*Din");
-  hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NV(Din, hipLaunchKernelGGL((mp_scatter_grad_kernel<NV>), dim3((N + 3) / 4), dim3(256), 0, st, g_a, ld_ga,
-                                       src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, 0, g_h_lo, ld_lo, node_order, split,
-                                       g_h_hi, ld_hi))
-  BL_LAUNCH_CHECK("bl_mp_scatter_grad_split");
-  return BL_OK;
+  return mp_scatter_launch("bl_mp_scatter_grad_split", g_a, ld_ga, src_ptr, src_msgs, tgt_ptr, tgt_msgs, N, Din, 0, g_h_lo, ld_lo, node_order,
+                           split, g_h_hi, ld_hi, 0, stream);
 }
 
 extern "C" int bl_gru_cell_fwd(const float* gi, const float* gh, const float* h, int32_t ld_h, int32_t N, int32_t D,

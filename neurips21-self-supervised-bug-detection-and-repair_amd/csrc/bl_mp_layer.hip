@@ -415,7 +415,7 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
       BL_TRY(bl_routed_dgrad_nodes_rows(B.g_ln, Dm, L->msg_src, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, Din, split,
                                         g_h_lo, ld_lo, g_h_hi, ld_hi, B.g_a, Din, st));
       BL_TRY(bl_mp_scatter_src_accum_impl(B.g_a, Din, L->src_ptr, L->src_msgs, N, Din, split, g_h_lo, ld_lo, g_h_hi, ld_hi,
-                                          node_order, st));
+                                          node_order, L->num_hub_slots, st));
     } else if (vec_dgrad) {
       ProfScope ps(9, 2.0 * N * (2.0 * Din) * Dm, st, two);
       BL_TRY(bl_routed_dgrad_vec(B.g_ln, Dm, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, 2 * Din, B.g_a, 2 * Din, st));
@@ -432,12 +432,8 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   if (!fused_sums) {
     ProfScope ps(10, 0.0, st, two);
     // E == 0: both CSRs are empty and g_a is never read
-    if (g_h_hi == nullptr)
-      BL_TRY(bl_mp_scatter_grad(B.g_a, 2 * Din, L->src_ptr, L->src_msgs, L->tgt_ptr, L->tgt_msgs, N, Din, 0, g_h_lo, ld_lo,
-                                node_order, st));
-    else
-      BL_TRY(bl_mp_scatter_grad_split(B.g_a, 2 * Din, L->src_ptr, L->src_msgs, L->tgt_ptr, L->tgt_msgs, N, Din, width_lo, g_h_lo,
-                                      ld_lo, g_h_hi, ld_hi, node_order, st));
+    BL_TRY(bl_mp_scatter_grad_hubs_impl(B.g_a, 2 * Din, L->src_ptr, L->src_msgs, L->tgt_ptr, L->tgt_msgs, N, Din, width_lo, g_h_lo, ld_lo,
+                                        g_h_hi, ld_hi, node_order, L->num_hub_slots, st));
   }
   if (two && join_side) {
     (void)hipEventRecord(ev->join, side);
