@@ -179,7 +179,8 @@ def cpu_baseline(args, seconds_budget=30.0):
     from oracle import buglab_oracle as O
 
     nb = 4
-    cfg = O.OracleConfig(hidden=args.hidden, num_layers=args.layers, num_edge_types=args.types, dropout=args.dropout)
+    cfg = O.OracleConfig(hidden=args.hidden, num_layers=args.layers, num_edge_types=args.types, dropout=args.dropout,
+                         msg_act_placement=getattr(args, "placement", "aggregated"))
     samples = make_samples(nb, seed=123, num_nodes=args.nodes, num_messages=args.messages, num_edge_types=args.types)
     t0 = time.perf_counter()
     mb = collate_samples(samples, args.types)
@@ -336,6 +337,9 @@ def main():
     ap.add_argument("--messages", type=int, default=10000)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--degree", default="uniform", choices=["uniform", "powerlaw"], help="in-degree law (powerlaw = BASELINE config c4, max 512)")
+    ap.add_argument("--placement", default="aggregated", choices=["aggregated", "message"],
+                    help="where the message activation (GELU) sits relative to the max aggregation: on the aggregated [N, Dm] tensor "
+                         "(default: ptgnn's order as recollected, DESIGN.md section 2) or on every message before the max (rounds 1-5)")
     ap.add_argument("--serial", action="store_true", help="weight-gradient GEMMs on the main stream everywhere (no side-stream overlap): the run "
                     "whose rocprofv3 --kernel-trace --stats averages are the exclusive kernel times the roofline quotes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -407,7 +411,7 @@ def main():
             mb_ = to_device(collate_samples(samples, a.types), device)
             # what the registry's gnn() builds: layer dropout a.dropout, node-embedder dropout 0 (reference modelregistry.py:79-82)
             module_ = build_gnn_mlp_module(a.hidden, a.layers, a.types, dropout_rate=a.dropout, dropout_base_seed=rank,
-                                           embedder_dropout_rate=0.0).to(device).train()
+                                           embedder_dropout_rate=0.0, message_activation_placement=a.placement).to(device).train()
         opt_ = FlatAdam(module_.parameters())
         if world > 1:
             opt_.broadcast_parameters(0)  # what the trainer does before its first step
@@ -564,6 +568,10 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         also["configs[2] gnn-mlp hidden=256 layers=8 edge_types=16 batch=32 graphs/GPU"] = side_config(hidden=256, graphs=32)
+        # the reference's own minibatch regime: stop_extending_minibatch_after_num_nodes = 30000 (modelregistry.py:53) = 15 graphs of 2000 nodes
+        also["reference minibatch regime: configs[1] model, batch=15 graphs/GPU (30000 nodes: modelregistry.py:53)"] = side_config(graphs=15)
+        other = "message" if args.placement == "aggregated" else "aggregated"
+        also[f"configs[1] with message_activation_placement={other} (the non-default placement of the one unpinned spec point)"] = side_config(placement=other)
         if world == 1:
             also["configs[4] seq-great hidden=256 layers=5 heads=8 ff=1024 batch=32 sequences x 512 tokens"] = side_config(
                 model="seq-great", hidden=256, graphs=32, layers=5, types=8, dropout=0.1)
@@ -592,6 +600,7 @@ def main():
                             (f"gnn-mlp hidden={args.hidden} layers={args.layers} edge_types={args.types} "
                              f"batch={args.graphs} graphs/GPU x ({args.nodes} nodes, {args.messages} msgs) dropout={args.dropout}"
                              + (" power-law in-degree (max 512)" if args.degree == "powerlaw" else "")),
+                **({} if seq else {"message_activation_placement": args.placement}),
                 "global_batch": args.graphs * world,
                 "parallelism": f"dp{world}",
                 "loss_last_step": round(last_loss, 5),

@@ -29,8 +29,10 @@ extern "C" {
 #define BL_EINVAL (-1) /* bad argument (null pointer, misaligned, unsupported size) */
 #define BL_ERANGE (-2) /* dimension outside what the kernels were built for */
 
-/* activation codes shared by every entry point */
-enum { BL_ACT_NONE = 0, BL_ACT_RELU = 1, BL_ACT_SIGMOID = 2, BL_ACT_TANH = 3, BL_ACT_GELU = 4 };
+/* activation codes shared by every entry point.  BL_ACT_GELU_AGG is accepted only where a segmented max is involved
+ * (bl_segment_max_fwd / _bwd, bl_mp_layer_t.msg_act): GELU applied to the AGGREGATE, out = gelu(max_i x_i), instead of to every
+ * item before the max, out = max_i gelu(x_i) (BL_ACT_GELU) -- the two placements of ptgnn's `message_activation`. */
+enum { BL_ACT_NONE = 0, BL_ACT_RELU = 1, BL_ACT_SIGMOID = 2, BL_ACT_TANH = 3, BL_ACT_GELU = 4, BL_ACT_GELU_AGG = 5 };
 
 const char* bl_last_error(void);
 int bl_version(void);
@@ -209,6 +211,7 @@ int bl_gemm_wgrad_routed(const bl_rows_t* a, const float* g_node, int32_t ld_g, 
 /* ---------------------------------------------------------------------------------------------
  * M2(+M3a)  segmented max with argmax, optional fused LayerNorm.
  *   out[v, d] = max_{i in seg_ptr[v]..seg_ptr[v+1]} act(x[item(i), d]),  item(i) = seg_items ? seg_items[i] : i
+ *   (act = BL_ACT_GELU_AGG: out[v, d] = gelu(max_i x[item(i), d]) -- the winner is the largest RAW item)
  *   arg[v, d] = that item (ties: first in segment order), -1 and out = 0 for an empty segment;
  *   if ln_g != NULL also  ln_out[v,:] = LayerNorm(out[v,:]; ln_g, ln_b, eps), mean[v], rstd[v];
  *   if dact != NULL also  dact[v, d] = act'(x[arg[v, d], d]) (0 for an empty segment): with it the
@@ -307,7 +310,9 @@ int bl_gru_cell_bwd(const float* g_out, const float* gi, const float* gh, const 
  * MlpMessagePassingLayer.forward and its autograd; kwargs of the reference call site
  * buglab/models/gnnlayerdefs.py:6-23 map to Din = input_state_dimension, Dm = message_dimension,
  * Dout = output_state_dimension, T = num_edge_types, aggregation "max", drop.p = dropout_rate.
- *   m_e = act_msg([h_src ; h_tgt] . W[type(e)]);  a_v = max_{e -> v} m_e (0 if none);
+ *   msg_act BL_ACT_GELU_AGG (ptgnn's order as recollected, the product's default):
+ *     m_e = [h_src ; h_tgt] . W[type(e)];  a_v = gelu(max_{e -> v} m_e) (0 if none);
+ *   msg_act BL_ACT_GELU: m_e = gelu([h_src ; h_tgt] . W[type(e)]);  a_v = max_{e -> v} m_e (0 if none);  BL_ACT_NONE: no gelu;
  *   h'_v = Dropout(tanh(LayerNorm(a_v; ln_g, ln_b, ln_eps) . Wd + bd))
  * Widths: Din, Dm multiples of 32 (the message GEMMs run as bf16x6), Dm <= 512.  Messages are type-major
  * (type_ptr [T+1]) and target-sorted inside a type; tgt_ptr/tgt_msgs and src_ptr/src_msgs are the CSRs node ->
@@ -319,7 +324,7 @@ typedef struct {
   const float *ln_g, *ln_b;       /* [Dm] */
   const float* Wd;                /* [Dm, Dout] */
   const float* bd;                /* [Dout] */
-  int32_t msg_act;                /* BL_ACT_GELU or BL_ACT_NONE */
+  int32_t msg_act;                /* BL_ACT_GELU_AGG, BL_ACT_GELU or BL_ACT_NONE */
   float ln_eps;
   bl_dropout_t drop;
   const float* Wt;                /* optional (backward only): W transposed, [T, Dm, 2 Din].  When given and

@@ -306,7 +306,8 @@ def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_
                          dropout_rate: float = 0.2, message_activation: str = "gelu",
                          buggy_samples_weight: float = 1.0, dropout_base_seed: int = 0, model: str = "gnn-mlp",
                          edge_feature_size: int = 0, edge_vocabulary_size: int = 0,
-                         embedder_dropout_rate: Optional[float] = None) -> GnnBugLabModule:
+                         embedder_dropout_rate: Optional[float] = None,
+                         message_activation_placement: str = "aggregated") -> GnnBugLabModule:
     """Device module for given hyper-parameters without a metadata pass (bench / tests / synthetic
     runs).  `GnnBugLabModel.build_neural_module()` goes through the same constructors.
     `embedder_dropout_rate`: dropout of the node embedder; None = `dropout_rate` (the oracle's single-rate
@@ -327,7 +328,8 @@ def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_
         recipe = create_ggnn_mp_layers(hidden_state_size, dropout_rate, num_edge_types)
     else:
         recipe = create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edge_types, features_dimension=edge_feature_size,
-                                      num_layers=num_layers, message_activation=message_activation)
+                                      num_layers=num_layers, message_activation=message_activation,
+                                      message_activation_placement=message_activation_placement)
     return GnnBugLabModule(GraphNeuralNetwork(embed, recipe, edge_embedder=edge_embed), rewrite_vocabulary_size,
                            buggy_samples_weight_schedule=partial(const_weight_schedule, weight=buggy_samples_weight),
                            dropout_base_seed=dropout_base_seed)

@@ -16,8 +16,20 @@ from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4
-_ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH, "gelu": ACT_GELU}
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GELU, ACT_GELU_AGG = 0, 1, 2, 3, 4, 5
+# "gelu_aggregated": GELU on the aggregate of a segmented max (gelu(max x)) instead of on every item (max gelu(x)) -- only
+# meaningful as a message-passing layer's `msg_act` / segment_max's `act`
+_ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH, "gelu": ACT_GELU,
+         "gelu_aggregated": ACT_GELU_AGG}
+
+
+def message_activation_code(activation: str, placement: str = "aggregated") -> str:
+    """(message_activation, message_activation_placement) of an MlpMessagePassingLayer -> the `msg_act` name of mp_layer()."""
+    if activation not in ("gelu", "none"):
+        raise ValueError(f"message_activation must be 'gelu' or 'none' (got {activation!r})")
+    if placement not in ("aggregated", "message"):
+        raise ValueError(f"message_activation_placement must be 'aggregated' or 'message' (got {placement!r})")
+    return "gelu_aggregated" if (activation == "gelu" and placement == "aggregated") else activation
 LIB_NAME = "libbuglab_hip.so"
 LIB_PATH = os.environ.get("BL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)  # BL_HIP_LIB: tuning builds
 
@@ -1373,7 +1385,7 @@ class _MpLayerFeat(torch.autograd.Function):
         return g_h, g_W, g_lng, g_lnb, g_Wd, g_bd, g_table, None, None, None, None
 
 
-def mp_layer_with_edge_features(h, W, ln_g, ln_b, Wd, bd, table, msg_feat, graph: GraphIndex, msg_act: str = "gelu",
+def mp_layer_with_edge_features(h, W, ln_g, ln_b, Wd, bd, table, msg_feat, graph: GraphIndex, msg_act: str = "gelu_aggregated",
                                 drop: Dropout = NO_DROPOUT):
     """mp_layer with [h_src ; h_tgt ; table[msg_feat]] as the message input (W: [T, 2 Din + F, Dm])."""
     if isinstance(h, (tuple, list)):
@@ -1381,7 +1393,7 @@ def mp_layer_with_edge_features(h, W, ln_g, ln_b, Wd, bd, table, msg_feat, graph
     return _MpLayerFeat.apply(h.contiguous(), W, ln_g, ln_b, Wd, bd, table, msg_feat, graph, _ACTS[msg_act], drop)
 
 
-def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu", drop: Dropout = NO_DROPOUT):
+def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu_aggregated", drop: Dropout = NO_DROPOUT):
     """h: the node states [N, Din], or a pair (stash, current) standing for their concatenation (ConcatResidual)."""
     pair = isinstance(h, (tuple, list))
     Din = sum(t.shape[1] for t in h) if pair else h.shape[1]

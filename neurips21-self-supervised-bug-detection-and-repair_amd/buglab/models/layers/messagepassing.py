@@ -3,10 +3,12 @@ GraphNeuralNetwork container -- the roles ptgnn plays in the reference (call sit
 buglab/models/gnnlayerdefs.py:5-39, modelregistry.py:59-90, gnn.py:70-76,116-123).
 
 Arithmetic spec (frozen here because ptgnn's source is unavailable):
-  message    m_e  = act_msg([h_src ; h_tgt] @ W[type(e)])     W: [T, 2*Din, Dm], no bias
+  message    m_e  = [h_src ; h_tgt] @ W[type(e)]              W: [T, 2*Din, Dm], no bias
   aggregate  a_v  = max over incoming messages (0 if none; ties -> lowest message id)
+  activation message_activation_placement = "aggregated" (default, ptgnn's order as recollected): a_v <- gelu(a_v);
+             "message" (this repository's rounds 1-5): m_e <- gelu(m_e) before the max
   update     h'_v = Dropout(tanh(LayerNorm(a_v) @ Wd + bd))
-  edge features (features_dimension F > 0): m_e = act_msg([h_src ; h_tgt ; f_e] @ W[type(e)]), W: [T, 2*Din + F, Dm],
+  edge features (features_dimension F > 0): m_e = [h_src ; h_tgt ; f_e] @ W[type(e)], W: [T, 2*Din + F, Dm],
              f_e = edge-embedding row of the edge's feature token (reversed edge: its forward edge's; self loop: pad)
 Every FLOP runs in libbuglab_hip (buglab.models.hip_ops); this file only owns parameters.
 """
@@ -72,19 +74,26 @@ class MlpMessagePassingLayer(nn.Module):
 
     def __init__(self, input_state_dimension: int, message_dimension: int, output_state_dimension: int,
                  num_edge_types: int, message_aggregation_function: str = "max", dropout_rate: float = 0.0,
-                 features_dimension: int = 0, message_activation: str = "gelu"):
+                 features_dimension: int = 0, message_activation: str = "gelu",
+                 message_activation_placement: str = "aggregated"):
         super().__init__()
+        hip_ops.message_activation_code(message_activation, message_activation_placement)  # validates both
         if message_aggregation_function != "max":
             raise NotImplementedError("the HIP path implements the reference's `max` aggregation (gnnlayerdefs.py:11,21)")
         din, dm, dout, T = input_state_dimension, message_dimension, output_state_dimension, num_edge_types
         self.input_state_dimension, self.message_dimension, self.output_state_dimension = din, dm, dout
         self.num_edge_types, self.dropout_rate, self.message_activation = T, dropout_rate, message_activation
+        self.message_activation_placement = message_activation_placement
         self.features_dimension = F = int(features_dimension)  # edge features: the message input is [h_src ; h_tgt ; f_e]
         self.W = nn.Parameter(_uniform_(torch.empty(T, 2 * din + F, dm), 1.0 / math.sqrt(2 * din + F)))
         self.ln_g = nn.Parameter(torch.ones(dm))
         self.ln_b = nn.Parameter(torch.zeros(dm))
         self.Wd = nn.Parameter(_uniform_(torch.empty(dm, dout), math.sqrt(6.0 / (dm + dout))))
         self.bd = nn.Parameter(_uniform_(torch.empty(dout), 1.0 / math.sqrt(dm)))
+
+    def _msg_act(self) -> str:
+        # a module pickled before round 6 has no placement attribute: it was trained with the per-message placement
+        return hip_ops.message_activation_code(self.message_activation, getattr(self, "message_activation_placement", "message"))
 
     def forward(self, node_states, graph: GraphIndex, drop: Dropout, edge_features=None):
         """edge_features: (table [V, F], msg_feat int32 [E]) when the layer was built with features_dimension = F > 0."""
@@ -93,9 +102,8 @@ class MlpMessagePassingLayer(nn.Module):
                 raise ValueError("this layer was built with features_dimension > 0: the minibatch must carry `msg_feat`")
             table, msg_feat = edge_features
             return hip_ops.mp_layer_with_edge_features(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, table, msg_feat,
-                                                       graph, self.message_activation, drop)
-        return hip_ops.mp_layer(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, graph,
-                                self.message_activation, drop)
+                                                       graph, self._msg_act(), drop)
+        return hip_ops.mp_layer(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, graph, self._msg_act(), drop)
 
 
 class GatedMessagePassingLayer(nn.Module):

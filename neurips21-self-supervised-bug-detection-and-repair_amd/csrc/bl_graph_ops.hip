@@ -251,6 +251,14 @@ __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int l
   for (int j = 0; j < NV; ++j) {
     const int d = lane + 64 * j;
     if (barg[j] < 0) best[j] = 0.f;  // empty segment (torch_scatter leaves 0) or padding lane
+    float dv_agg = 0.f;
+    if (act == BL_ACT_GELU_AGG && barg[j] >= 0) {
+      // activation on the AGGREGATE (ptgnn's order): the scan compared raw messages, best[j] is the largest one; one erf per
+      // (segment, channel) gives both gelu(best) and gelu'(best)
+      const float r = best[j], er = erff(r * 0.70710678118654752440f);
+      dv_agg = 0.5f * (1.0f + er) + r * (0.39894228040143267794f * expf(-0.5f * r * r));
+      best[j] = 0.5f * r * (1.0f + er);
+    }
     if (d < D) {
       if (out) out[(size_t)seg * D + d] = best[j];  // (forward-only layer calls keep nothing but the LayerNorm output)
       if (arg) arg[(size_t)seg * D + d] = barg[j];
@@ -259,7 +267,9 @@ __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int l
         float dv = 1.f;
         // (the winner's raw message is in a register: re-reading it would be 64 scattered 4-byte loads per wave,
         // several times the address-coalescing work of the whole message sweep above)
-        if (act == BL_ACT_GELU) {
+        if (act == BL_ACT_GELU_AGG) {
+          dv = dv_agg;
+        } else if (act == BL_ACT_GELU) {
           if (GELU2)  // bl_gelu_grad(raw) with the erf that segmax_pick already evaluated
             dv = barg[j] >= 0 ? 0.5f * (1.0f + werf[j]) + raw[j] * (0.39894228040143267794f * expf(-0.5f * raw[j] * raw[j])) : 0.f;
           else
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __res
   if (a.x == i || a.y == i || a.z == i || a.w == i) {
     const float4 go = *reinterpret_cast<const float4*>(g_out + (size_t)seg * D + d);
     float4 dv = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (act == BL_ACT_GELU) {
+    if (act == BL_ACT_GELU || act == BL_ACT_GELU_AGG) {  // the winner's raw item IS the aggregate's pre-activation: same derivative
       const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)i * ldx + d);
       dv.x = bl_gelu_grad(xv.x); dv.y = bl_gelu_grad(xv.y); dv.z = bl_gelu_grad(xv.z); dv.w = bl_gelu_grad(xv.w);
     }
@@ -812,7 +822,7 @@ int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr,
   // arg (the winner table) is optional; so are out / mean / rstd when only the LayerNorm output is wanted (forward-only calls)
   BL_CHECK_ARG(seg_ptr && (out || ln_g), "bl_segment_max_fwd: null pointer");
   BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_max_fwd: D must be in 1..512 (got %d)", D);
-  BL_CHECK_ARG(act == BL_ACT_NONE || act == BL_ACT_GELU, "bl_segment_max_fwd: act must be NONE or GELU");
+  BL_CHECK_ARG(act == BL_ACT_NONE || act == BL_ACT_GELU || act == BL_ACT_GELU_AGG, "bl_segment_max_fwd: act must be NONE, GELU or GELU_AGG");
   const bool has_ln = ln_g != nullptr;
   BL_CHECK_ARG(!has_ln || (ln_b && (ln_out || ln_out_packed) && (mean == nullptr) == (rstd == nullptr)), "bl_segment_max_fwd: LayerNorm outputs missing");
   BL_CHECK_ARG(ln_out_packed == nullptr || (has_ln && D % 8 == 0), "bl_segment_max_fwd: the packed LayerNorm output needs D %% 8 == 0");
@@ -846,7 +856,7 @@ extern "C" int bl_segment_max_bwd(const float* g_out, const int32_t* arg, const 
   if (nitems == 0) return BL_OK;
   BL_CHECK_ARG(g_out && arg && seg_of && g_x, "bl_segment_max_bwd: null pointer");
   BL_CHECK_ARG(D > 0 && D % 4 == 0 && ldx % 4 == 0, "bl_segment_max_bwd: D and ldx must be multiples of 4");
-  BL_CHECK_ARG(act == BL_ACT_NONE || (act == BL_ACT_GELU && x), "bl_segment_max_bwd: act must be NONE or GELU (+x)");
+  BL_CHECK_ARG(act == BL_ACT_NONE || ((act == BL_ACT_GELU || act == BL_ACT_GELU_AGG) && x), "bl_segment_max_bwd: act must be NONE or GELU / GELU_AGG (+x)");
   const long long total = (long long)nitems * (D / 4);
   hipLaunchKernelGGL(segment_max_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      g_out, arg, x, ldx, seg_of, (long long)nitems, D, act, g_x);

@@ -192,7 +192,8 @@ int check_layer(const bl_mp_layer_t* L, const char* who) {
   BL_CHECK_ARG(L->type_ptr && L->tgt_ptr && L->src_ptr && (L->E == 0 || (L->msg_src && L->msg_tgt && L->tgt_msgs && L->src_msgs)),
                "%s: null graph index array", who);
   BL_CHECK_ARG(L->W && L->ln_g && L->ln_b && L->Wd && L->bd, "%s: null parameter", who);
-  BL_CHECK_ARG(L->msg_act == BL_ACT_NONE || L->msg_act == BL_ACT_GELU, "%s: message activation must be none or gelu", who);
+  BL_CHECK_ARG(L->msg_act == BL_ACT_NONE || L->msg_act == BL_ACT_GELU || L->msg_act == BL_ACT_GELU_AGG,
+               "%s: message activation must be none, gelu (per message) or gelu_agg (on the aggregate)", who);
   return BL_OK;
 }
 }  // namespace

@@ -75,8 +75,14 @@ def apply_dropout(x: torch.Tensor, p: float, seed: Optional[int], stream: int) -
 class MpSpec:
     """Frozen spec of ptgnn's MlpMessagePassingLayer as this repo defines it.
 
-    message     m_e = act_msg( [h_src(e) ; h_tgt(e)] @ W[type(e)] )      W: [T, 2*Din, Dm], no bias
+    message     m_e = [h_src(e) ; h_tgt(e)] @ W[type(e)]                 W: [T, 2*Din, Dm], no bias
     aggregate   a_v = max_{e -> v} m_e  (per channel); empty segment -> 0; ties -> lowest message index
+    activation  msg_act_placement "aggregated" (default): a_v <- act_msg(a_v), on the [N, Dm] aggregate -- the order of
+                public ptgnn's MlpMessagePassingLayer.forward as recollected (Linear per type -> aggregate ->
+                message_activation -> LayerNorm -> Linear -> tanh -> Dropout; the reference passes no activation
+                kwarg, gnnlayerdefs.py:6-23, so ptgnn's default nn.GELU() governs);
+                "message": m_e <- act_msg(m_e) before the max (rounds 1-5 of this repository).  GELU is not
+                monotone (minimum at -0.7518), so the two differ in value AND in routing.
     update      h'_v = Dropout( tanh( LayerNorm(a_v; eps 1e-5) @ Wd + bd ) )
     Kwargs pinned by the reference call site (gnnlayerdefs.py:6-23): input/message/output
     dimension, num_edge_types, aggregation "max", dropout_rate.  Everything else above is the
@@ -87,6 +93,7 @@ class MpSpec:
     dm: int
     dout: int
     msg_act: str = "gelu"  # "gelu" (exact erf form) or "none"
+    msg_act_placement: str = "aggregated"  # "aggregated" (after the max, ptgnn's order) or "message" (before it)
     # edge features (`features_dimension` = F > 0, gnnlayerdefs.py:13,22): the message input is [h_src ; h_tgt ; f_e],
     # W: [T, 2*Din + F, Dm]; f_e = row of the edge-embedding table picked by the edge's feature token (modelregistry.py:70-74)
     features_dimension: int = 0
@@ -124,6 +131,7 @@ class OracleConfig:
     rewrite_vocab_size: int = 48
     dropout: float = 0.0
     msg_act: str = "gelu"
+    msg_act_placement: str = "aggregated"  # see MpSpec
     buggy_samples_weight: float = 1.0
     abstain_weight: float = 0.0  # LocalizationModule(abstain_weight=...), localizationmodule.py:15,95-100
     use_all_gnn_layer_outputs: bool = False  # gnn.py:68-74,118-121
@@ -255,8 +263,12 @@ def _gelu(x):
 # M1-M3  one MlpMessagePassingLayer (spec: MpSpec)
 # ----------------------------------------------------------------------------
 def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_drop, seed, stream, trace=None, force_arg=None,
-             feat=None):
-    """feat: [E, F] per-message edge-feature embeddings (message order), or None."""
+             feat=None, msg_act_placement="aggregated"):
+    """feat: [E, F] per-message edge-feature embeddings (message order), or None.
+    msg_act_placement: where the message activation sits relative to the max (MpSpec)."""
+    assert msg_act in ("gelu", "none") and msg_act_placement in ("aggregated", "message")
+    act_before = msg_act == "gelu" and msg_act_placement == "message"
+    act_after = msg_act == "gelu" and msg_act_placement == "aggregated"
     N = h.shape[0]
     src = torch.as_tensor(msg_src, dtype=torch.int64)
     tgt = torch.as_tensor(msg_tgt, dtype=torch.int64)
@@ -267,7 +279,7 @@ def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_dr
         a = torch.cat(parts, dim=-1)  # [E_t, 2*Din (+ F)]
         msgs.append(a @ W[t])
     pre = torch.cat(msgs, dim=0) if msgs else h.new_zeros((0, W.shape[2]))
-    m = _gelu(pre) if msg_act == "gelu" else pre
+    m = _gelu(pre) if act_before else pre  # the values the max compares
     agg, arg = scatter_max_with_arg(m, tgt, N)
     if force_arg is not None:
         # routing injected by a test: take the given message per (node, channel) instead of this layer's own
@@ -275,6 +287,8 @@ def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_dr
         E = m.shape[0]
         fa = torch.as_tensor(force_arg, dtype=torch.int64)
         agg = torch.where(fa >= E, torch.zeros_like(agg), m.gather(0, fa.clamp(max=max(E - 1, 0)))) if E else agg
+    if act_after:
+        agg = _gelu(agg)  # an empty segment's 0 stays 0
     ln = torch.nn.functional.layer_norm(agg, (agg.shape[1],), ln_g, ln_b, eps=1e-5)
     out = torch.tanh(ln @ Wd + bd)
     out = apply_dropout(out, p_drop, seed, stream)
@@ -346,6 +360,7 @@ def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None, force_arg=
                 trace=trace,
                 force_arg=None if force_arg is None else force_arg[li],
                 feat=feat,
+                msg_act_placement=cfg.msg_act_placement,
             )
         if op[0] in ("gg", "mp"):
             all_states.append(h)

@@ -135,6 +135,34 @@ def test_node_embedder_dropout_comes_from_node_representations_only():
     assert m.gnn_model.node_representation_model.dropout_rate == 0.0
 
 
+def test_message_activation_placement_reaches_every_layer_and_old_pickles_keep_theirs():
+    """`message_activation_placement` enters through the registry's kwargs dict like `num_layers` (default "aggregated" =
+    ptgnn's order as recollected); a module pickled before the switch existed has no such attribute
+    and keeps the per-message placement it was trained with."""
+    from buglab.models import hip_ops
+    from buglab.models.gnn import build_gnn_mlp_module
+    from buglab.models.layers.messagepassing import MlpMessagePassingLayer
+
+    assert hip_ops.message_activation_code("gelu") == "gelu_aggregated"
+    assert hip_ops.message_activation_code("gelu", "message") == "gelu"
+    assert hip_ops.message_activation_code("none", "aggregated") == "none"
+    with pytest.raises(ValueError):
+        hip_ops.message_activation_code("gelu", "sideways")
+    with pytest.raises(ValueError):
+        MlpMessagePassingLayer(8, 8, 8, 2, message_activation="swish")
+    for kw, want in (({}, "gelu_aggregated"), ({"message_activation_placement": "message"}, "gelu"),
+                     ({"message_activation": "none"}, "none")):
+        creator = _model(**kw).gnn_model.message_passing_layer_creator
+        layers = [l for l in creator(5) if isinstance(l, MlpMessagePassingLayer)]
+        assert len(layers) == 4 and all(l._msg_act() == want for l in layers), (kw, [l._msg_act() for l in layers])
+    m = build_gnn_mlp_module(32, 4, 3, 50, message_activation_placement="message")
+    assert all(l._msg_act() == "gelu" for l in m._gnn.mp)
+    old = build_gnn_mlp_module(32, 4, 3, 50)
+    for l in old._gnn.mp:
+        del l.__dict__["message_activation_placement"]  # what unpickling a round-5 checkpoint yields
+        assert l._msg_act() == "gelu"
+
+
 def test_tensorize_rewrite_bookkeeping_and_drop_rule():
     data = make_buglab_dataset(10, seed=4)
     model = _model()

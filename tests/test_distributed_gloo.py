@@ -99,6 +99,29 @@ def test_partition_by_messages_balances_load():
     assert max(loads) - min(loads) <= 40
 
 
+def test_partition_by_messages_at_world_size_8():
+    """8 ranks, graphs dealt by message count.  BASELINE configs[2] / [3] (256 graphs of 10 000 messages
+    each, uniform or power-law in-degree) split exactly; a PyPI-like population of very unequal graphs (log-normal sizes over
+    two decades) stays within 3 % between the heaviest and the lightest rank -- the step time follows the messages."""
+    from buglab.data.synthetic import make_samples
+    from buglab.runtime.distributed import partition_by_messages
+
+    c4 = make_samples(32, seed=3, num_nodes=500, num_messages=2500, num_edge_types=16, degree="powerlaw", max_degree=512)
+    msgs = [int(sum(len(a) for a in s.graph_data.adjacency_lists)) for s in c4]
+    parts = partition_by_messages(msgs, 8)
+    assert sorted(i for p in parts for i in p) == list(range(32)) and {len(p) for p in parts} == {4}
+    loads = [sum(msgs[i] for i in p) for p in parts]
+    assert max(loads) == min(loads)
+    rng = np.random.default_rng(1)
+    msgs = np.exp(rng.normal(np.log(8000.0), 1.0, 256)).astype(np.int64).clip(200, 200_000).tolist()
+    parts = partition_by_messages(msgs, 8)
+    assert sorted(i for p in parts for i in p) == list(range(256))
+    loads = [sum(msgs[i] for i in p) for p in parts]
+    assert (max(loads) - min(loads)) / max(loads) <= 0.03, loads
+    by_count = [sum(msgs[i::8]) for i in range(8)]  # what dealing by graph COUNT would give
+    assert (max(by_count) - min(by_count)) / max(by_count) > 0.15
+
+
 def test_balanced_rank_share_is_a_partition_by_messages():
     from buglab.runtime.distributed import balanced_rank_share
 
@@ -231,6 +254,7 @@ def _bucket_worker(rank, world, port, out_dir):
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     D.init_from_env("cpu")
+    torch.set_num_threads(1)
     Opt = _cpu_flat_adam()
     g = torch.Generator().manual_seed(5)
     shapes = [(7, 3), (5,), (4, 6), (6,), (3, 3), (2,), (9,)]  # "embedding", layer 1 (2 tensors), layer 2 (2), "heads" (2)
@@ -240,8 +264,12 @@ def _bucket_worker(rank, world, port, out_dir):
         opt = Opt([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=0.01, num_warmup_steps=0)
         if mode == "buckets":
             assert opt.set_overlap_groups([opt.params[1:3], opt.params[3:5]])
-        for step, Bs in enumerate([(3, 2), (4, 0), (0, 0), (1, 5)]):  # graphs per rank; (4, 0): rank 1 has no minibatch; (0, 0): idle
-            B = Bs[rank]
+        # graphs per rank and step -- two ranks: (3, 2), (4, 0), (0, 0), (1, 5): at step 1 the odd ranks have no minibatch,
+        # step 2 is idle everywhere; at eight ranks ranks 6 and 7 are also dry at step 3 (they ran out at different steps)
+        plan = [lambda r: 3 - r % 2, lambda r: 0 if r % 2 else 4 - r // 2, lambda r: 0,
+                lambda r: 0 if (world > 2 and r >= world - 2) else 1 + (4 * r + 4) % 7]
+        for step, graphs_of in enumerate(plan):
+            B = graphs_of(rank)
             opt.zero_grad()
             if mode == "buckets":
                 opt.begin_data_parallel_step(B)
@@ -280,33 +308,49 @@ def _bucket_worker(rank, world, port, out_dir):
             opt.zero_grad()
             opt.begin_data_parallel_step(1)
             opt.step_data_parallel(1)
-    assert torch.equal(results["plain"][0], results["buckets"][0]), "bucketed reduction must give bit-identical parameters"
-    assert torch.equal(results["plain"][1], results["buckets"][1]) and torch.equal(results["plain"][2], results["buckets"][2])
+    if world == 2:  # one addition per element, whatever the collective's chunking: the two plans agree bit for bit
+        assert torch.equal(results["plain"][0], results["buckets"][0]), "bucketed reduction must give bit-identical parameters"
+        assert torch.equal(results["plain"][1], results["buckets"][1]) and torch.equal(results["plain"][2], results["buckets"][2])
+    else:
+        # more than two ranks: a ring / halving all-reduce adds the ranks' contributions of an element in an order that depends
+        # on the element's position in the reduced buffer, so one long buffer and the per-layer buckets round differently
+        # (1 ulp).  What must hold bit for bit is that every REPLICA sees the same sums (checked by the parent on the saved
+        # parameters and here on the gradient); the two plans agree to rounding.
+        every = [torch.zeros_like(results["buckets"][1]) for _ in range(world)]
+        dist.all_gather(every, results["buckets"][1])
+        assert all(torch.equal(every[0], e) for e in every[1:]), "replicas must hold identical reduced gradients"
+        for a, b in zip(results["plain"][:3], results["buckets"][:3]):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+    assert results["plain"][3] == results["buckets"][3]
     torch.save(results["buckets"][0], os.path.join(out_dir, f"b{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_layerwise_gradient_buckets_equal_single_allreduce(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_layerwise_gradient_buckets_equal_single_allreduce(tmp_path, world):
     """FlatAdam with overlap groups (one all-reduce per layer group issued from the backward notifications, last layer
-    first, then the remaining ranges with the tail) against the single all-reduce: bit-identical parameters on both ranks,
-    including a step where one rank has no minibatch (it issues the same collectives from step_data_parallel) and an idle
-    step; no hang under out-of-order notifications."""
-    _spawn(_bucket_worker, (2, _free_port(), str(tmp_path)))
-    assert torch.equal(torch.load(tmp_path / "b0.pt"), torch.load(tmp_path / "b1.pt"))
+    first, then the remaining ranges with the tail) against the single all-reduce: bit-identical parameters on every rank
+    (2 and 8 ranks over gloo), including steps where some ranks have no minibatch (they issue the same collectives from
+    step_data_parallel) and an idle step; no hang under out-of-order notifications or an aborted backward."""
+    _spawn(_bucket_worker, (world, _free_port(), str(tmp_path)), nprocs=world, timeout=300.0)
+    first = torch.load(tmp_path / "b0.pt")
+    for r in range(1, world):
+        assert torch.equal(first, torch.load(tmp_path / f"b{r}.pt")), r
 
 
-def test_bench_launches_itself_for_several_ranks():
-    """`python bench.py --gpus 2` with no launcher around it must become the launcher (torch.distributed.run on 127.0.0.1)
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_itself_for_several_ranks(world):
+    """`python bench.py --gpus N` with no launcher around it must become the launcher (torch.distributed.run on 127.0.0.1)
     and get both ranks through init_process_group -- the first hardware SCALE run may be started exactly like that.
     --dry-launch stops after one all-reduce (gloo here: no GPU)."""
     import json
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
-                         capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-launch"], env=env,
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
-    assert rec == {"dry_launch": True, "ok": True, "n_gpus": 2, "backend": "gloo", "rank_sum": 1.0}
+    assert rec == {"dry_launch": True, "ok": True, "n_gpus": world, "backend": "gloo", "rank_sum": world * (world - 1) / 2.0}

@@ -98,7 +98,15 @@ def test_gemm_rows_bias_act_dropout_three_sources(ops, act):
     assert ((out.cpu() == 0) == (~keep | (ref_d == 0))).all()  # identical mask, bit for bit
 
 
-@pytest.mark.parametrize("D,act", [(96, "gelu"), (320, "none"), (128, "gelu"), (8, "none")])
+def _segmax_ref_values(x, act):
+    """what the max compares, and what is applied to the aggregate afterwards (gelu_aggregated = ptgnn's order: gelu(max x))"""
+    before = O._gelu(x) if act == "gelu" else x
+    after = O._gelu if act == "gelu_aggregated" else (lambda v: v)
+    return before, after
+
+
+@pytest.mark.parametrize("D,act", [(96, "gelu"), (320, "none"), (128, "gelu"), (8, "none"), (128, "gelu_aggregated"), (96, "gelu_aggregated"),
+                                   (512, "gelu_aggregated")])
 def test_segment_max_layernorm_fwd_bwd(ops, D, act):
     rng = np.random.default_rng(2)
     nseg, E = 57, 900
@@ -116,8 +124,9 @@ def test_segment_max_layernorm_fwd_bwd(ops, D, act):
     order = np.argsort(seg, kind="stable").astype(np.int32)
     ptr[1:] = np.cumsum(np.bincount(seg, minlength=nseg))
     g, b = torch.randn(D), torch.randn(D)
-    xa = O._gelu(x.double()) if act == "gelu" else x.double()
+    xa, after = _segmax_ref_values(x.double(), act)
     ref, arg = O.scatter_max_with_arg(xa, torch.from_numpy(seg), nseg)
+    ref = after(ref)
     ref_ln = torch.nn.functional.layer_norm(ref, (D,), g.double(), b.double(), eps=1e-5)
     out, a, ln_out, mean, rstd, dact, wbits = ops.segment_max(_dev(x), _dev(ptr), _dev(order), nseg, act=ops._ACTS[act], ln=(_dev(g), _dev(b)),
                                                               want_dact=True, want_bits=True)
@@ -141,8 +150,8 @@ def test_segment_max_layernorm_fwd_bwd(ops, D, act):
     if D % 4 == 0:
         go = torch.randn(nseg, D)
         xr = x.double().requires_grad_(True)
-        xa = O._gelu(xr) if act == "gelu" else xr
-        O.scatter_max_with_arg(xa, torch.from_numpy(seg), nseg)[0].backward(go.double())
+        xa, after = _segmax_ref_values(xr, act)
+        after(O.scatter_max_with_arg(xa, torch.from_numpy(seg), nseg)[0]).backward(go.double())
         gx = ops.segment_max_bwd(_dev(go), a, _dev(x), _dev(seg.astype(np.int32)), act=ops._ACTS[act])
         assert (gx.cpu().double() - xr.grad).abs().max() < 1e-5
         # routed GEMMs: the same gradient, never materialised: G[i,:] = (go * dact)[seg[i]] masked to i's wins
@@ -618,7 +627,8 @@ def test_gather_rows_fwd_bwd(ops):
     assert (xd.grad.cpu() - ref).abs().max() < 1e-5
 
 
-def test_fused_layer_call_equals_kernel_by_kernel_path():
+@pytest.mark.parametrize("placement", ["aggregated", "message"])
+def test_fused_layer_call_equals_kernel_by_kernel_path(placement):
     """bl_mp_layer_fwd / bl_mp_layer_bwd (one C call per layer and direction, ConcatResidual input read as a
     pair) against the same kernels driven one by one from Python with a materialised concatenation."""
     from buglab.data.collate import collate_samples, to_device
@@ -628,7 +638,7 @@ def test_fused_layer_call_equals_kernel_by_kernel_path():
 
     mb = to_device(collate_samples(make_samples(3, seed=5, num_nodes=300, num_messages=1500, num_edge_types=6, vocab_size=500), 6), "cuda")
     torch.manual_seed(0)
-    module = build_gnn_mlp_module(64, 8, 6, vocabulary_size=500, dropout_rate=0.1).cuda().train()
+    module = build_gnn_mlp_module(64, 8, 6, vocabulary_size=500, dropout_rate=0.1, message_activation_placement=placement).cuda().train()
     res = {}
     for fused in (True, False):
         hip_ops.FUSED_LAYER = fused
@@ -735,8 +745,9 @@ def test_fused_node_update_backward_equals_the_three_kernel_chain(hidden):
         assert float((g - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7, k
 
 
+@pytest.mark.parametrize("placement", ["aggregated", "message"])
 @pytest.mark.parametrize("degree", ["uniform", "powerlaw"])
-def test_forward_only_layer_call_equals_the_training_forward(degree):
+def test_forward_only_layer_call_equals_the_training_forward(degree, placement):
     """bl_mp_layer_fwd with saved == NULL (what model.predict / evaluate.py run under no_grad: reference
     buglab/models/gnn.py:606-645) keeps nothing for a backward pass; its outputs are those of the training-form call, bit
     for bit -- hubs (4-wave segmented max) and a ConcatResidual input included."""
@@ -748,7 +759,7 @@ def test_forward_only_layer_call_equals_the_training_forward(degree):
     mb = to_device(collate_samples(make_samples(3, seed=9, num_nodes=400, num_messages=2400, num_edge_types=6, vocab_size=500,
                                                 degree=degree, max_degree=200), 6), "cuda")
     torch.manual_seed(1)
-    module = build_gnn_mlp_module(64, 8, 6, vocabulary_size=500, dropout_rate=0.1).cuda().eval()
+    module = build_gnn_mlp_module(64, 8, 6, vocabulary_size=500, dropout_rate=0.1, message_activation_placement=placement).cuda().eval()
     res = {}
     for infer in (True, False):
         hip_ops.INFERENCE_MODE = infer

@@ -71,20 +71,26 @@ def _check_against_oracle(cfg, mb_np, seed=None, train=True, grad_rtol=1e-4, ora
     return module, out, worst
 
 
-def test_forward_backward_matches_oracle_small():
-    cfg, _, mb = Hh.make_case(B=4, n=80, E=400, T=5, H=64, layers=4)
+PLACEMENTS = ["aggregated", "message"]  # of the message activation relative to the max (oracle MpSpec)
+
+
+@pytest.mark.parametrize("placement", PLACEMENTS)
+def test_forward_backward_matches_oracle_small(placement):
+    cfg, _, mb = Hh.make_case(B=4, n=80, E=400, T=5, H=64, layers=4, msg_act_placement=placement)
     module, out, _ = _check_against_oracle(cfg, mb)
     m = module.report_metrics()
     assert abs(m["Localization Accuracy"] - out["loc_stats"]["num_correct"] / 4) < 1e-9
 
 
-def test_forward_backward_matches_oracle_8_layers_h128():
-    cfg, _, mb = Hh.make_case(B=3, n=150, E=800, T=16, H=128, layers=8, C=10, seed=3)
+@pytest.mark.parametrize("placement", PLACEMENTS)
+def test_forward_backward_matches_oracle_8_layers_h128(placement):
+    cfg, _, mb = Hh.make_case(B=3, n=150, E=800, T=16, H=128, layers=8, C=10, seed=3, msg_act_placement=placement)
     _check_against_oracle(cfg, mb)
 
 
-def test_dropout_parity_same_counter_mask():
-    cfg, _, mb = Hh.make_case(B=3, n=60, E=300, T=4, H=64, layers=4, dropout=0.2, seed=5)
+@pytest.mark.parametrize("placement", PLACEMENTS)
+def test_dropout_parity_same_counter_mask(placement):
+    cfg, _, mb = Hh.make_case(B=3, n=60, E=300, T=4, H=64, layers=4, dropout=0.2, seed=5, msg_act_placement=placement)
     _check_against_oracle(cfg, mb, seed=777)
 
 
@@ -93,10 +99,12 @@ def test_message_activation_none_and_weighted_loss():
     _check_against_oracle(cfg, mb)
 
 
-def test_power_law_hub_degree_512():
+@pytest.mark.parametrize("placement", PLACEMENTS)
+def test_power_law_hub_degree_512(placement):
     """BASELINE config c4 shape (truncated power-law in-degree, hub of degree 512) at a size the
     oracle finishes in seconds."""
-    cfg, _, mb = Hh.make_case(B=2, n=400, E=2400, T=8, H=64, layers=4, degree="powerlaw", max_degree=512, seed=9)
+    cfg, _, mb = Hh.make_case(B=2, n=400, E=2400, T=8, H=64, layers=4, degree="powerlaw", max_degree=512, seed=9,
+                              msg_act_placement=placement)
     deg = np.diff(mb["graph_data"]["tgt_ptr"])
     assert deg.max() >= 512
     _check_against_oracle(cfg, mb)
@@ -180,20 +188,23 @@ def _check_tie_aware(cfg, mb_np, seed=None, tie_eps=1e-5, max_flip_frac=2e-3):
     return flips, total
 
 
-def test_c3_c4_shapes_hidden_256_match_oracle():
+@pytest.mark.parametrize("placement", PLACEMENTS)
+def test_c3_c4_shapes_hidden_256_match_oracle(placement):
     """BASELINE configs c3 / c4 (hidden 256, 8 layers, 16 edge types; c4 = truncated power-law in-degree with a
     512-hub) at a node count the oracle finishes in seconds.  Widths 256 / 512 / 1024 exercise the split-precision
     GEMMs with several column tiles and 8-32 k stages, and the 4-words-per-message routing bitmask.  Tie-aware:
     winner tables must match the fp64 oracle except at true near-ties, gradients at 1e-4 with the routing injected."""
-    cfg, _, mb = Hh.make_case(B=2, n=300, E=1500, T=16, H=256, layers=8, C=10, seed=11)
+    cfg, _, mb = Hh.make_case(B=2, n=300, E=1500, T=16, H=256, layers=8, C=10, seed=11, msg_act_placement=placement)
     _check_tie_aware(cfg, mb)
-    cfg, _, mb = Hh.make_case(B=2, n=400, E=2400, T=16, H=256, layers=8, C=10, degree="powerlaw", max_degree=512, dropout=0.2, seed=12)
+    cfg, _, mb = Hh.make_case(B=2, n=400, E=2400, T=16, H=256, layers=8, C=10, degree="powerlaw", max_degree=512, dropout=0.2, seed=12,
+                              msg_act_placement=placement)
     assert np.diff(mb["graph_data"]["tgt_ptr"]).max() >= 512
     _check_tie_aware(cfg, mb, seed=5)
 
 
+@pytest.mark.parametrize("placement", PLACEMENTS)
 @pytest.mark.parametrize("H,degree,B", [(128, "uniform", 2), (256, "uniform", 2), (256, "powerlaw", 2), (128, "uniform", 8), (128, "uniform", 64)])
-def test_baseline_graph_size_matches_fp64_oracle(H, degree, B):
+def test_baseline_graph_size_matches_fp64_oracle(H, degree, B, placement):
     """The BASELINE per-graph size -- 2000 nodes / 10000 messages per graph, 8 layers, 16 edge types -- on a
     2-graph minibatch (what bench.py's cpu_baseline leg runs) and, at the headline configuration's width, on an 8-graph
     one (16 000 nodes / 80 000 messages: several tiles per edge type in every GEMM, 250 tiles in the node kernels) and on the
@@ -202,11 +213,12 @@ def test_baseline_graph_size_matches_fp64_oracle(H, degree, B):
     tables equal up to near-ties, every gradient within 1e-4 (routing injected)."""
     if B >= 64 and (os.cpu_count() or 1) < 64:
         pytest.skip("the fp64 oracle of the full 64-graph minibatch needs a many-core host (3 minutes on the 256-thread GPU boxes)")
-    cfg, _, mb = Hh.make_case(B=B, n=2000, E=10000, T=16, H=H, layers=8, vocab=15000, C=40, degree=degree, max_degree=512, seed=21)
+    cfg, _, mb = Hh.make_case(B=B, n=2000, E=10000, T=16, H=H, layers=8, vocab=15000, C=40, degree=degree, max_degree=512, seed=21,
+                              msg_act_placement=placement)
     if degree == "powerlaw":
         assert np.diff(mb["graph_data"]["tgt_ptr"]).max() >= 512
     flips, total = _check_tie_aware(cfg, mb)
-    print(f"H={H} {degree} B={B}: {flips} near-tie routing differences out of {total} (node, channel) entries")
+    print(f"H={H} {degree} B={B} {placement}: {flips} near-tie routing differences out of {total} (node, channel) entries")
 
 
 def test_no_buggy_graphs_and_empty_edge_types():

@@ -85,6 +85,33 @@ def test_generator_loss_matches_reference(golden_dir, loss_type):
     np.testing.assert_allclose(h.grad.numpy(), z["grad_node_states_" + loss_type], atol=2e-6, rtol=1e-4)
 
 
+def test_message_activation_placement_hand_checked():
+    """The one spec point the reference's call site leaves to ptgnn's defaults (gnnlayerdefs.py:6-23 passes no activation):
+    GELU on every message before the max ("message") or on the aggregated [N, Dm] tensor ("aggregated", default).  A toy layer
+    whose messages are known numbers: node 0 receives raw messages {-3.0, -0.7}, node 1 {0.5, 2.0}, node 2 nothing.
+    gelu(-3.0) = -0.00405 > gelu(-0.7) = -0.1694: per-message placement routes node 0 to the -3.0 message, the aggregated
+    placement to the -0.7 one -- value AND routing differ; on the monotone side (node 1) they agree."""
+    import math
+
+    h = torch.tensor([[-3.0], [-0.7], [0.5], [2.0]], dtype=torch.float64)  # 4 nodes, Din = 1
+    W = torch.tensor([[[1.0], [0.0]]], dtype=torch.float64)  # one type: message = h[src]
+    src, tgt = np.array([0, 1, 2, 3], np.int64), np.array([0, 0, 1, 1], np.int64)
+    ident = dict(ln_g=torch.ones(1, dtype=torch.float64), ln_b=torch.zeros(1, dtype=torch.float64))
+    gelu = lambda x: 0.5 * x * (1.0 + math.erf(x / math.sqrt(2.0)))
+    for placement, want_agg, want_arg in (("aggregated", [gelu(-0.7), gelu(2.0), 0.0, 0.0], [1, 3, 4, 4]),
+                                          ("message", [gelu(-3.0), gelu(2.0), 0.0, 0.0], [0, 3, 4, 4])):
+        trace = []
+        O.mp_layer(h, W, ident["ln_g"], ident["ln_b"], torch.ones(1, 1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64), src, tgt,
+                   np.array([0, 4]), "gelu", 0.0, None, 1, trace=trace, msg_act_placement=placement)
+        np.testing.assert_allclose(trace[0]["agg"].numpy().ravel(), want_agg, atol=1e-12)
+        assert trace[0]["arg"].numpy().ravel().tolist() == want_arg  # 4 = E marks an empty segment
+    # without an activation the placement is irrelevant
+    outs = [O.mp_layer(h, W, ident["ln_g"], ident["ln_b"], torch.ones(1, 1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64), src, tgt,
+                       np.array([0, 4]), "none", 0.0, None, 1, msg_act_placement=pl) for pl in ("aggregated", "message")]
+    assert torch.equal(outs[0], outs[1])
+    assert O.OracleConfig().msg_act_placement == "aggregated" and O.MpSpec(1, 1, 1).msg_act_placement == "aggregated"
+
+
 def test_config_c1_plumbing_on_cpu_oracle():
     """BASELINE.json configs[0]: gnn-mlp, hidden 128, 4 layers, ONE graph of ~500 nodes, CPU.  The product has no CPU path
     (it fails loudly without the GPU), so the CPU-runnable case is the oracle's: a few clip + Adam steps on that batch
