@@ -150,6 +150,29 @@ def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, 
     return roof
 
 
+def calibrate_rooflines(box, roof, also, per_gpu_rate):
+    """Adds the per-box view to the rooflines: `frac_calibrated` = achieved / the ceiling THIS box reached on the library's fixed
+    calibration kernels (dense bf16 MFMA loop / 6 for a bf16x6 kernel; the HBM copy for an HBM-bound one) instead of the paper
+    peak, and to `box` the headline per calibrated unit (graphs/s per calibrated bf16 PFLOP/s): two boxes that differ in the
+    clock they sustain agree on it far better than on the raw rate."""
+    def one(r):
+        if not r:
+            return
+        if r["bound"] == "hbm":
+            r["peak_calibrated"] = round(1e3 * box["hbm_calib_tbs"], 1)
+        elif "bf16x6" in r.get("peak_basis", ""):
+            r["peak_calibrated"] = round(box["mfma_calib_tflops"] / 6.0, 1)
+        else:
+            return
+        r["frac_calibrated"] = round(r["achieved"] / r["peak_calibrated"], 4)
+    one(roof)
+    for entry in (also or {}).values():
+        one(entry.get("roofline"))
+    box["value_per_calibrated_pflops"] = round(per_gpu_rate / (box["mfma_calib_tflops"] / 1e3), 1)
+    box["mfma_calib_frac_of_paper_peak"] = round(box["mfma_calib_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)
+    box["hbm_calib_frac_of_paper_peak"] = round(1e3 * box["hbm_calib_tbs"] / HBM_PEAK_GBS, 4)
+
+
 def measured_mfma_busy(kind):
     """Matrix-pipe busy fraction of `kind`'s kernel from the newest committed SQ counter summary under profiles/
     (`*_pmc_sq.json`: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMDs x CUs), a separate rocprofv3 --pmc pass over
@@ -343,6 +366,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="weight-gradient GEMMs on the main stream everywhere (no side-stream overlap): the run "
                     "whose rocprofv3 --kernel-trace --stats averages are the exclusive kernel times the roofline quotes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-box", action="store_true", help="skip the box calibration (MFMA loop, HBM copy, clock / power sampling) after the timed region")
     ap.add_argument("--unfused-node-bwd", action="store_true", help="A/B: the node update's backward chain as three kernels "
                     "(act backward, dense input gradient, LayerNorm backward) instead of bl_node_update_bwd")
     ap.add_argument("--default-stream", action="store_true", help="A/B: run the steps on the default stream instead of the trainer's "
@@ -535,6 +559,28 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # What this box delivers (outside the timed region, rank 0's device): boxes of the pool differ by several
+    # per cent in the clock they hold at the package power limit.  (i) shader clock + package power sampled through librocm_smi64
+    # while plain training steps run (no event records), (ii) two fixed kernels of the library: a dense bf16 MFMA loop from
+    # registers and a 2 GiB HBM copy.  The roofline entry carries `frac_calibrated` = achieved / (this box's calibrated ceiling).
+    box = None
+    if not args.no_box:
+        from buglab.models.hip_ops.calibration import SmiSampler, box_calibration
+
+        torch.cuda.synchronize()
+        with SmiSampler() as smi:
+            for _ in range(max(args.steps, 30)):
+                step()
+            torch.cuda.synchronize()
+        box = box_calibration(device)
+        under_load = smi.summary()
+        box["sclk_mhz_step"] = None if under_load is None else under_load["sclk_mhz"]
+        box["power_w_step"] = None if under_load is None else under_load["power_w"]
+        box["smi"] = None if under_load is None else {k: under_load[k] for k in ("samples", "smi_device", "source")}
+        box["device"] = torch.cuda.get_device_name(device)
+        if world > 1:
+            dist.barrier()
+
     # forward-only ("predict": localization + repair log-probabilities, eval mode) on the same batch --
     # SURVEY section 8d asks for it next to the training rate; outside the timed training region
     module.eval()
@@ -581,6 +627,8 @@ def main():
         fwd_flop, fwd_bytes = fwd_work(args)
         value = total_graphs / elapsed
         roof = build_roofline(kern, kern_overlap, prof_steps, serial_step_s, value / world, fwd_flop, fwd_bytes)
+        if box is not None:
+            calibrate_rooflines(box, roof, also, value / world)
         line = {
             "metric": "code-graphs/sec (train: fwd+bwd+optimizer)",
             "value": round(value, 2),
@@ -608,6 +656,7 @@ def main():
             },
             "predict_graphs_per_s": None if predict_elapsed is None else round(args.graphs * world * args.steps / predict_elapsed, 1),  # forward-only, eval mode
             "roofline": roof,
+            "box": box,
             "also": also or None,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else (cpu_baseline_seq(args) if seq else cpu_baseline(args)),
         }

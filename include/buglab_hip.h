@@ -402,6 +402,15 @@ int bl_prof_num_kinds(void);
 const char* bl_prof_kind_name(int32_t kind);
 int bl_prof_read(int32_t kind, double* ms, double* flop, int64_t* launches, int32_t* overlapped);
 
+/* Box calibration (measurement support for bench.py; nothing on the training path calls these): boxes
+ * of the pool differ by several per cent in the shader clock they sustain at the package power limit, so the bench line
+ * carries what THIS chip delivers on two fixed kernels next to the paper peaks.  The caller times the launch with HIP events.
+ *   bl_calib_mfma_bf16: `workgroups` x 4 waves, each `iters` x 4 independent chains of v_mfma_f32_32x32x16_bf16 from registers;
+ *     *flop = the launch's floating-point operations (dense bf16 MFMA: paper peak 2 500 TF/s).
+ *   bl_calib_stream_copy: 16 B / lane grid-stride copy of nbytes (multiple of 16, aligned): 2 x nbytes of HBM traffic. */
+int bl_calib_mfma_bf16(int32_t iters, int32_t workgroups, float* sink, double* flop, void* stream);
+int bl_calib_stream_copy(const void* src, void* dst, int64_t nbytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Heads.
  * H7  scatter_log_softmax (buglab/models/utils.py:15-28) over CSR segments:

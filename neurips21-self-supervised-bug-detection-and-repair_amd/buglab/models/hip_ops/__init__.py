@@ -152,6 +152,8 @@ _SIGNATURES = {
     "bl_rel_value_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_dropout_inplace": ([c_void_p, c_int64, bl_dropout_t, c_void_p], ctypes.c_int),
+    "bl_calib_mfma_bf16": ([c_int32, c_int32, c_void_p, POINTER(ctypes.c_double), c_void_p], ctypes.c_int),
+    "bl_calib_stream_copy": ([c_void_p, c_void_p, c_int64, c_void_p], ctypes.c_int),
     "bl_prof_enable": ([c_int32], ctypes.c_int),
     "bl_prof_reset": ([], ctypes.c_int),
     "bl_prof_num_kinds": ([], ctypes.c_int),
@@ -674,19 +676,34 @@ def join_side_stream():
     _free_running = False
 
 
+def _opted_in_for_direct_grad(param) -> bool:
+    """THE CONTRACT of direct gradient accumulation (every Function of this module that owns parameters: the message-passing
+    layers, gather_linear, mlp_score, localization_scores, rowdot, the relational attention's bias tables): a parameter
+    whose owner set `param._bl_direct_grad = True` and bound `param.grad` to a preallocated fp32 buffer (FlatAdam does both for
+    the parameters it owns, zeroing the flat buffer in zero_grad()) gets its gradient ADDED INTO `param.grad` by the kernels,
+    and backward returns None for it.  Consequences: `torch.autograd.grad(...)` sees no gradient for such a parameter and
+    tensor hooks registered on it would never fire -- so a parameter that has hooks (or post-accumulate-grad hooks) is treated
+    as not opted in and receives its gradient through autograd as usual.  Parameters without the flag always take that
+    path."""
+    if not (DIRECT_PARAM_GRAD and getattr(param, "_bl_direct_grad", False)):
+        return False
+    if getattr(param, "_backward_hooks", None) or getattr(param, "_post_accumulate_grad_hooks", None):
+        return False
+    return True
+
+
 def _direct_small(param):
     """.grad of a small (bias / LayerNorm) parameter when the kernels may accumulate into it directly
-    (FlatAdam's flat gradient buffer): no zero-fill, no autograd accumulation kernel."""
+    (FlatAdam's flat gradient buffer): no zero-fill, no autograd accumulation kernel.  Contract: _opted_in_for_direct_grad."""
     g = getattr(param, "grad", None)
-    if (DIRECT_PARAM_GRAD and getattr(param, "_bl_direct_grad", False) and g is not None and g.is_cuda and g.dtype == torch.float32
-            and g.is_contiguous()):
+    if _opted_in_for_direct_grad(param) and g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
         return g
     return None
 
 
 def _direct_grad_target(param):
     g = getattr(param, "grad", None)
-    if (DIRECT_PARAM_GRAD and USE_SIDE_STREAM and getattr(param, "_bl_direct_grad", False) and g is not None and g.is_cuda
+    if (USE_SIDE_STREAM and _opted_in_for_direct_grad(param) and g is not None and g.is_cuda
             and g.dtype == torch.float32 and g.is_contiguous()):
         return g
     return None
@@ -731,6 +748,17 @@ class _on_side_stream:
 
 # ------------------------------------------------------------------------------------------------
 # autograd wrappers
+def _take_saved(ctx):
+    """What a Function's forward kept in `ctx.saved`, handed over ONCE: backward drops the references at once (activations are
+    freed as the backward pass proceeds), so a second backward through the same graph has nothing to read."""
+    saved = ctx.saved
+    if saved is None:
+        raise RuntimeError("hip_ops: this graph's buffers were freed by its first backward pass; retain_graph=True / a second "
+                           "backward through the same forward is not supported by the hip_ops Functions")
+    ctx.saved = None
+    return saved
+
+
 class GraphIndex(NamedTuple):
     """Device-side index arrays of one minibatch (buglab.data.collate.to_device)."""
 
@@ -765,8 +793,7 @@ class _EmbedSubtokenMax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
-        table, ids, argsub, drop, V, H, tok_csr = ctx.saved
-        ctx.saved = None
+        table, ids, argsub, drop, V, H, tok_csr = _take_saved(ctx)
         g_out = g_out.contiguous()
         N, S = ids.shape
         direct = _direct_small(table)
@@ -834,13 +861,16 @@ class _MpLayer(torch.autograd.Function):
         if msg_act == ACT_NONE:
             dact = None  # derivative is identically 1
         out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
-        ctx.saved = (h, hp, W, ln_g, ln_b, Wd, bd, dact, arg, bits, agg, mean, rstd, ln_out, out, g, msg_act, drop)
+        # (the OUTPUT goes through save_for_backward: output -> grad_fn -> ctx -> output held as a plain attribute is a cycle
+        # across the C++ boundary that nothing collects when no backward pass runs -- see _GatherLinear)
+        ctx.save_for_backward(out)
+        ctx.saved = (h, hp, W, ln_g, ln_b, Wd, bd, dact, arg, bits, agg, mean, rstd, ln_out, g, msg_act, drop)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        h, hp, W, ln_g, ln_b, Wd, bd, dact, arg, bits, agg, mean, rstd, ln_out, out, g, msg_act, drop = ctx.saved
-        ctx.saved = None
+        h, hp, W, ln_g, ln_b, Wd, bd, dact, arg, bits, agg, mean, rstd, ln_out, g, msg_act, drop = _take_saved(ctx)
+        (out,) = ctx.saved_tensors
         N, Din = h.shape
         T, K2, Dm = W.shape
         Dout = Wd.shape[1]
@@ -1149,14 +1179,15 @@ class _MpLayerFused(torch.autograd.Function):
             WINNER_SINK.append(winner)
         if need_bwd:
             _note_use((W, ln_g, ln_b, Wd, bd))
-        ctx.saved = (h_lo.shape[1], h_hi.shape[1] if h_hi is not None else 0, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk,
+        ctx.save_for_backward(out)  # (an output: never as a plain ctx attribute, see _MpLayer)
+        ctx.saved = (h_lo.shape[1], h_hi.shape[1] if h_hi is not None else 0, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, wnk,
                      dense_x6, wd_kn, wd_nk, wt)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, out, wnk, dense_x6, wd_kn, wd_nk, wt = ctx.saved
-        ctx.saved = None
+        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, wnk, dense_x6, wd_kn, wd_nk, wt = _take_saved(ctx)
+        (out,) = ctx.saved_tensors
         lib = load_library()
         N, E = g.num_nodes, g.num_messages
         T, K2, Dm = W.shape
@@ -1273,8 +1304,7 @@ class _GatedMpLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
-        h, W, Wi, Wh, agg, arg, gi, gh, g, drop = ctx.saved
-        ctx.saved = None
+        h, W, Wi, Wh, agg, arg, gi, gh, g, drop = _take_saved(ctx)
         N, D = h.shape
         T, _, Dm = W.shape
         E = g.num_messages
@@ -1348,13 +1378,14 @@ class _MpLayerFeat(torch.autograd.Function):
         if msg_act == ACT_NONE:
             dact = None
         out = gemm_rows([(ln_out, None)], _f32(Wd, "Wd"), N, Dout, bias=_f32(bd), act=ACT_TANH, drop=drop)
-        ctx.saved = (h, hp, tp, bits, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, out, g, drop)
+        ctx.save_for_backward(out)  # (an output: never as a plain ctx attribute, see _MpLayer)
+        ctx.saved = (h, hp, tp, bits, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, g, drop)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        h, hp, tp, bits, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, out, g, drop = ctx.saved
-        ctx.saved = None
+        h, hp, tp, bits, W, ln_g, Wd, table, msg_feat, dact, arg, agg, mean, rstd, ln_out, g, drop = _take_saved(ctx)
+        (out,) = ctx.saved_tensors
         N, Din = h.shape
         T, K3, Dm = W.shape
         F, Dout, E, dev = table.shape[1], Wd.shape[1], g.num_messages, h.device
@@ -1420,8 +1451,7 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
-        idx, shape = ctx.saved
-        ctx.saved = None
+        idx, shape = _take_saved(ctx)
         g_x = torch.zeros(shape, dtype=torch.float32, device=g_out.device)
         scatter_add_rows(g_out.contiguous(), 0, shape[1], idx, g_x)
         return g_x, None
@@ -1479,9 +1509,8 @@ class _GatherLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
-        W, bias_p, act, sources, drop, xp, wnk = ctx.saved
+        W, bias_p, act, sources, drop, xp, wnk = _take_saved(ctx)
         (out,) = ctx.saved_tensors
-        ctx.saved = None
         has_bias = bias_p is not None
         R, N = out.shape
         K = W.shape[0]
@@ -1514,6 +1543,9 @@ class _GatherLinear(torch.autograd.Function):
 
 
 def gather_linear(sources: Sequence[RowSource], W, bias, act: str = "none", drop: Dropout = NO_DROPOUT):
+    """drop(act(concat_j(x_j[idx_j]) @ W + bias)).  W / bias gradients: added straight into `W.grad` / `bias.grad` (backward
+    returns None for them) when the parameter opted in -- see _opted_in_for_direct_grad for the contract and its consequences
+    for torch.autograd.grad and parameter hooks -- through autograd otherwise."""
     xs = [x for x, _ in sources]
     idxs = [i for _, i in sources]
     extra = (drop,) if drop is not NO_DROPOUT else ()
@@ -1532,8 +1564,7 @@ class _RowDot(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_y):
-        x, w, has_b = ctx.saved
-        ctx.saved = None
+        x, w, has_b = _take_saved(ctx)
         R, H = x.shape
         g_x = torch.empty_like(x)
         g_w = torch.zeros_like(w)
@@ -1563,9 +1594,8 @@ class _SegmentLogSoftmax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_y):
-        seg_ptr, seg_items, nseg = ctx.saved
+        seg_ptr, seg_items, nseg = _take_saved(ctx)
         (y,) = ctx.saved_tensors
-        ctx.saved = None
         g_x = torch.zeros_like(y)
         _check(
             load_library().bl_segment_log_softmax_bwd(_f32(g_y.contiguous()).data_ptr(), y.data_ptr(), seg_ptr.data_ptr(),
@@ -1591,8 +1621,7 @@ class _SegmentMaxPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, _g_arg):
-        arg, shape, seg_of = ctx.saved
-        ctx.saved = None
+        arg, shape, seg_of = _take_saved(ctx)
         x_like = torch.empty(shape, dtype=torch.float32, device=g_out.device)
         g_x = segment_max_bwd(g_out.contiguous(), arg, x_like, seg_of, out=x_like)
         return g_x, None, None, None
@@ -1636,8 +1665,7 @@ class _MlpScore(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_score):
-        W1, b1, w2, b2, xs, idxs, hidden, K = ctx.saved
-        ctx.saved = None
+        W1, b1, w2, b2, xs, idxs, hidden, K = _take_saved(ctx)
         lib = load_library()
         R, H = hidden.shape
         dev = W1.device
@@ -1691,8 +1719,7 @@ class _LocalizationScores(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_score):
-        x, cand, cand_graph, cand_ptr, B, Ws, bs, W1, b1, w, saved = ctx.saved
-        ctx.saved = None
+        x, cand, cand_graph, cand_ptr, B, Ws, bs, W1, b1, w, saved = _take_saved(ctx)
         lib = load_library()
         C, H = cand.shape[0], x.shape[1]
         dev = x.device
@@ -1774,8 +1801,7 @@ class _BugLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
-        loc_scores, logits, sizes, ix, w_buggy, abstain, loc_lp, rep_lp = ctx.saved
-        ctx.saved = None
+        loc_scores, logits, sizes, ix, w_buggy, abstain, loc_lp, rep_lp = _take_saved(ctx)
         dev = loc_scores.device
         d = _bug_loss_desc(loc_scores, logits, sizes, ix, w_buggy, abstain)
         scratch = torch.empty((d.C + d.B + logits.shape[0] + 1,), dtype=torch.float32, device=dev)
@@ -1814,8 +1840,7 @@ class _AddLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_y):
-        z, mean, rstd, gamma, beta, has_r = ctx.saved
-        ctx.saved = None
+        z, mean, rstd, gamma, beta, has_r = _take_saved(ctx)
         (gg, rg), (gb, rb) = _grad_target(gamma), _grad_target(beta)
         g_z = layernorm_bwd(g_y.contiguous(), z, mean, rstd, gamma, gg, gb)
         return g_z, (g_z if has_r else None), rg, rb, None
@@ -1909,8 +1934,7 @@ class _RelAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
-        qs, kt, vt, P, Pd, lens, edges, bias_f, bias_r, vb_f, vb_r, B, L, H, dk, T, mode, drop, gptr, scale = ctx.saved
-        ctx.saved = None
+        qs, kt, vt, P, Pd, lens, edges, bias_f, bias_r, vb_f, vb_r, B, L, H, dk, T, mode, drop, gptr, scale = _take_saved(ctx)
         lib = load_library()
         G, D = B * H, H * dk
         dev = g_out.device

@@ -39,6 +39,19 @@ class GnnOutput(NamedTuple):
     head_idx_references: Optional[Dict[str, torch.Tensor]] = None
 
 
+MAX_MESSAGE_DIMENSION = 512  # csrc/bl_graph_ops.hip: a wavefront of the per-node kernels holds one row of <= 8 x 64 channels
+
+
+def _check_message_width(dm: int, who: str) -> None:
+    """The segmented max / LayerNorm / node-gradient kernels keep a whole message row in one wavefront's registers (DISPATCH_NV,
+    <= 512 channels).  gnn-mlp's concat layers have 2 x hidden message channels, so hidden_state_size <= 256 (every BASELINE
+    configuration: 128 / 256).  Said here, at construction, rather than as a BL_EINVAL from the first forward pass."""
+    if dm > MAX_MESSAGE_DIMENSION:
+        raise NotImplementedError(f"{who}: message_dimension {dm} > {MAX_MESSAGE_DIMENSION}: the HIP per-node kernels hold a message row "
+                                  f"of at most {MAX_MESSAGE_DIMENSION} channels per wavefront (gnn-mlp: hidden_state_size <= 256, its "
+                                  "ConcatResidual layers carry 2 x hidden channels)")
+
+
 def _uniform_(t: torch.Tensor, bound: float) -> torch.Tensor:
     return t.uniform_(-bound, bound)
 
@@ -81,6 +94,7 @@ class MlpMessagePassingLayer(nn.Module):
         if message_aggregation_function != "max":
             raise NotImplementedError("the HIP path implements the reference's `max` aggregation (gnnlayerdefs.py:11,21)")
         din, dm, dout, T = input_state_dimension, message_dimension, output_state_dimension, num_edge_types
+        _check_message_width(dm, "MlpMessagePassingLayer")
         self.input_state_dimension, self.message_dimension, self.output_state_dimension = din, dm, dout
         self.num_edge_types, self.dropout_rate, self.message_activation = T, dropout_rate, message_activation
         self.message_activation_placement = message_activation_placement
@@ -117,6 +131,7 @@ class GatedMessagePassingLayer(nn.Module):
         if message_aggregation_function != "max":
             raise NotImplementedError("the HIP path implements the reference's `max` aggregation (gnnlayerdefs.py:47,63)")
         D, Dm, T = state_dimension, message_dimension, num_edge_types
+        _check_message_width(Dm, "GatedMessagePassingLayer")
         self.state_dimension, self.message_dimension, self.output_state_dimension = D, Dm, D
         self.num_edge_types, self.dropout_rate = T, dropout_rate
         k = 1.0 / math.sqrt(D)

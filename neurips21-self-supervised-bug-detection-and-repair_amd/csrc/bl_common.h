@@ -50,6 +50,18 @@ int bl_mp_scatter_grad_hubs_impl(const float* g_a, int32_t ld_ga, const int32_t*
 
 static inline bool bl_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a DEVICE's copy of a kernel: raised once per (call site, device) -- a
+// process may drive several devices (done: the call site's own `static bool [BL_MAX_DEVICES]`)
+#define BL_MAX_DEVICES 64
+static inline int bl_raise_lds_limit_once(const void* fn, int bytes, bool (&done)[BL_MAX_DEVICES]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BL_MAX_DEVICES) return BL_EINVAL;
+  if (done[dev]) return BL_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return BL_EINVAL;
+  done[dev] = true;
+  return BL_OK;
+}
+
 // ---- counter-based dropout: identical to oracle/buglab_oracle.py::dropout_keep_mask -----------
 __host__ __device__ static inline uint32_t bl_lowbias32(uint32_t x) {
   x ^= x >> 16;

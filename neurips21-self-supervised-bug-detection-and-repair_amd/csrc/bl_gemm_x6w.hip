@@ -39,6 +39,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "bl_common.h"
 #include "bl_x6_locate.h"
 #include "bl_x6w_image.h"
@@ -266,28 +268,9 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_x6w_kernel(
       if (mm_ < nrows && n_ < N) *reinterpret_cast<float4*>(c + (size_t)(row0 + mm_) * ldc + n_) = v_;                   \
     }                                                                                                                    \
   }
-#ifndef X6W_DIRECT_STORE
-#define X6W_DIRECT_STORE 0  // 1 (experiment builds): float4 stores straight from the accumulator layout
-#endif
-#if X6W_DIRECT_STORE
-#define W_STORE_ROW(ti_, accA_, accB_)                                                                       \
-  {                                                                                                          \
-    const int m = wm * 64 + (ti_) * 32 + li;                                                                 \
-    if (m < nrows) {                                                                                         \
-      float* __restrict__ crow = c + (size_t)(row0 + m) * ldc;                                               \
-      _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
-        const int na = n0 + wn * 64 + 8 * gq + 4 * half, nb = na + 32;                                       \
-        if (na < N) *reinterpret_cast<float4*>(crow + na) = make_float4(accA_[4 * gq], accA_[4 * gq + 1], accA_[4 * gq + 2], accA_[4 * gq + 3]); \
-        if (nb < N) *reinterpret_cast<float4*>(crow + nb) = make_float4(accB_[4 * gq], accB_[4 * gq + 1], accB_[4 * gq + 2], accB_[4 * gq + 3]); \
-      }                                                                                                      \
-    }                                                                                                        \
-  }
-  W_STORE_ROW(0, acc00, acc01)
-  W_STORE_ROW(1, acc10, acc11)
-#else
+  // (direct float4 stores from the accumulator layout instead of the LDS-staged row pieces: measured slower, profiles/r05f_rows_wide.log)
   W_STORE_HALF(0, acc00, acc01)
   W_STORE_HALF(1, acc10, acc11)
-#endif
 }
 
 
@@ -308,15 +291,29 @@ extern "C" int64_t bl_packed_weight_elems_x6w(int32_t G, int32_t K, int32_t N) {
 }
 
 // Shapes the wide form takes.  The switch (bl_set_rows_tile) is a measurement aid like bl_set_wgrad_tile.
-static bool g_rows_wide = true;
-extern "C" int32_t bl_set_rows_tile(int32_t cols) {
-  const int32_t prev = g_rows_wide ? 256 : 128;
-  g_rows_wide = cols != 128;
-  return prev;
+static std::atomic<bool> g_rows_wide{true};
+extern "C" int32_t bl_set_rows_tile(int32_t cols) { return g_rows_wide.exchange(cols != 128) ? 256 : 128; }
+
+// Can the CURRENT device run the wide kernel (two 72 KB stage images of dynamic LDS)?  Cached per device.  Without a visible device
+// (the build container's header / export checks) the shape rule alone answers, so that packing and dispatch agree everywhere:
+// bl_mp_layer_weight_image, the weight packers and the layer calls all go through bl_gemm_rows_x6w_ok, and a device that cannot
+// hold the image falls back to the 128 x 128 kernel's weight image in all three places instead of failing inside the layer call.
+static bool x6w_device_ok() {
+  static std::atomic<int8_t> cache[BL_MAX_DEVICES];  // 0 unknown, 1 yes, 2 no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BL_MAX_DEVICES) return true;
+  int8_t c = cache[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    c = bl_max_lds_per_block() >= 2 * W_STAGE_BYTES ? 1 : 2;
+    cache[dev].store(c, std::memory_order_relaxed);
+  }
+  return c == 1;
 }
 // (the kernel itself takes any K >= 64 that is a multiple of 64; below 8 stages per tile its prologue and epilogue cost as much as
 // the loop and the 128 x 128 kernel's three workgroups per CU hide them better -- measured equal at K = 256, so the line is there)
-extern "C" int32_t bl_gemm_rows_x6w_ok(int32_t N, int32_t K) { return g_rows_wide && N > 0 && N % WBN == 0 && K >= 256 && K % 64 == 0; }
+extern "C" int32_t bl_gemm_rows_x6w_ok(int32_t N, int32_t K) {
+  return g_rows_wide.load(std::memory_order_relaxed) && N > 0 && N % WBN == 0 && K >= 256 && K % 64 == 0 && x6w_device_ok();
+}
 
 extern "C" int bl_gemm_rows_x6w(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                                 int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M,
@@ -339,19 +336,13 @@ extern "C" int bl_gemm_rows_x6w(const bl_rows_packed_t* a, const uint32_t* win_b
   BL_CHECK_ARG(win_bits == nullptr || (a->nsrc == 1 && a->idx[0] && ld_bits * 32 >= K),
                "%s: the routed form needs exactly one gathered source and ld_bits >= K / 32", who);
   const size_t lds = (size_t)2 * W_STAGE_BYTES;
-  static bool attr_set[64] = {false};  // per device: the attribute belongs to the device's copy of the function
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    BL_CHECK_ARG(bl_max_lds_per_block() >= (int)lds, "%s: the device offers %d B of LDS per workgroup, %d needed", who,
-                 bl_max_lds_per_block(), (int)lds);
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_x6w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_rows_x6w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      bl_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
-      return (int)e;
-    }
-    attr_set[dev] = true;
+  static bool attr_plain[BL_MAX_DEVICES] = {false}, attr_routed[BL_MAX_DEVICES] = {false};  // (calls come from one thread per process)
+  BL_CHECK_ARG(bl_max_lds_per_block() >= (int)lds, "%s: the device offers %d B of LDS per workgroup, %d needed (bl_gemm_rows_x6w_ok)", who,
+               bl_max_lds_per_block(), (int)lds);
+  if (bl_raise_lds_limit_once((const void*)gemm_rows_x6w_kernel<false>, (int)lds, attr_plain) != BL_OK ||
+      bl_raise_lds_limit_once((const void*)gemm_rows_x6w_kernel<true>, (int)lds, attr_routed) != BL_OK) {
+    bl_set_error("%s: cannot raise the dynamic LDS limit to %d B", who, (int)lds);
+    return BL_EINVAL;
   }
   dim3 grid((M + WBM - 1) / WBM + (group_ptr ? G : 0), N / WBN);
 #define X6W_ARGS                                                                                                              \

@@ -139,16 +139,12 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
 // two erf per (segment, channel) instead of one per (message, channel), and it has the winner's raw message at hand for
 // the derivative.  (A -inf message still gives gelu(-inf) = NaN, like the eager op.)
 // Segments longer than SEGMAX_HUB items among the first hub_slots entries of seg_order are "hubs": a whole workgroup
-// each (segment_max_hub_kernel: the waves scan contiguous shares); the wave-per-segment kernel skips exactly those.
+// each, at the front of the same launch (the waves scan contiguous shares, segment_max_kernel below).
 #define SEGMAX_HUB 40  // longer segments (among the hub candidates) get a 4-wave workgroup
 // (measured at BASELINE config c4, hidden 256: one wave per segment 3.06 ms per step; 4-wave hubs 2.39; 16-wave hubs 2.75;
 // 16 waves above 128 items + 4 waves below 2.76 -- the 1024-thread workgroups cost more to dispatch than their shorter
 // chains save)
 #define SEGMAX_HUB_SLOTS 4096  // hub_slots unknown to the caller: the first so many slots of seg_order are looked at
-
-__device__ __forceinline__ bool segmax_is_hub(const int* __restrict__ seg_ptr, int hub_slots, int slot, int seg) {
-  return slot < hub_slots && seg_ptr[seg + 1] - seg_ptr[seg] > SEGMAX_HUB;
-}
 
 // extremes of the items [beg, end) of one segment: best = largest (activated, unless GELU2) value and its item, low = smallest raw value
 template <int NV, bool GELU2>
@@ -319,82 +315,95 @@ __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int l
       float *__restrict__ dact, uint32_t *__restrict__ winbits, const int *__restrict__ seg_order,                               \
       uint32_t *__restrict__ ln_out_packed, int hub_slots
 
-// Wave-per-segment kernel (skips the hubs) ...
-template <int NV, bool HAS_LN, bool GELU2>
+// One launch for every segment.  The first hub_slots workgroups look at one entry of seg_order each (the collator sorts the
+// high-degree nodes to the front): a segment longer than SEGMAX_HUB items is taken by all four waves -- wave w scans the w-th
+// contiguous share, the partial extremes of waves 1..3 go through LDS and wave 0 merges them in share order with the same
+// strict comparisons (so the first of equal values still wins, and a NaN sticks); the final winners come back through LDS for
+// the routing bitmask, which every wave writes for its own share.  A shorter segment in a hub slot is wave 0's alone.  The
+// remaining workgroups take four ordinary segments each, one per wave.  Until round 6 the hubs had a launch of their own in
+// front of this one: the kernel boundary made the ordinary segments wait for the longest hub's last round trip (c4: 0.9 ms
+// per step at ~2 TB/s); inside one launch the dispatcher backfills ordinary workgroups as hub workgroups retire.
+// HUBS = false: the instantiation for launches without hub candidates (hub_slots == 0: every minibatch of uniform-degree graphs) --
+// without the hub path's registers the 128-channel form keeps 62 registers = eight waves per SIMD; with it, 66 = seven, and the
+// kernel lives on waves in flight (hidden-128 layers measured 6 % slower).
+template <int NV, bool HAS_LN, bool GELU2, bool HUBS>
 __global__ __launch_bounds__(256) void segment_max_kernel(SEGMAX_PARAMS) {
-  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  constexpr int W = HUBS ? 64 * NV : 1;
+  __shared__ float hub_f[3][W];
+  __shared__ int hub_i[3][W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool hub_wg = HUBS && (int)blockIdx.x < hub_slots;  // (uniform over the workgroup)
+  const int slot = hub_wg ? (int)blockIdx.x : hub_slots + ((int)blockIdx.x - hub_slots) * 4 + wave;
   if (slot >= nseg) return;
   // seg_order (optional): processing order, long segments first
   const int seg = seg_order ? seg_order[slot] : slot;
-  if (segmax_is_hub(seg_ptr, hub_slots, slot, seg)) return;  // segment_max_hub_kernel's
   const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
-  float best[NV], low[NV], raw[NV], werf[NV];
-  int barg[NV], larg[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; raw[j] = 0.f; werf[j] = 0.f; }
-  segmax_scan<NV, GELU2>(x, ldx, seg_items, beg, end, D, act, best, barg, low, larg);
-  segmax_pick<NV, GELU2>(best, barg, low, larg, raw, werf);
-  if (winbits) segmax_winbits<NV>(seg_items, beg, end, D, barg, winbits);
-  segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, werf, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
-                                   ln_out_packed);
-}
-
-// ... and the hub kernel, launched in front of it: workgroup b looks at entry b of seg_order and, if that segment is a hub,
-// takes it with all four waves -- wave w scans the w-th contiguous share of the items, the partial extremes go through LDS
-// and wave 0 merges them in share order with the same strict comparisons (so the first of equal values still wins, and a
-// NaN sticks); the final winners come back through LDS for the routing bitmask, which every wave writes for its own share.
-template <int NV, bool HAS_LN, bool GELU2, int SEGMAX_HUB_WAVES>
-__global__ __launch_bounds__(64 * SEGMAX_HUB_WAVES) void segment_max_hub_kernel(SEGMAX_PARAMS, int len_lo, int len_hi) {
-  constexpr int W = 64 * NV;
-  __shared__ float hub_f[2][SEGMAX_HUB_WAVES][W];
-  __shared__ int hub_i[2][SEGMAX_HUB_WAVES][W];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slot = blockIdx.x;
-  if (slot >= nseg || slot >= hub_slots) return;
-  const int seg = seg_order[slot];
-  {  // this kernel's share of the hubs: len_lo < length <= len_hi (uniform over the workgroup: nobody reaches a barrier)
-    const int len = seg_ptr[seg + 1] - seg_ptr[seg];
-    if (len <= len_lo || len > len_hi) return;
+  const bool split = HUBS && hub_wg && end - beg > SEGMAX_HUB;  // (uniform over the workgroup: every wave reaches the barriers below)
+  if (hub_wg && !split && wave > 0) return;
+  int wb = beg, we = end;
+  if (split) {
+    const int share = (end - beg + 3) >> 2;
+    wb = min(end, beg + wave * share);
+    we = min(end, wb + share);
   }
   float best[NV], low[NV], raw[NV], werf[NV];
   int barg[NV], larg[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) { best[j] = NEG_INF; barg[j] = -1; low[j] = -NEG_INF; larg[j] = -1; raw[j] = 0.f; werf[j] = 0.f; }
-  const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
-  const int share = (end - beg + SEGMAX_HUB_WAVES - 1) / SEGMAX_HUB_WAVES;
-  const int wb = min(end, beg + wave * share), we = min(end, wb + share);
   segmax_scan<NV, GELU2>(x, ldx, seg_items, wb, we, D, act, best, barg, low, larg);
+  if (HUBS && split) {
+    if (wave > 0) {
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const int o = lane + 64 * j;
-    hub_f[0][wave][o] = best[j]; hub_i[0][wave][o] = barg[j]; hub_f[1][wave][o] = low[j]; hub_i[1][wave][o] = larg[j];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    for (int w = 1; w < SEGMAX_HUB_WAVES; ++w) {
+      for (int j = 0; j < NV; ++j) { hub_f[wave - 1][lane + 64 * j] = best[j]; hub_i[wave - 1][lane + 64 * j] = barg[j]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 0; w < 3; ++w) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int o = lane + 64 * j;
-        const float tb = hub_f[0][w][o], tl = hub_f[1][w][o];
-        const int ab = hub_i[0][w][o], al = hub_i[1][w][o];
-        if (ab >= 0 && BL_MAX_WINS(tb, best[j])) { best[j] = tb; barg[j] = ab; }
-        if (GELU2 && al >= 0 && tl < low[j]) { low[j] = tl; larg[j] = al; }
+        for (int j = 0; j < NV; ++j) {
+          const float tb = hub_f[w][lane + 64 * j];
+          const int ab = hub_i[w][lane + 64 * j];
+          if (ab >= 0 && BL_MAX_WINS(tb, best[j])) { best[j] = tb; barg[j] = ab; }
+        }
       }
     }
+    if (GELU2) {  // the smallest raw items the same way (the buffers are re-used)
+      __syncthreads();
+      if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { hub_f[wave - 1][lane + 64 * j] = low[j]; hub_i[wave - 1][lane + 64 * j] = larg[j]; }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        for (int w = 0; w < 3; ++w) {
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            const float tl = hub_f[w][lane + 64 * j];
+            const int al = hub_i[w][lane + 64 * j];
+            if (al >= 0 && tl < low[j]) { low[j] = tl; larg[j] = al; }
+          }
+        }
+      }
+    }
+    if (wave == 0) {
+      segmax_pick<NV, GELU2>(best, barg, low, larg, raw, werf);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) hub_i[0][lane + 64 * j] = barg[j];  // the final winners (wave 0 was the only reader of hub_i)
+    }
+    __syncthreads();
+    if (winbits) {
+      int fin[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) fin[j] = hub_i[0][lane + 64 * j];
+      segmax_winbits<NV>(seg_items, wb, we, D, fin, winbits);
+    }
+    if (wave > 0) return;
+  } else {
     segmax_pick<NV, GELU2>(best, barg, low, larg, raw, werf);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) hub_i[0][0][lane + 64 * j] = barg[j];  // the final winners
+    if (winbits) segmax_winbits<NV>(seg_items, beg, end, D, barg, winbits);
   }
-  __syncthreads();
-  if (winbits) {
-    int fin[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) fin[j] = hub_i[0][0][lane + 64 * j];
-    segmax_winbits<NV>(seg_items, wb, we, D, fin, winbits);
-  }
-  if (wave == 0)
-    segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, werf, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
-                                     ln_out_packed);
+  segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, werf, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
+                                   ln_out_packed);
 }
 
 // backward of the segmented max in gather form: each item row looks up its segment's argmax
@@ -629,11 +638,17 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
   const int slot = hub_wg ? (int)blockIdx.x : hub_slots + ((int)blockIdx.x - hub_slots) * 4 + wave;
   if (slot >= N) return;
   const int n = node_order ? node_order[slot] : slot;  // hubs first (see segment_max_kernel)
+  // the four-way split pays from a few round trips per wave on: a node with fewer than MPS_SPLIT_MIN incident messages in a hub
+  // slot (the collator counts a node as a hub candidate above 32) is wave 0's alone -- no LDS merge, no barrier, and the same
+  // summation order as on the ordinary path (uniform over the workgroup: it depends on n only)
+  constexpr int MPS_SPLIT_MIN = 64;
+  const bool split4 = hub_wg && (src_ptr[n + 1] - src_ptr[n]) + (tgt_ptr ? tgt_ptr[n + 1] - tgt_ptr[n] : 0) >= MPS_SPLIT_MIN;
+  if (hub_wg && !split4 && wave > 0) return;
   float acc[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int d = lane + 64 * j;
-    acc[j] = (accumulate && d < Din && !(hub_wg && wave > 0)) ? (d < split ? g_h[(size_t)n * ld_gh + d] : g_h2[(size_t)n * ld_gh2 + d - split]) : 0.f;
+    acc[j] = (accumulate && d < Din && !(split4 && wave > 0)) ? (d < split ? g_h[(size_t)n * ld_gh + d] : g_h2[(size_t)n * ld_gh2 + d - split]) : 0.f;
   }
 #pragma unroll
   for (int part = 0; part < 2; ++part) {
@@ -642,7 +657,7 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
     const int* __restrict__ items = part == 0 ? src_msgs : tgt_msgs;
     const int coff = part == 0 ? 0 : Din;
     int beg = ptr[n], end = ptr[n + 1];
-    if (hub_wg) {  // this wave's contiguous share of the segment
+    if (split4) {  // this wave's contiguous share of the segment
       const int share = (end - beg + 3) >> 2;
       beg = min(end, beg + wave * share);
       end = min(end, beg + share);
@@ -674,7 +689,7 @@ __global__ __launch_bounds__(256) void mp_scatter_grad_kernel(const float* __res
       }
     }
   }
-  if (hub_wg) {  // partial sums of waves 1..3 -> wave 0, added in wave order (a fixed order: deterministic)
+  if (split4) {  // partial sums of waves 1..3 -> wave 0, added in wave order (a fixed order: deterministic)
     if (wave > 0) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) hub_part[wave - 1][lane + 64 * j] = acc[j];
@@ -826,20 +841,20 @@ int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr,
   const bool has_ln = ln_g != nullptr;
   BL_CHECK_ARG(!has_ln || (ln_b && (ln_out || ln_out_packed) && (mean == nullptr) == (rstd == nullptr)), "bl_segment_max_fwd: LayerNorm outputs missing");
   BL_CHECK_ARG(ln_out_packed == nullptr || (has_ln && D % 8 == 0), "bl_segment_max_fwd: the packed LayerNorm output needs D %% 8 == 0");
-  dim3 grid((nseg + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   uint32_t* lnp = reinterpret_cast<uint32_t*>(ln_out_packed);
-  // hub candidates: the first hub_slots entries of seg_order (the collator sorts high-degree nodes to the front); their
-  // kernel goes first so that the longest segments start at t = 0
+  // hub candidates: the first hub_slots entries of seg_order (the collator sorts high-degree nodes to the front) get a
+  // workgroup each at the front of the grid, so that the longest segments start at t = 0
   const int hub_slots = seg_order ? (num_hub_slots < 0 ? min(nseg, SEGMAX_HUB_SLOTS) : min(nseg, num_hub_slots)) : 0;
+  dim3 grid(hub_slots + (nseg - hub_slots + 3) / 4), block(256);
 #define SEGMAX_GO(LN_, G2_)                                                                                                          \
   DISPATCH_NV(D, {                                                                                                                   \
     if (hub_slots > 0)                                                                                                               \
-      hipLaunchKernelGGL((segment_max_hub_kernel<NV, LN_, G2_, 4>), dim3(hub_slots), dim3(256), 0, st, x, ldx, seg_ptr, seg_items,    \
-                         nseg, D, act, out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order, lnp, hub_slots,      \
-                         SEGMAX_HUB, 0x7fffffff);                                                                                    \
-    hipLaunchKernelGGL((segment_max_kernel<NV, LN_, G2_>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, act, out, arg,   \
-                       ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order, lnp, hub_slots);                              \
+      hipLaunchKernelGGL((segment_max_kernel<NV, LN_, G2_, true>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, act, out, \
+                         arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order, lnp, hub_slots);                        \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((segment_max_kernel<NV, LN_, G2_, false>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, act,     \
+                         out, arg, ln_g, ln_b, eps, ln_out, mean, rstd, dact, winbits, seg_order, lnp, 0);                           \
   })
   if (has_ln) {
     if (act == BL_ACT_GELU) SEGMAX_GO(true, true) else SEGMAX_GO(true, false)

@@ -899,13 +899,10 @@ extern "C" int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32
   int rc = -1;
 #define ATT_CASE(DK_, KC_)                                                                                                        \
   if (dk == DK_ && kc == KC_) {                                                                                                   \
-    static bool attr = false;                                                                                                     \
-    if (!attr) {                                                                                                                  \
-      if (hipFuncSetAttribute((const void*)attn_probs_fwd_kernel<DK_, KC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) { \
-        bl_set_error("bl_rel_attn_probs_fwd: cannot raise the LDS limit");                                                        \
-        return BL_EINVAL;                                                                                                         \
-      }                                                                                                                           \
-      attr = true;                                                                                                                \
+    static bool attr[BL_MAX_DEVICES] = {false}; /* per device: the attribute belongs to the device's copy of the function */   \
+    if (bl_raise_lds_limit_once((const void*)attn_probs_fwd_kernel<DK_, KC_>, 72 * 1024, attr) != BL_OK) {                         \
+      bl_set_error("bl_rel_attn_probs_fwd: cannot raise the LDS limit");                                                          \
+      return BL_EINVAL;                                                                                                           \
     }                                                                                                                             \
     hipLaunchKernelGGL((attn_probs_fwd_kernel<DK_, KC_>), grid, dim3(1024), lds, st, q, k, row_ptr, ekey, ecode, L, H, T, bias_f, \
                        bias_r, lens, bl_make_drop(drop), P, pd);                                                                  \
@@ -935,13 +932,10 @@ extern "C" int bl_rel_attn_probs_bwd(const float* g_ctx, const float* v, const f
   int rc = -1;
 #define ATT_CASE(DK_, KC_)                                                                                                        \
   if (dk == DK_ && kc == KC_) {                                                                                                   \
-    static bool attr = false;                                                                                                     \
-    if (!attr) {                                                                                                                  \
-      if (hipFuncSetAttribute((const void*)attn_probs_bwd_kernel<DK_, KC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) { \
-        bl_set_error("bl_rel_attn_probs_bwd: cannot raise the LDS limit");                                                        \
-        return BL_EINVAL;                                                                                                         \
-      }                                                                                                                           \
-      attr = true;                                                                                                                \
+    static bool attr[BL_MAX_DEVICES] = {false}; /* per device: the attribute belongs to the device's copy of the function */   \
+    if (bl_raise_lds_limit_once((const void*)attn_probs_bwd_kernel<DK_, KC_>, 72 * 1024, attr) != BL_OK) {                         \
+      bl_set_error("bl_rel_attn_probs_bwd: cannot raise the LDS limit");                                                          \
+      return BL_EINVAL;                                                                                                           \
     }                                                                                                                             \
     hipLaunchKernelGGL((attn_probs_bwd_kernel<DK_, KC_>), grid, dim3(1024), lds, st, g_ctx, v, P, q, row_ptr, ekey, ecode, L, H, T, \
                        bias_f, bias_r, bl_make_drop(drop), drop.p > 0.f ? 1 : 0, dS, gq_edge, g_bias_f, g_bias_r);                \

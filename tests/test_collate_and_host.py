@@ -163,6 +163,19 @@ def test_message_activation_placement_reaches_every_layer_and_old_pickles_keep_t
         assert l._msg_act() == "gelu"
 
 
+def test_message_width_limit_is_reported_at_construction():
+    """hidden_state_size > 256 (message rows wider than 512 channels in the concat layers) is not built: said loudly when the
+    layers are constructed, not by a failing kernel call in the first training step."""
+    from buglab.models.gnn import build_gnn_mlp_module
+    from buglab.models.layers.messagepassing import MlpMessagePassingLayer
+
+    MlpMessagePassingLayer(512, 512, 256, 2)  # hidden 256: the widest shipped layer
+    with pytest.raises(NotImplementedError, match="512"):
+        MlpMessagePassingLayer(1024, 1024, 512, 2)
+    with pytest.raises(NotImplementedError, match="hidden_state_size <= 256"):
+        build_gnn_mlp_module(384, 4, 2, 50)
+
+
 def test_tensorize_rewrite_bookkeeping_and_drop_rule():
     data = make_buglab_dataset(10, seed=4)
     model = _model()

@@ -341,13 +341,17 @@ def test_seq_model_end_to_end_matches_oracle(model_name):
         assert set(k for k in loc if k >= 0) == set(point["graph"]["reference_nodes"])
 
 
+@pytest.mark.parametrize("with_backward", [True, False])
 @pytest.mark.parametrize("family", ["seq-great", "seq-rat", "gnn-mlp", "gnn-mlp-all-outputs", "gnn-mlp-edge-features", "ggnn"])
-def test_training_steps_do_not_accumulate_device_memory(family):
+def test_training_steps_do_not_accumulate_device_memory(family, with_backward):
     """A custom autograd Function that keeps its own OUTPUT as a plain ctx attribute forms a cycle (output -> grad_fn -> ctx ->
     output) that crosses into C++ and is never collected: every step's activations stay allocated.  `_GatherLinear` did that
     until round 5 -- seq-great lost ~1 GiB per step at BASELINE configs[4] and filled a 288 GB device after ~280 steps.  After
     a warm-up the allocated bytes must be the same after every step, for every model family and option that has its own
-    autograd Functions."""
+    autograd Functions.  with_backward = False: a grad-mode forward whose loss is dropped WITHOUT a backward pass (evaluation
+    without no_grad, a step skipped after an exception, abort_data_parallel_step) -- backward's own clearing of `ctx` never
+    runs there, so the outputs must not be plain ctx attributes in any Function (round-5 advisor finding: the layer Functions
+    still did that)."""
     import copy
     import gc
     from pathlib import Path
@@ -379,6 +383,8 @@ def test_training_steps_do_not_accumulate_device_memory(family):
     def step():
         opt.zero_grad()
         loss = nn_(**mb)
+        if not with_backward:
+            return float(loss.detach())  # the graph is dropped here, unused
         loss.backward()
         opt.step()
         return float(loss.detach())

@@ -1,3 +1,8 @@
+// EXPERIMENT SOURCE (not built into the library): csrc/bl_gemm_x6.hip as of round 6 WITH its measurement switches -- X6_ABLATE
+// (1 rows not gathered, 2 no MFMAs, 4 no result stores), X6_TERM_MAJOR, X6_STAGED_STORE, BL_WW_ABLATE (1 no staging in the loop,
+// 2 no MFMAs, 4 fragments read once), BL_TRACE_WGRAD (shader-clock stamps).  The product source carries none of them.  Build a
+// variant library with  bash tools/experiments/variant_lib.sh NAME bl_gemm_x6.hip -DX6_ABLATE=2  (takes this file instead of the
+// product's when a *_switches.hip twin exists) or tools/experiments/wgrad_trace.py.  Numbers: tools/experiments/README.md.
 // fp32-accurate GEMMs on the bf16 matrix cores ("bf16x6").
 //
 // The exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 MFMA rate, and at the
@@ -41,7 +46,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // Measured (profiles/r04y_swizzle.log): the routed form gains 2 % (H = 128 layer) / 4.3 % (concat layer), the plain form loses 2 %
 // at the H = 128 layer (equal at the concat layer).  So: swizzled for the routed form, padded for the plain one (X6_SWZ: 0 = padded
 // everywhere, 1 = swizzled everywhere, 2 = as measured).
+#ifndef X6_SWZ
 #define X6_SWZ 2
+#endif
 #define X6_SWIZZLED(masked_) (X6_SWZ == 1 || (X6_SWZ == 2 && (masked_)))
 #define XROW_MAX 13
 
@@ -148,11 +155,17 @@ struct X6Epi {
 // keeps its routing bytes and masks in registers and runs two.
 // EPI: -1 = no epilogue, else the activation code (a template parameter: with a run-time switch the compiler evaluates
 // every activation's libm call for every element -- measured 0.12 vs 0.05 ms on the c2 dense shape)
-#define X6_MASKED_WGS 2  // workgroups per CU the routed form is compiled for (3: 168 registers with 11 of them in scratch)
-#define X6_PLAIN_WGS 3
-// (ablation builds of this kernel -- rows not gathered, no MFMAs, no result stores, term-major MFMA order, direct stores -- are made
-// from tools/experiments/bl_gemm_x6_switches.hip; their numbers are in tools/experiments/README.md)
 template <bool MASKED, int EPI>
+#ifndef X6_MASKED_WGS
+#define X6_MASKED_WGS 2  // workgroups per CU the routed form is compiled for (3: 168 registers with 11 of them in scratch)
+#endif
+#ifndef X6_PLAIN_WGS
+#define X6_PLAIN_WGS 3
+#endif
+#ifndef X6_ABLATE
+#define X6_ABLATE 0  // experiment builds (tools/experiments/variant_lib.sh): 1 A rows not gathered (tile-local rows: L2 hits), 2 no MFMAs,
+#endif               // 4 no result stores
+
 __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void gemm_rows_x6_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
@@ -185,6 +198,7 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
     gr0[i] = idx0 ? idx0[r] : r;
     gr1[i] = nsrc > 1 ? (idx1 ? idx1[r] : r) : 0;
     gr2[i] = nsrc > 2 ? (idx2 ? idx2[r] : r) : 0;
+    if (X6_ABLATE & 1) { gr0[i] = gr1[i] = gr2[i] = p_row0 + 64 * i; }
   }
   uint4 ra[2][3], rb[2][3];
   uint32_t ma[2];
@@ -267,13 +281,26 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
       }
       // swapped operands (B fragment in the A slot): the accumulator holds the transposed tile, so
       // a lane owns 4 consecutive columns of one row.  Small terms first.  The six terms of one accumulator are written back to
-      // back (hipcc alternates between two accumulators); letting the four accumulators take turns instead measured equal
-      // (profiles/r04y_term_major.log): a dependent MFMA two issue slots later does not stall
+      // back (hipcc alternates between two accumulators); X6_TERM_MAJOR=1 lets the four accumulators take turns instead --
+      // measured equal (profiles/r04y_term_major.log): a dependent MFMA two issue slots later does not stall
+#ifndef X6_TERM_MAJOR
+#define X6_TERM_MAJOR 0
+#endif
+#if X6_TERM_MAJOR
+#define X6_TERM(bx_, ax_)                                                                              \
+  _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj) {  \
+    if (X6_ABLATE & 2) { asm volatile("" ::"v"(bx_[tj]), "v"(ax_[ti])); continue; }                    \
+    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_[tj], ax_[ti], acc[ti][tj], 0, 0, 0);      \
+  }
+      X6_TERM(bm, am) X6_TERM(bl, ah) X6_TERM(bh, al) X6_TERM(bm, ah) X6_TERM(bh, am) X6_TERM(bh, ah)
+#undef X6_TERM
+#else
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
           f32x16 a = acc[ti][tj];
+          if (X6_ABLATE & 2) { asm volatile("" ::"v"(bm[tj]), "v"(am[ti]), "v"(bl[tj]), "v"(ah[ti]), "v"(bh[tj]), "v"(al[ti])); continue; }
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[tj], am[ti], a, 0, 0, 0);
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[tj], ah[ti], a, 0, 0, 0);
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], al[ti], a, 0, 0, 0);
@@ -282,6 +309,7 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], ah[ti], a, 0, 0, 0);
           acc[ti][tj] = a;
         }
+#endif
     }
     __syncthreads();
     if (kt + 1 < nk) {
@@ -290,6 +318,9 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
     }
   }
 
+#ifndef X6_STAGED_STORE
+#define X6_STAGED_STORE 1  // 0 (experiment builds): float4 stores straight from the accumulator layout
+#endif
   // The accumulator layout gives a lane 4 consecutive columns of one row, a wave-wide store 64 pieces of 16 B on 32 different
   // rows: 32-byte segments.  The tile goes through LDS instead (per wave [32 rows][64 + 4] fp32, the operand images are dead
   // after the last stage's barrier) and leaves as whole 256-byte row pieces, 16 lanes per piece: measured on the node
@@ -298,11 +329,18 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     const int m = wm * 64 + ti * 32 + li;
+#if !X6_STAGED_STORE
+    if (m >= nrows) continue;
+    float* __restrict__ crow = c + (size_t)(row0 + m) * ldc;
+#endif
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = n0 + wn * 64 + tj * 32 + 8 * gq + 4 * half;
+#if !X6_STAGED_STORE
+        if (n >= N) continue;
+#endif
         float v[4] = {acc[ti][tj][4 * gq + 0], acc[ti][tj][4 * gq + 1], acc[ti][tj][4 * gq + 2], acc[ti][tj][4 * gq + 3]};
         if (EPI >= 0) {
           float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -317,8 +355,13 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
             }
           }
         }
+#if X6_STAGED_STORE
         *reinterpret_cast<float4*>(stage + li * 68 + tj * 32 + 8 * gq + 4 * half) = make_float4(v[0], v[1], v[2], v[3]);
+#else
+        *reinterpret_cast<float4*>(crow + n) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
       }
+#if X6_STAGED_STORE
     // (a wave reads back only what it wrote itself; its LDS operations execute in order)
     const int c4 = lane & 15, n = n0 + wn * 64 + 4 * c4;
 #pragma unroll
@@ -326,8 +369,9 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
       const int r = (lane >> 4) + 4 * j;
       const int mm = wm * 64 + ti * 32 + r;
       const float4 v = *reinterpret_cast<const float4*>(stage + r * 68 + 4 * c4);
-      if (mm < nrows && n < N) *reinterpret_cast<float4*>(c + (size_t)(row0 + mm) * ldc + n) = v;
+      if (mm < nrows && n < N && !(X6_ABLATE & 4)) *reinterpret_cast<float4*>(c + (size_t)(row0 + mm) * ldc + n) = v;
     }
+#endif
   }
 }
 
@@ -550,6 +594,21 @@ __device__ __forceinline__ uint4 keep_from_bits_bfi(uint32_t b) {
   return k;
 }
 
+#ifdef BL_TRACE_WGRAD
+// experiment build only (tools/experiments/wgrad_trace.py): shader-clock stamps of one workgroup's waves
+__device__ unsigned long long* g_ww_trace = nullptr;
+__device__ int g_ww_trace_wg = -1;
+extern "C" int bl_debug_wgrad_trace(unsigned long long* buf, int wg) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ww_trace), &buf, sizeof(buf)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ww_trace_wg), &wg, sizeof(wg)) != hipSuccess) return -1;
+  return 0;
+}
+#define WW_TR(kt_, i_)                                                                                          \
+  if (tr_on && (kt_) < 64 && lane == 0) g_ww_trace[((size_t)wave * 64 + (kt_)) * 8 + (i_)] = __builtin_readcyclecounter();
+#else
+#define WW_TR(kt_, i_)
+#endif
+
 // GATHER: every operand row is addressed through an index array (idx0/1/2, g_idx all non-null); otherwise none is
 template <bool ROUTED, bool GATHER>
 __global__ __launch_bounds__(512) void gemm_wgrad_x6_wide_kernel(
@@ -689,16 +748,30 @@ __global__ __launch_bounds__(512) void gemm_wgrad_x6_wide_kernel(
 // scheduling fence: VALU, SALU and LDS reads may move across it; MFMAs, global loads and LDS stores may not -- the staging pieces
 // stay where they are written (left alone, hipcc sinks the loads to the end of the iteration and hoists the stores)
 #define WW_PIN() __builtin_amdgcn_sched_barrier(0x106);
-// (WW_S staging piece, WW_T six-term MFMA group, WW_F fragment reads: the ablation / trace builds that blank them out one at a
-// time are made from tools/experiments/bl_gemm_x6_switches.hip, profiles/r04d_wgrad_ablation.log)
+#ifndef BL_WW_ABLATE
+#define BL_WW_ABLATE 0  // experiment builds (tools/experiments/wgrad_trace.py): 1 no staging in the loop, 2 no MFMAs, 4 fragments read once
+#endif
+#if BL_WW_ABLATE & 1
+#define WW_S(x_)
+#else
 #define WW_S(x_) x_
+#endif
+#if BL_WW_ABLATE & 2
+#define WW_T(pa_, pb_) _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) { asm volatile("" ::"v"(af[t_][pa_]), "v"(bf[t_][pb_])); }
+#else
 #define WW_T(pa_, pb_) WX6_TERM(pa_, pb_)
+#endif
+#if BL_WW_ABLATE & 4
+#define WW_F(rd_, s_)
+#else
 #define WW_F(rd_, s_) WW_FRAGS(rd_, s_)
+#endif
 #define WW_ITER(X, Y, KT)                                                                              \
   {                                                                                                    \
     const int kt_ = (KT);                                                                              \
     const short* rd_ = Ls + (kt_ & 1) * WW_STAGE;                                                      \
     short* wr_ = Ls + ((kt_ + 1) & 1) * WW_STAGE + slot;                                               \
+    WW_TR(kt_, 0)                                                                                      \
     WW_F(rd_, 0)                                                                                       \
     WW_S(WW_IDX(e0 + (kt_ + 3) * 32, Y))                                                               \
     WW_PIN()                                                                                           \
@@ -721,6 +794,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_x6_wide_kernel(
     WW_S(WW_STORE_A0(Y))                                                                               \
     WW_PIN()                                                                                           \
     WW_T(0, 0)                                                                                         \
+    WW_TR(kt_, 1)                                                                                      \
     WW_F(rd_, 1)                                                                                       \
     WW_T(1, 1)                                                                                         \
     WW_PIN()                                                                                           \
@@ -731,9 +805,14 @@ __global__ __launch_bounds__(512) void gemm_wgrad_x6_wide_kernel(
     WW_S(WW_STORE_B(Y))                                                                                \
     WW_PIN()                                                                                           \
     WW_T(0, 2) WW_T(1, 0) WW_T(0, 1) WW_T(0, 0)                                                        \
+    WW_TR(kt_, 2)                                                                                      \
     __syncthreads();                                                                                   \
+    WW_TR(kt_, 5)                                                                                      \
   }
 
+#ifdef BL_TRACE_WGRAD
+  const bool tr_on = g_ww_trace != nullptr && (int)blockIdx.x == g_ww_trace_wg && blockIdx.y == 0;
+#endif
   // prologue: stage 0 through set A into buffer 0, stage 1 into set B, rows of stage 2 into index set A
   WW_IDX(e0, A)
   WW_LOAD_A0(A) WW_LOAD_A1(A) WW_LOAD_B(A)
@@ -747,6 +826,9 @@ __global__ __launch_bounds__(512) void gemm_wgrad_x6_wide_kernel(
   WW_IDX(e0 + 64, A)
   __syncthreads();
   bf16x8 af[2][3], bf[2][3];
+#if BL_WW_ABLATE & 4
+  WW_FRAGS(Ls, 0)
+#endif
   for (int kt = 0; kt < nk2; kt += 2) {
     WW_ITER(A, B, kt)
     WW_ITER(B, A, kt + 1)

@@ -24,7 +24,9 @@ for f in srcs:
     o = os.path.join(OUT, f[:-4] + ".o")
     objs.append(o)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", f"-DBL_WW_ABLATE={ABLATE}"] + (["-DBL_TRACE_WGRAD"] if TRACE else []) + [
-                    "-c", os.path.join(CSRC, f), "-o", o], check=True)
+                    "-I", CSRC, "-I", os.path.join(CSRC, "..", "..", "include"),
+                    "-c", (os.path.join(os.path.dirname(os.path.abspath(__file__)), "bl_gemm_x6_switches.hip") if f == "bl_gemm_x6.hip"
+                           else os.path.join(CSRC, f)), "-o", o], check=True)  # (the switches live in the experiment twin of bl_gemm_x6.hip)
 lib_path = os.path.join(OUT, "libbuglab_hip_trace.so")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path], check=True)
 
