@@ -188,69 +188,15 @@ def measured_mfma_busy(kind):
     return round(float(rec["mfma_busy_frac"]), 4), os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(args, seconds_budget=30.0):
-    """The CPU oracle (a restatement; the reference's ptgnn stack is not installable) on a bounded sample of the same
-    workload, SURVEY section 8(d)'s protocol as far as ~30 s allow: synthetic samples of the headline shape through the
-    product's collator (timed separately), then forward + backward + clip/Adam steps of a 4-graph minibatch in fp32 on all
-    host cores -- one warm-up step, median of up to three timed ones."""
-    import statistics
+def cpu_baseline(args, seconds_budget=20.0, graphs_per_minibatch=8):
+    """SURVEY section 8(d)'s protocol within a ~20 s budget: the CPU oracle (a restatement: the reference's ptgnn stack is not
+    installable) driven through the kept training entry -- synthetic *.msgpack.l.gz shard -> registry model -> metadata pass ->
+    ModelTrainer.train on CPU (oracle/cpu_train.py) -- one 8-graph minibatch of BASELINE-sized graphs per epoch, fp32, a warm-up
+    epoch and then up to five timed ones (median); reading + tensorising + collating is timed apart."""
+    from oracle.cpu_train import run_cpu_train
 
-    import torch
-
-    from buglab.data.collate import collate_samples
-    from buglab.data.synthetic import make_samples
-    from oracle import buglab_oracle as O
-
-    nb = 4
-    cfg = O.OracleConfig(hidden=args.hidden, num_layers=args.layers, num_edge_types=args.types, dropout=args.dropout,
-                         msg_act_placement=getattr(args, "placement", "aggregated"))
-    samples = make_samples(nb, seed=123, num_nodes=args.nodes, num_messages=args.messages, num_edge_types=args.types)
-    t0 = time.perf_counter()
-    mb = collate_samples(samples, args.types)
-    collate_s = time.perf_counter() - t0
-    params = O.init_params(cfg, seed=0)
-    m = {k: torch.zeros_like(v) for k, v in params.items()}
-    v = {k: torch.zeros_like(vv) for k, vv in params.items()}
-    # thread count: the oracle's ops are small; on a many-core host the default (one thread per core) is several times SLOWER than
-    # a handful (256-thread box: 4.2 / 5.6 / 3.8 / 1.9 / 0.84 graphs/s at 8 / 16 / 32 / 64 / 128 threads, tools/experiments/cpu_threads.py).
-    # One calibration step per candidate (they double as the warm-up), then the timed steps at the fastest.
-    default_threads, ncores = torch.get_num_threads(), os.cpu_count() or 8
-    step, cal = 0, {}
-    for nt in sorted({min(c, ncores) for c in (8, 16, 32)}):
-        torch.set_num_threads(nt)
-        t0 = time.perf_counter()
-        _, grads = O.forward_backward(params, mb, cfg, seed=step + 1 if args.dropout > 0 else None)
-        step += 1
-        O.adam_clip_step(params, grads, m, v, step)
-        cal[nt] = time.perf_counter() - t0
-    best_nt = min(cal, key=cal.get)
-    torch.set_num_threads(best_nt)
-    times, spent = [], sum(cal.values())
-    try:
-        while True:
-            t0 = time.perf_counter()
-            _, grads = O.forward_backward(params, mb, cfg, seed=step + 1 if args.dropout > 0 else None)  # same dropout rate as the GPU run
-            step += 1
-            O.adam_clip_step(params, grads, m, v, step)
-            dt = time.perf_counter() - t0
-            spent += dt
-            times.append(dt)
-            if spent + dt > seconds_budget or len(times) >= 3:
-                break
-    finally:
-        torch.set_num_threads(default_threads)
-    return {
-        "value": round(nb / statistics.median(times), 3),
-        "unit": "graphs/s",
-        "cores": best_nt,
-        "kind": "port",
-        "sample": f"median of {len(times)} train steps of a {nb}-graph minibatch ({args.nodes} nodes/{args.messages} msgs per graph, "
-                  f"H{args.hidden}, {args.layers} layers, T{args.types}) on the CPU oracle, dropout {args.dropout}, {best_nt} torch threads "
-                  f"(fastest of {sorted(cal)} on this {ncores}-thread host; one warm-up / calibration step each); collation of the minibatch "
-                  f"(product collator, not in the rate): {1e3 * collate_s:.1f} ms",
-        "collate_ms": round(1e3 * collate_s, 2),
-        "host_threads": ncores,
-    }
+    return run_cpu_train(seconds_budget=seconds_budget, graphs_per_minibatch=graphs_per_minibatch, nodes_per_graph=args.nodes,
+                         hidden=args.hidden, num_layers=args.layers, dropout=args.dropout, placement=getattr(args, "placement", "aggregated"))
 
 
 def cpu_baseline_seq(args, seconds_budget=25.0):

@@ -11,15 +11,19 @@ sys.path.insert(0, ROOT)
 
 
 def test_cpu_baseline_leg_returns_the_contract_fields():
+    """the CPU oracle through ModelTrainer.train on a synthetic shard (oracle/cpu_train.py), here on a toy
+    configuration -- the record must carry the contract's fields, say what the sample was, and leave the thread count alone."""
     import bench
 
     before = torch.get_num_threads()
-    a = argparse.Namespace(hidden=32, layers=4, types=4, dropout=0.1, nodes=60, messages=240)
-    out = bench.cpu_baseline(a, seconds_budget=5.0)
-    assert torch.get_num_threads() == before  # the calibration restores the thread count
+    a = argparse.Namespace(hidden=32, layers=4, types=4, dropout=0.1, nodes=120, messages=0, placement="message")
+    out = bench.cpu_baseline(a, seconds_budget=4.0, graphs_per_minibatch=3)
+    assert torch.get_num_threads() == before
     assert out["kind"] == "port" and out["unit"] == "graphs/s" and out["value"] > 0
     assert 1 <= out["cores"] <= (os.cpu_count() or 1) and out["host_threads"] == (os.cpu_count() or 8)
-    assert "4-graph minibatch" in out["sample"] and out["collate_ms"] >= 0
+    assert out["minibatch"]["graphs"] == 3 and out["minibatch"]["edge_types"] > 4 and out["epochs_timed"] >= 1
+    assert "ModelTrainer.train" in out["sample"] and "placement message" in out["sample"] and out["input_ms_per_minibatch"] >= 0
+    assert out["end_to_end_graphs_per_s"] <= out["value"] * 1.001
 
 
 def test_pmc_record_of_a_kind_is_the_launch_weighted_mean_over_its_kernels(tmp_path):
