@@ -29,6 +29,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak
 # The message-passing GEMMs compute fp32-accurate products as SIX bf16 MFMA terms (csrc/bl_gemm_x6.hip),
 # so their ceiling in algorithmic (2 M N K) FLOP/s is the bf16 pipe's peak / 6.
 MFMA_X6_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
+# ... or, since round 6, as THREE fp16 MFMA terms over two fp16 planes per operand (csrc/bl_gemm_h3.hip; the fp16 pipe's dense
+# peak equals the bf16 one's): ceiling = peak / 3.
+MFMA_H3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -42,6 +45,9 @@ _KIND_TO_KERNEL = {
     "msg_gemm_x6": ["void gemm_rows_x6_kernel<false, -1>", "void gemm_rows_x6w_kernel<false>"],
     "msg_dgrad_x6": ["void gemm_rows_x6_kernel<true, -1>", "void gemm_rows_x6w_kernel<true>"],
     "msg_wgrad_x6": ["void gemm_wgrad_x6_wide_kernel<true, true>", "void gemm_wgrad_x6_kernel<true>"],
+    "msg_gemm_h3": ["void gemm_rows_h3_kernel<false>"],
+    "msg_dgrad_h3": ["void gemm_rows_h3_kernel<true>"],
+    "msg_wgrad_h3": ["void gemm_wgrad_h3_kernel<true>"],
 }
 
 
@@ -105,8 +111,8 @@ def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, 
     d = kern[dom]
     hbm = d.get("bytes", 0) > 0
     achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if hbm else d["flop"] / (d["ms"] * 1e-3) / 1e12
-    x6 = "x6" in dom
-    peak = HBM_PEAK_GBS if hbm else (MFMA_X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS)
+    x6, h3 = "x6" in dom, "h3" in dom
+    peak = HBM_PEAK_GBS if hbm else (MFMA_H3_PEAK_TFLOPS if h3 else MFMA_X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS)
     traffic, traffic_src = measured_traffic(dom)
     per_step = lambda table: {k: {"ms_per_step": round(v["ms"] / prof_steps, 3),
                                   **({"tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flop"] > 0 and v["ms"] > 0 else {}),
@@ -118,17 +124,20 @@ def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, 
         "achieved": round(achieved, 2),
         "peak": round(peak, 1),
         "peak_basis": ("HBM3E peak; achieved = algorithmic bytes of the launch (operands read once, results written once) / its duration"
-                       if hbm else "dense bf16 MFMA peak 2500 TF/s / 6 (bf16x6: six bf16 MFMA terms per fp32-accurate product)"
+                       if hbm else "dense fp16 MFMA peak 2500 TF/s / 3 (f16x3: three fp16 MFMA terms per fp32-accurate product)"
+                       if h3 else "dense bf16 MFMA peak 2500 TF/s / 6 (bf16x6: six bf16 MFMA terms per fp32-accurate product)"
                        if x6 else "dense fp32 MFMA peak"),
         "unit": "GB/s" if hbm else "TFLOP/s",
         "frac": round(achieved / peak, 4),
-        **({} if hbm else {"frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4)}),
+        **({} if hbm else {"frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                            "frac_of_bf16x6_ceiling": round(achieved / MFMA_X6_PEAK_TFLOPS, 4)}),
         "avg_launch_ms": round(d["ms"] / d["launches"], 4),
         "launches_per_step": d["launches"] / prof_steps,
         "share_of_serial_gpu_time": round(d["ms"] / sum(v["ms"] for v in kern.values()), 4),
         "serial_ms_per_step": round(1e3 * serial_step_s, 3),
         # whole-step view against both ceilings: training ~ 3x forward work
         "step_frac_of_mfma_x6_roofline": round(per_gpu_rate * 3 * fwd_flop / (MFMA_X6_PEAK_TFLOPS * 1e12), 4),
+        "step_frac_of_mfma_h3_roofline": round(per_gpu_rate * 3 * fwd_flop / (MFMA_H3_PEAK_TFLOPS * 1e12), 4),
     }
     mfma_busy = measured_mfma_busy(dom)
     if mfma_busy is not None:
@@ -160,6 +169,8 @@ def calibrate_rooflines(box, roof, also, per_gpu_rate):
             return
         if r["bound"] == "hbm":
             r["peak_calibrated"] = round(1e3 * box["hbm_calib_tbs"], 1)
+        elif "f16x3" in r.get("peak_basis", ""):
+            r["peak_calibrated"] = round(box["mfma_calib_tflops"] / 3.0, 1)
         elif "bf16x6" in r.get("peak_basis", ""):
             r["peak_calibrated"] = round(box["mfma_calib_tflops"] / 6.0, 1)
         else:
@@ -309,6 +320,9 @@ def main():
     ap.add_argument("--placement", default="aggregated", choices=["aggregated", "message"],
                     help="where the message activation (GELU) sits relative to the max aggregation: on the aggregated [N, Dm] tensor "
                          "(default: ptgnn's order as recollected, DESIGN.md section 2) or on every message before the max (rounds 1-5)")
+    ap.add_argument("--msg-gemm", default="f16x3", choices=["f16x3", "bf16x6"],
+                    help="operand split of the message GEMMs (forward, weight gradient, routed input gradient): two fp16 planes / three MFMA "
+                         "terms with power-of-two tensor scales (default, csrc/bl_gemm_h3.hip) or three bf16 planes / six terms (rounds 2-5)")
     ap.add_argument("--serial", action="store_true", help="weight-gradient GEMMs on the main stream everywhere (no side-stream overlap): the run "
                     "whose rocprofv3 --kernel-trace --stats averages are the exclusive kernel times the roofline quotes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -353,6 +367,7 @@ def main():
     if world != args.gpus and rank == 0:  # the launcher decides; the line reports what actually ran (n_gpus = world)
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running and reporting n_gpus={world}", file=sys.stderr)
     hip_ops.load_library()  # fail loudly if the HIP extension is missing
+    hip_ops.set_msg_gemm_mode(args.msg_gemm)
     if args.serial:
         hip_ops.USE_SIDE_STREAM = False
     if args.wgrad_kcap:
@@ -458,10 +473,14 @@ def main():
             setattr(a, k, v)
         m_, mb2_, o_ = build_workload(a)
         st_ = make_step(m_, mb2_, o_, a.graphs)
-        el_, _ = timed(st_, args.steps, args.warmup)
-        kern_, serial_s_ = profile_pass(st_, False)  # exclusive kernel times of this configuration (after its timed region)
-        hip_ops.join_side_stream()
-        torch.cuda.synchronize()
+        prev_mode = hip_ops.set_msg_gemm_mode(a.msg_gemm)
+        try:
+            el_, _ = timed(st_, args.steps, args.warmup)
+            kern_, serial_s_ = profile_pass(st_, False)  # exclusive kernel times of this configuration (after its timed region)
+            hip_ops.join_side_stream()
+            torch.cuda.synchronize()
+        finally:
+            hip_ops.set_msg_gemm_mode(prev_mode)
         del m_, mb2_, o_, st_
         gc.collect()
         torch.cuda.empty_cache()
@@ -564,6 +583,8 @@ def main():
         also["reference minibatch regime: configs[1] model, batch=15 graphs/GPU (30000 nodes: modelregistry.py:53)"] = side_config(graphs=15)
         other = "message" if args.placement == "aggregated" else "aggregated"
         also[f"configs[1] with message_activation_placement={other} (the non-default placement of the one unpinned spec point)"] = side_config(placement=other)
+        if args.msg_gemm == "f16x3":
+            also["configs[1] with the message GEMMs as bf16x6 (three bf16 planes, six MFMA terms: rounds 2-5)"] = side_config(msg_gemm="bf16x6")
         if world == 1:
             also["configs[4] seq-great hidden=256 layers=5 heads=8 ff=1024 batch=32 sequences x 512 tokens"] = side_config(
                 model="seq-great", hidden=256, graphs=32, layers=5, types=8, dropout=0.1)
@@ -586,7 +607,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (bf16x6 split products)",  # fp32 storage / accumulation; matrix-core products as six bf16 split terms
+            # fp32 storage / accumulation; matrix-core products as split terms: message GEMMs two fp16 planes x three terms (or bf16x6),
+            # dense node update / sequence-model projections three bf16 planes x six terms
+            "dtype": "f32 (f16x3 / bf16x6 split products)" if args.msg_gemm == "f16x3" and not seq else "f32 (bf16x6 split products)",
             "data": "synthetic",
             "config": {
                 "workload": (f"seq-great relational transformer hidden={args.hidden} layers={args.layers} heads=8 ff={4 * args.hidden} "
@@ -594,7 +617,7 @@ def main():
                             (f"gnn-mlp hidden={args.hidden} layers={args.layers} edge_types={args.types} "
                              f"batch={args.graphs} graphs/GPU x ({args.nodes} nodes, {args.messages} msgs) dropout={args.dropout}"
                              + (" power-law in-degree (max 512)" if args.degree == "powerlaw" else "")),
-                **({} if seq else {"message_activation_placement": args.placement}),
+                **({} if seq else {"message_activation_placement": args.placement, "message_gemm_split": args.msg_gemm}),
                 "global_batch": args.graphs * world,
                 "parallelism": f"dp{world}",
                 "loss_last_step": round(last_loss, 5),

@@ -402,6 +402,42 @@ int bl_prof_num_kinds(void);
 const char* bl_prof_kind_name(int32_t kind);
 int bl_prof_read(int32_t kind, double* ms, double* flop, int64_t* launches, int32_t* overlapped);
 
+/* ---------------------------------------------------------------------------------------------
+ * fp32-accurate GEMMs on the fp16 matrix cores ("f16x3", csrc/bl_gemm_h3.hip): the second operand split of the message-passing
+ * GEMMs.  An fp32 operand x, multiplied by a power-of-two scale s of its tensor, is split into TWO fp16 planes hi + lo
+ * (22+ significant bits where |x s| >= 2^-3; an absolute error of 2^-25 / s below; finite values saturate at 65504 / s); a
+ * product is three fp16 MFMA terms hh + hl + lh with fp32 accumulation, times 1 / (s_a s_b): half the matrix-pipe work and
+ * two thirds of the operand bytes of bf16x6 at fp32-class accuracy (error vs fp64 below a plain fp32 matmul's) -- for tensors
+ * whose range is bounded or measured.  Same contracts as the bf16x6 entry points they mirror (ptgnn MlpMessagePassingLayer's
+ * per-type Linear forward / backward, buglab/models/gnnlayerdefs.py:6-23).
+ *   packed rows: two planes back to back per row, [hi x D | lo x D] halves (4 D bytes);
+ *   bl_pack_f16x2: rows of x[:, 0:D] into columns col_off .. col_off + D of D_total-wide packed rows (a ConcatResidual pair is
+ *     packed in two calls); effective scale = scale x (amax_dev ? 2^(14 - ceil(log2 *amax_dev)) : 1) -- amax_dev: device float
+ *     holding max |x| of the tensor (gradient tensors, whose magnitude is not known in advance; bl_amax or a producing kernel);
+ *   bl_amax: *amax_dev = max(*amax_dev, max |x[0:n]|) (zero it first);
+ *   bl_pack_weights_h3 / bl_packed_weight_elems_h3: tiled weight image (16 KB block per group, 128-column tile, 32-k stage);
+ *   bl_gemm_rows_h3: C[rows of g] = out_scale x rows(a) . B_g (+ routed left operand with win_bits); out_scale = 1 / (s_a s_b),
+ *     divided by 2^(14 - ceil(log2 *a_amax_dev)) when a_amax_dev is given (left operand packed with a device amax);
+ *   bl_gemm_wgrad_h3: gW_g += out_scale x rows(a)^T . G rows (g_idx gather, win_bits routing as bl_gemm_wgrad_routed_x6);
+ *     g_amax_dev: the device amax G was packed with. */
+#define BL_H3_ROW_SCALE 256.0f /* layer inputs: |h| <= 1.25 after tanh x dropout, embedding rows O(1); saturation at 255.9 */
+#define BL_H3_W_SCALE 64.0f    /* weights: saturation at 1023 */
+/* which split the message GEMMs of bl_mp_layer_fwd / _bwd use: 1 = f16x3 (default), 0 = bf16x6; BL_MSG_GEMM=x6 / h3 in the
+ * environment sets the initial value.  Returns the previous mode.  bl_mp_layer_weight_image then returns 2 (f16x3 image). */
+int32_t bl_set_msg_gemm_mode(int32_t f16x3);
+int32_t bl_get_msg_gemm_mode(void);
+int bl_pack_f16x2(const float* x, int32_t ld, int64_t R, int32_t D, int32_t D_total, int32_t col_off, float scale,
+                  const float* amax_dev, uint16_t* out, void* stream);
+int bl_amax(const float* x, int64_t n, float* amax_dev, void* stream);
+int64_t bl_packed_weight_elems_h3(int32_t G, int32_t K, int32_t N);
+int bl_pack_weights_h3(const float* w, int32_t G, int32_t K, int32_t N, int32_t w_is_kn, float scale, uint16_t* out, void* stream);
+int bl_gemm_rows_h3(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp, int64_t b_group_stride,
+                    const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, float out_scale,
+                    const float* a_amax_dev, float* c, int32_t ldc, void* stream);
+int bl_gemm_wgrad_h3(const bl_rows_packed_t* a, const uint16_t* g_packed, const int32_t* g_idx, const uint32_t* win_bits,
+                     int32_t ld_bits, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K,
+                     float out_scale, const float* g_amax_dev, float* gw, int64_t gw_group_stride, int32_t ld_gw, void* stream);
+
 /* Box calibration (measurement support for bench.py; nothing on the training path calls these): boxes
  * of the pool differ by several per cent in the shader clock they sustain at the package power limit, so the bench line
  * carries what THIS chip delivers on two fixed kernels next to the paper peaks.  The caller times the launch with HIP events.

@@ -152,6 +152,16 @@ _SIGNATURES = {
     "bl_rel_value_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_dropout_inplace": ([c_void_p, c_int64, bl_dropout_t, c_void_p], ctypes.c_int),
+    "bl_pack_f16x2": ([c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_amax": ([c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "bl_packed_weight_elems_h3": ([c_int32, c_int32, c_int32], c_int64),
+    "bl_pack_weights_h3": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gemm_rows_h3": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                         c_int32, c_float, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gemm_wgrad_h3": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                          c_int32, c_float, c_void_p, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
+    "bl_set_msg_gemm_mode": ([c_int32], c_int32),
+    "bl_get_msg_gemm_mode": ([], c_int32),
     "bl_calib_mfma_bf16": ([c_int32, c_int32, c_void_p, POINTER(ctypes.c_double), c_void_p], ctypes.c_int),
     "bl_calib_stream_copy": ([c_void_p, c_void_p, c_int64, c_void_p], ctypes.c_int),
     "bl_prof_enable": ([c_int32], ctypes.c_int),
@@ -443,6 +453,83 @@ def gemm_rows_x6(sources, bp, M, N, *, group_ptr=None, group_w=None, G=1, win_bi
                                            int(G), int(M), int(N), int(K), out.data_ptr(), out.stride(0), _stream()),
             "bl_gemm_rows_x6")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# f16x3: fp32-accurate GEMMs on the fp16 matrix cores (csrc/bl_gemm_h3.hip) -- two fp16 planes per operand, three MFMA terms,
+# power-of-two tensor scales.  H3_ROW_SCALE: layer inputs (|h| <= 1.25 after tanh x dropout; embedding rows), H3_W_SCALE: weights.
+H3_ROW_SCALE = 256.0
+H3_W_SCALE = 64.0
+
+
+def pack_f16x2(x: torch.Tensor, scale: float = H3_ROW_SCALE, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[R, D] fp32 -> [R, 2 D] int16 (hi plane | lo plane of x * scale; amax: device float with max |x| -> the scale is derived on
+    the device, the consumer GEMM takes the same tensor as `a_amax` / `g_amax`)."""
+    _f32(x, "x")
+    R, D = x.shape
+    out = torch.empty((R, 2 * D), dtype=torch.int16, device=x.device)
+    _check(load_library().bl_pack_f16x2(x.data_ptr(), x.stride(0), int(R), int(D), int(D), 0, float(scale), _p(amax), out.data_ptr(), _stream()),
+           "bl_pack_f16x2")
+    return out
+
+
+def amax(x: torch.Tensor) -> torch.Tensor:
+    """device float [1] = max |x| (bl_amax)"""
+    _f32(x, "x")
+    out = torch.zeros((1,), dtype=torch.float32, device=x.device)
+    _check(load_library().bl_amax(x.data_ptr(), int(x.numel()), out.data_ptr(), _stream()), "bl_amax")
+    return out
+
+
+def pack_weights_h3(w: torch.Tensor, w_is_kn: bool, scale: float = H3_W_SCALE) -> torch.Tensor:
+    """w [G, K, N] (w_is_kn) or [G, N, K] -> tiled f16x2 image [G, *] int16 (bl_pack_weights_h3)"""
+    _f32(w, "w")
+    G, K, N = (w.shape[0], w.shape[1], w.shape[2]) if w_is_kn else (w.shape[0], w.shape[2], w.shape[1])
+    lib = load_library()
+    out = torch.empty((G, int(lib.bl_packed_weight_elems_h3(1, K, N))), dtype=torch.int16, device=w.device)
+    _check(lib.bl_pack_weights_h3(w.data_ptr(), G, K, N, 1 if w_is_kn else 0, float(scale), out.data_ptr(), _stream()), "bl_pack_weights_h3")
+    return out
+
+
+def _rows_packed_h(sources):
+    r = bl_rows_packed_t()
+    K = 0
+    for j, (xp, idx, width) in enumerate(sources):
+        _req(xp, torch.int16, f"packed source {j}")
+        r.xp[j] = xp.data_ptr()
+        r.idx[j] = _i32(idx).data_ptr() if idx is not None else None
+        r.width[j] = width
+        K += width
+    r.nsrc = len(sources)
+    return r, K
+
+
+def gemm_rows_h3(sources, bp, M, N, *, out_scale, group_ptr=None, group_w=None, G=1, win_bits=None, a_amax=None, kind="gemm_rows_h3"):
+    """sources: [(pack_f16x2 rows, row index or None, width)]; bp: pack_weights_h3 image; out_scale = 1 / (row scale x weight scale)"""
+    r, K = _rows_packed_h(sources)
+    out = torch.empty((M, N), dtype=torch.float32, device=bp.device)
+    if M == 0:
+        return out
+    with _timed(kind + ("_grouped" if group_ptr is not None else ""), 2.0 * M * N * K):
+        _check(load_library().bl_gemm_rows_h3(ctypes.byref(r), _p(win_bits), int(win_bits.stride(0)) if win_bits is not None else 0,
+                                              _req(bp, torch.int16, "bp").data_ptr(), int(bp.stride(0)), _p(group_ptr), _p(group_w), int(G),
+                                              int(M), int(N), int(K), float(out_scale), _p(a_amax), out.data_ptr(), out.stride(0), _stream()),
+               "bl_gemm_rows_h3")
+    return out
+
+
+def gemm_wgrad_h3(sources, g_packed, M, N, gw, *, out_scale, g_idx=None, win_bits=None, g_amax=None, gw_group_stride=0, group_ptr=None,
+                  group_w=None, G=1):
+    """gw[g] += out_scale * rows(sources)^T . G rows (g_idx gather, win_bits routing): bl_gemm_wgrad_h3"""
+    r, K = _rows_packed_h(sources)
+    if M == 0:
+        return gw
+    with _timed("gemm_wgrad_h3", 2.0 * M * N * K):
+        _check(load_library().bl_gemm_wgrad_h3(ctypes.byref(r), _req(g_packed, torch.int16, "g_packed").data_ptr(), _p(g_idx), _p(win_bits),
+                                               int(win_bits.stride(0)) if win_bits is not None else 0, _p(group_ptr), _p(group_w), int(G), int(M),
+                                               int(N), int(K), float(out_scale), _p(g_amax), gw.data_ptr(), int(gw_group_stride), int(gw.stride(-2)),
+                                               _stream()), "bl_gemm_wgrad_h3")
+    return gw
 
 
 def _rows_packed(sources):
@@ -963,6 +1050,19 @@ def set_deterministic(on: bool = True) -> None:
     os.environ["BL_DETERMINISTIC"] = "1" if on else "0"
 
 
+def set_msg_gemm_mode(mode: str) -> str:
+    """'f16x3' (default) or 'bf16x6': the operand split of the message GEMMs inside the fused layer calls (bl_set_msg_gemm_mode).
+    Returns the previous mode.  Not to be switched between a forward pass and its backward pass."""
+    if mode not in ("f16x3", "bf16x6"):
+        raise ValueError("mode must be 'f16x3' or 'bf16x6'")
+    prev = load_library().bl_set_msg_gemm_mode(1 if mode == "f16x3" else 0)
+    return "f16x3" if prev else "bf16x6"
+
+
+def msg_gemm_mode() -> str:
+    return "f16x3" if load_library().bl_get_msg_gemm_mode() else "bf16x6"
+
+
 def set_wgrad_tile(rows: int) -> int:
     """256 (default): wide weight-gradient tile where it applies; 128: the 128 x 128 tile everywhere.  -> previous value."""
     return int(load_library().bl_set_wgrad_tile(int(rows)))
@@ -1017,7 +1117,8 @@ def _as_groups(w: torch.Tensor) -> torch.Tensor:
 # step -- in ONE launch (bl_pack_weights_multi) over a table of every copy any layer has asked for so far, instead of one
 # launch per layer and form.  Validity = (parameter object, its autograd version, the epoch bumped by whoever writes
 # parameters behind autograd's back, its storage address).
-_KIND = {"nk": 0, "kn": 1, "t": 2, "nkw": 3, "knw": 4}  # ..w: the wide row GEMM's image (bl_pack_weights_x6w)
+# ..w: the wide row GEMM's image (bl_pack_weights_x6w); ..h: the f16x3 image (bl_pack_weights_h3, scale BL_H3_W_SCALE)
+_KIND = {"nk": 0, "kn": 1, "t": 2, "nkw": 3, "knw": 4, "nkh": 5, "knh": 6}
 
 
 class _WeightCopies:
@@ -1048,6 +1149,7 @@ class _WeightCopies:
                 else:  # "kn": C = A . W (K x N) ; "nk": C = G . W^T, i.e. bl_pack_weights_x6 of [G][N'][K'] with N' = K, K' = N
                     n_out, k_in = (N, K) if nm.startswith("kn") else (K, N)
                     per = (int(load_library().bl_packed_weight_elems_x6w(1, k_in, n_out)) if nm.endswith("w")
+                           else int(load_library().bl_packed_weight_elems_h3(1, k_in, n_out)) if nm.endswith("h")
                            else ((n_out + 127) // 128) * (k_in // 32) * 12288)
                     ent["forms"][nm] = torch.empty((G, per), dtype=torch.int16, device=W.device)
                 ent["version"] = -1  # (a new form has to be filled)
@@ -1102,10 +1204,11 @@ def _packed_message_weights(W: torch.Tensor, Din: int, need_bwd: bool):
     row GEMM's image where that kernel takes the shape, the tiled one otherwise."""
     lib = load_library()
     Dm = W.shape[2]
-    fwd = "knw" if lib.bl_mp_layer_weight_image(int(Din), int(Dm), 0) else "kn"
+    suffix = ("", "w", "h")  # bl_mp_layer_weight_image: 0 = 128 x 128 bf16x6 image, 1 = wide bf16x6 image, 2 = f16x3 image
+    fwd = "kn" + suffix[int(lib.bl_mp_layer_weight_image(int(Din), int(Dm), 0))]
     if not need_bwd:
         return _weight_copies.get(W, (fwd,))[0], None
-    bwd = "nkw" if lib.bl_mp_layer_weight_image(int(Din), int(Dm), 1) else "nk"
+    bwd = "nk" + suffix[int(lib.bl_mp_layer_weight_image(int(Din), int(Dm), 1))]
     got = _weight_copies.get(W, (fwd, bwd))
     return got[0], got[1]
 

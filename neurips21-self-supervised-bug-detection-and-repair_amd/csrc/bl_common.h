@@ -32,6 +32,11 @@ int bl_mp_scatter_grad_hubs_impl(const float* g_a, int32_t ld_ga, const int32_t*
                                  const int32_t* tgt_msgs, int32_t N, int32_t Din, int32_t split, float* g_h_lo, int32_t ld_lo, float* g_h_hi,
                                  int32_t ld_hi, const int32_t* node_order, int32_t hub_slots, void* stream);
 
+int bl_node_update_bwd_impl(const float* g_out, const float* h_out, int32_t nrows, int32_t Dout, bl_dropout_t drop,
+                            const uint16_t* wd_packed_bwd, const float* agg, const float* mean, const float* rstd, const float* ln_g,
+                            const float* dact, int32_t Dm, uint16_t* g_z_packed, float* g_bias, float* gq, uint16_t* gq_packed,
+                            float* g_ln_g, float* g_ln_b, float* gq_amax, void* stream);
+
 #define BL_CHECK_ARG(cond, ...)   \
   do {                            \
     if (!(cond)) {                \
@@ -143,6 +148,22 @@ __device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& m, uint16
   m = f2bf_rne(r1);
   const float r2 = r1 - bf2f(m);  // exact
   l = f2bf_rne(r2);
+}
+
+// ---- f16x2 split of an fp32 value (csrc/bl_gemm_h3.hip): x = hi + lo up to 2^-24 |x| while both planes are normal fp16 numbers
+// (|x| >= 2^-3); below that the error is absolute, <= 2^-25.  The caller has multiplied x by the tensor's power-of-two scale.
+// A finite value beyond fp16's range saturates at +-65504; +-inf / NaN: hi = x's fp16 image, lo = 0 (inf - inf would be NaN
+// anyway: the product is NaN or inf either way, as in split3).
+__device__ __forceinline__ void split2h(float x, uint16_t& h, uint16_t& l) {
+  if (fabsf(x) > 65504.f && fabsf(x) <= 3.402823466e38f) x = copysignf(65504.f, x);
+  const _Float16 hh = (_Float16)x;  // round to nearest even
+  h = __builtin_bit_cast(uint16_t, hh);
+  if ((h & 0x7C00u) == 0x7C00u) {  // inf / NaN
+    l = 0;
+    return;
+  }
+  const float r = x - (float)hh;  // exact
+  l = __builtin_bit_cast(uint16_t, (_Float16)r);
 }
 
 // Ordered flush (deterministic mode): workgroup number `turn` of a counter's sequence may add only after workgroup

@@ -27,6 +27,7 @@
 #include "bl_common.h"
 #include "bl_x6_locate.h"
 #include "bl_x6w_image.h"
+#include "bl_h3_image.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // Every operand copy a training step needs of the (just updated) weights in ONE launch: a table of jobs in device memory
 // (built once per model by the caller), job j owning the workgroups first_block[j] .. first_block[j+1].
 //   kind 0 / 1: bl_pack_weights_x6 with w_is_kn = kind;  kind 2: out[g][n][k] = w[g][k][n] in fp32 (W transposed, the
-//   operand of bl_routed_dgrad_nodes);  kind 3 / 4: bl_pack_weights_x6w (the wide row GEMM's image) with w_is_kn = kind - 3.
+//   operand of bl_routed_dgrad_nodes);  kind 3 / 4: bl_pack_weights_x6w (the wide row GEMM's image) with w_is_kn = kind - 3;
+//   kind 5 / 6: bl_pack_weights_h3 (the f16x3 image) with w_is_kn = kind - 5.
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_job_t* __restrict__ jobs, int njobs) {
   int j = 0;
   while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;  // (a few dozen jobs: a linear walk of a cached table)
@@ -121,6 +123,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_j
   const long long t = (long long)((int)blockIdx.x - job.first_block) * 256 + threadIdx.x;
   if (job.kind <= 1) {
     pack_weights_thread(job.w, job.G, job.K, job.N, job.kind, reinterpret_cast<uint4*>(job.out), t);
+  } else if (job.kind >= 5) {  // 5 / 6: bl_pack_weights_h3 (the f16x3 image, scale BL_H3_W_SCALE) with w_is_kn = kind - 5
+    pack_weights_h_thread(job.w, job.G, job.K, job.N, job.kind - 5, reinterpret_cast<uint4*>(job.out), t, BL_H3_W_SCALE);
   } else if (job.kind >= 3) {
     pack_weights_wide_thread(job.w, job.G, job.K, job.N, job.kind - 3, reinterpret_cast<uint4*>(job.out), t);
   } else {
@@ -809,7 +813,7 @@ extern "C" int bl_pack_weights_x6(const float* w, int32_t G, int32_t K, int32_t 
 }
 
 extern "C" int64_t bl_pack_job_blocks(int32_t kind, int32_t G, int32_t K, int32_t N) {
-  if (kind <= 1) return ((int64_t)G * ((N + 127) / 128) * (K / 32) * 512 + 255) / 256;
+  if (kind <= 1 || kind >= 5) return ((int64_t)G * ((N + 127) / 128) * (K / 32) * 512 + 255) / 256;
   if (kind >= 3) return ((int64_t)G * ((N + WBN - 1) / WBN) * (K / 32) * (WBN * 4) + 255) / 256;
   return ((int64_t)G * K * N + 255) / 256;
 }

@@ -31,7 +31,7 @@ std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
 const char* kProfNames[] = {"pack_rows",      "msg_gemm_x6",  "segment_max_ln", "dense_fwd",    "act_bwd",       "dense_wgrad",
                             "dense_dgrad",    "layernorm_bwd", "msg_wgrad_x6",   "msg_dgrad_x6", "node_grad_sums", "msg_dgrad_nodes",
-                            "node_update_bwd"};
+                            "node_update_bwd", "msg_gemm_h3", "msg_wgrad_h3", "msg_dgrad_h3", "pack_gq_h3"};
 constexpr int kProfKinds = sizeof(kProfNames) / sizeof(kProfNames[0]);
 
 hipEvent_t prof_event() {
@@ -149,8 +149,9 @@ WsInfer carve_infer(void* base, int N, int E, int Din, int Dm) {
 struct WsBwd {
   float* g_z;      // [N, Dout] fp32, or its bf16x3-packed form [N, 3 Dout] (same region)
   float* g_ln;     // [N, Dm]
-  uint16_t* gqp;   // [N, 3 Dm]
+  uint16_t* gqp;   // [N, 3 Dm] (bf16x3) or [N, 2 Dm] (f16x2)
   float* g_a;      // [E, 2 Din]; [E, Din] (source halves only) when the node sums are fused into the input gradient
+  float* amax;     // f16x3 message GEMMs: max |gq| of this layer, on the device
   size_t bytes;
 };
 WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool full_ga = true) {
@@ -162,8 +163,23 @@ WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool full_g
   w.g_ln = (float*)take((size_t)N * Dm * 4);
   w.gqp = (uint16_t*)take((size_t)N * 3 * Dm * 2);
   w.g_a = (float*)take((size_t)E * (full_ga ? 2 : 1) * Din * 4);
+  w.amax = (float*)take(256);
   w.bytes = o;
   return w;
+}
+
+// Message GEMMs (forward, weight gradient, routed input gradient) as f16x3 (csrc/bl_gemm_h3.hip: two fp16 planes per operand,
+// three MFMA terms) instead of bf16x6.  The operands of the forward GEMM and the weight gradient's left operand are layer inputs
+// and weights -- bounded tensors, fixed power-of-two scales BL_H3_ROW_SCALE / BL_H3_W_SCALE; the routed gradient operand gq has
+// no bound known in advance: its amax is taken on the device and the scale derived from it there (no host round trip).  The
+// dense node update stays on bf16x6 (its operands g_z / LayerNorm outputs are produced packed by fused kernels).
+int g_msg_h3 = -1;
+bool msg_h3() {
+  if (g_msg_h3 < 0) {
+    const char* e = getenv("BL_MSG_GEMM");
+    g_msg_h3 = (e && (e[0] == 'x' || e[0] == 'b')) ? 0 : 1;  // "x6" / "bf16x6" -> 0; default f16x3
+  }
+  return g_msg_h3 == 1;
 }
 
 bool g_fused_node_bwd = true;  // bl_set_fused_node_bwd: act backward -> dense input gradient -> LayerNorm backward in one kernel
@@ -218,10 +234,18 @@ extern "C" int64_t bl_mp_layer_workspace_bytes(int32_t N, int32_t E, int32_t Din
 // Which image of the per-type weights a layer call expects: 1 = bl_pack_weights_x6w (the wide row GEMM takes this shape:
 // message GEMM N = Dm, K = 2 Din; input-gradient GEMM N = 2 Din, K = Dm), 0 = bl_pack_weights_x6.
 extern "C" int32_t bl_mp_layer_weight_image(int32_t Din, int32_t Dm, int32_t for_backward) {
+  if (msg_h3()) return 2;  // bl_pack_weights_h3 (kinds 5 / 6 of bl_pack_weights_multi)
   return for_backward ? bl_gemm_rows_x6w_ok(2 * Din, Dm) : bl_gemm_rows_x6w_ok(Dm, 2 * Din);
 }
+extern "C" int32_t bl_set_msg_gemm_mode(int32_t f16x3) {
+  const int32_t prev = msg_h3() ? 1 : 0;
+  g_msg_h3 = f16x3 ? 1 : 0;
+  return prev;
+}
+extern "C" int32_t bl_get_msg_gemm_mode(void) { return msg_h3() ? 1 : 0; }
 
 extern "C" int64_t bl_mp_layer_packed_weight_elems(int32_t T, int32_t Din, int32_t Dm, int32_t for_backward) {
+  if (msg_h3()) return for_backward ? bl_packed_weight_elems_h3(T, Dm, 2 * Din) : bl_packed_weight_elems_h3(T, 2 * Din, Dm);
   if (bl_mp_layer_weight_image(Din, Dm, for_backward))
     return for_backward ? bl_packed_weight_elems_x6w(T, Dm, 2 * Din) : bl_packed_weight_elems_x6w(T, 2 * Din, Dm);
   return (int64_t)(for_backward ? packed_w_elems(T, Dm, 2 * Din) : packed_w_elems(T, 2 * Din, Dm));
@@ -257,7 +281,12 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
     S.ln_out = I.ln_out;
     S.dact = nullptr; S.bits = nullptr; S.agg = nullptr; S.mean = nullptr; S.rstd = nullptr;
   }
-  {
+  const bool h3 = msg_h3();
+  if (h3) {
+    ProfScope ps(0, 0.0, st, false);
+    BL_TRY(bl_pack_f16x2(h_lo, ld_lo, N, h_hi ? width_lo : Din, Din, 0, BL_H3_ROW_SCALE, nullptr, S.hp, st));
+    if (h_hi) BL_TRY(bl_pack_f16x2(h_hi, ld_hi, N, Din - width_lo, Din, width_lo, BL_H3_ROW_SCALE, nullptr, S.hp, st));
+  } else {
     ProfScope ps(0, 0.0, st, false);
     if (h_hi == nullptr) {
       BL_TRY(bl_pack_bf16x3(h_lo, ld_lo, N, Din, S.hp, st));
@@ -271,7 +300,11 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
   a.idx[0] = L->msg_src; a.idx[1] = L->msg_tgt; a.idx[2] = nullptr;
   a.width[0] = Din; a.width[1] = Din; a.width[2] = 0;
   a.nsrc = 2;
-  {
+  if (h3) {
+    ProfScope ps(13, 2.0 * E * (2.0 * Din) * Dm, st, false);
+    BL_TRY(bl_gemm_rows_h3(&a, nullptr, 0, w_packed, bl_packed_weight_elems_h3(1, 2 * Din, Dm), L->type_ptr, nullptr, T, E, Dm, 2 * Din,
+                           1.0f / (BL_H3_ROW_SCALE * BL_H3_W_SCALE), nullptr, pre, Dm, st));
+  } else {
     ProfScope ps(1, 2.0 * E * (2.0 * Din) * Dm, st, false);
     if (bl_mp_layer_weight_image(Din, Dm, 0))  // >= 256 output columns: the wide (128 x 256 tile, LDS-DMA) form, bit-identical
       BL_TRY(bl_gemm_rows_x6w(&a, nullptr, 0, w_packed, bl_packed_weight_elems_x6w(1, 2 * Din, Dm), L->type_ptr, nullptr, T, E, Dm,
@@ -335,10 +368,14 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   BL_CHECK_ARG(dense_x6 || L->Wd_packed == nullptr, "bl_mp_layer_bwd: Wd_packed given without Wd_packed_bwd");
   // act backward -> dense input gradient -> LayerNorm backward x activation derivative in ONE kernel (csrc/bl_node_bwd.hip)
   const bool fused_node = dense_x6 && g_fused_node_bwd && bl_node_update_bwd_ok(Dm, Dout);
+  // f16x3 message GEMMs: gq leaves its producer in fp32 (B.g_ln); its packed form is made below, once its amax is known
+  const bool h3 = msg_h3();
+  if (h3 && E > 0 && hipMemsetAsync(B.amax, 0, 4, st) != hipSuccess) { bl_set_error("bl_mp_layer_bwd: memset failed"); return BL_EINVAL; }
   if (fused_node) {
     ProfScope ps(12, 2.0 * N * (double)Dm * Dout, st, false);
-    BL_TRY(bl_node_update_bwd(g_out, h_out, N, Dout, L->drop, L->Wd_packed_bwd, S.agg, S.mean, S.rstd, L->ln_g, S.dact, Dm,
-                              (uint16_t*)B.g_z, g_bd, vec_dgrad ? B.g_ln : nullptr, B.gqp, g_ln_g, g_ln_b, st));
+    BL_TRY(bl_node_update_bwd_impl(g_out, h_out, N, Dout, L->drop, L->Wd_packed_bwd, S.agg, S.mean, S.rstd, L->ln_g, S.dact, Dm,
+                                   (uint16_t*)B.g_z, g_bd, (vec_dgrad || h3) ? B.g_ln : nullptr, h3 ? nullptr : B.gqp, g_ln_g, g_ln_b,
+                                   (h3 && E > 0) ? B.amax : nullptr, st));
   } else {  // y = drop(tanh(z)): g_z (packed for the bf16x6 GEMMs), bias gradient
     ProfScope ps(4, 0.0, st, false);
     BL_TRY(bl_act_bwd_impl(g_out, h_out, N, Dout, Dout, BL_ACT_TANH, L->drop, dense_x6 ? nullptr : B.g_z, g_bd,
@@ -379,7 +416,13 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   if (!fused_node) {  // LayerNorm backward x activation derivative at the winners -> packed d loss / d (winning pre-activation)
     ProfScope ps(7, 0.0, st, two);
     // (the fp32 form of the result, for the vector input gradient, overwrites g_ln in place: the kernel is row-local)
-    BL_TRY(bl_layernorm_bwd(B.g_ln, S.agg, S.mean, S.rstd, L->ln_g, N, Dm, vec_dgrad ? B.g_ln : nullptr, g_ln_g, g_ln_b, S.dact, B.gqp, st));
+    BL_TRY(bl_layernorm_bwd(B.g_ln, S.agg, S.mean, S.rstd, L->ln_g, N, Dm, (vec_dgrad || h3) ? B.g_ln : nullptr, g_ln_g, g_ln_b, S.dact,
+                            h3 ? nullptr : B.gqp, st));
+  }
+  if (h3 && E > 0) {  // amax of gq on the device -> its power-of-two scale -> two fp16 planes
+    ProfScope ps(16, 0.0, st, two);
+    if (!fused_node) BL_TRY(bl_amax(B.g_ln, (int64_t)N * Dm, B.amax, st));  // (the fused node-update backward took it on the way)
+    BL_TRY(bl_pack_f16x2(B.g_ln, Dm, N, Dm, Dm, 0, 1.0f, B.amax, B.gqp, st));
   }
   if (E > 0) {
     bl_rows_packed_t a;
@@ -391,7 +434,11 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
       (void)hipEventRecord(ev->fork2, st);
       (void)hipStreamWaitEvent(side, ev->fork2, 0);
     }
-    {
+    if (h3) {
+      ProfScope ps(14, 2.0 * E * (2.0 * Din) * Dm, side, two);
+      BL_TRY(bl_gemm_wgrad_h3(&a, B.gqp, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, nullptr, T, E, Dm, 2 * Din, 1.0f / BL_H3_ROW_SCALE, B.amax,
+                              g_W, (int64_t)2 * Din * Dm, Dm, side));
+    } else {
       ProfScope ps(8, 2.0 * E * (2.0 * Din) * Dm, side, two);
       BL_TRY(bl_gemm_wgrad_routed_x6(&a, B.gqp, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, nullptr, T, E, Dm, 2 * Din, g_W,
                                      (int64_t)2 * Din * Dm, Dm, side));
@@ -420,6 +467,10 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
     } else if (vec_dgrad) {
       ProfScope ps(9, 2.0 * N * (2.0 * Din) * Dm, st, two);
       BL_TRY(bl_routed_dgrad_vec(B.g_ln, Dm, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, 2 * Din, B.g_a, 2 * Din, st));
+    } else if (h3) {
+      ProfScope ps(15, 2.0 * E * (2.0 * Din) * Dm, st, two);
+      BL_TRY(bl_gemm_rows_h3(&g, S.bits, Dm / 32, w_packed_bwd, bl_packed_weight_elems_h3(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E, 2 * Din,
+                             Dm, 1.0f / BL_H3_W_SCALE, B.amax, B.g_a, 2 * Din, st));
     } else {
       ProfScope ps(9, 2.0 * E * (2.0 * Din) * Dm, st, two);
       if (bl_mp_layer_weight_image(Din, Dm, 1))

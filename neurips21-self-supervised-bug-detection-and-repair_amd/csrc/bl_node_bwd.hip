@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
     uint4* __restrict__ gz_packed, float* __restrict__ g_bias, const uint4* __restrict__ bp, const float* __restrict__ agg,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
     const float* __restrict__ dact, float* __restrict__ gq_f32, uint32_t* __restrict__ gq_packed, float* __restrict__ g_gamma,
-    float* __restrict__ g_beta, int ntiles) {
+    float* __restrict__ g_beta, int ntiles, float* __restrict__ gq_amax) {
   constexpr int Dm = 128 * NT;
   constexpr int FR = 2 * NT;  // accumulator fragments (32 x 32) per wave
   // operand images of a stage (As: 64 rows, Bs: Dm rows); after the last stage the same memory holds the four waves' result
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
   for (int i = tid; i < Dm; i += 256) gamma_s[i] = gamma[i];
   __syncthreads();
 
+  float amx = 0.f;  // max |gq| over what this thread writes (gq_amax: the f16x3 message GEMMs scale gq by it)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * NB_ROWS;
     const int tr = min(NB_ROWS, nrows - row0);  // rows of this tile
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
         const float4 v = *reinterpret_cast<const float4*>(stage + r * ST_LD + 4 * c4);
         const size_t gr = (size_t)(row0 + wm * 32 + r);
         if (gq_f32) *reinterpret_cast<float4*>(gq_f32 + gr * Dm + col) = v;
+        amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         if (gq_packed) {
           const float gx[4] = {v.x, v.y, v.z, v.w};
           uint16_t h[4], mm[4], l[4];
@@ -329,6 +331,16 @@ __global__ __launch_bounds__(256, 2) void node_bwd_kernel(
   }
   if (g_bias)
     for (int c = tid; c < K; c += 256) unsafeAtomicAdd(&g_bias[c], bias_s[c]);
+  if (gq_amax) {  // one atomic per workgroup (non-negative floats order like their bit patterns; a NaN is not recorded)
+    amx = bl_wave_max(amx);
+    __syncthreads();
+    if (lane == 0) rowpart[0][wave][0] = amx;
+    __syncthreads();
+    if (tid == 0) {
+      const float m = fmaxf(fmaxf(rowpart[0][0][0], rowpart[0][1][0]), fmaxf(rowpart[0][2][0], rowpart[0][3][0]));
+      if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(gq_amax), __float_as_uint(m));
+    }
+  }
 }
 
 int g_node_bwd_resident[3] = {0, 0, 0};
@@ -336,7 +348,7 @@ int g_node_bwd_resident[3] = {0, 0, 0};
 template <int NT>
 int node_bwd_launch(const float* g_out, const float* h_out, int nrows, int K, bl_drop_dev drop, uint16_t* gz_packed, float* g_bias,
                     const uint16_t* wd_packed_bwd, const float* agg, const float* mean, const float* rstd, const float* gamma,
-                    const float* dact, float* gq_f32, uint16_t* gq_packed, float* g_gamma, float* g_beta, hipStream_t st) {
+                    const float* dact, float* gq_f32, uint16_t* gq_packed, float* g_gamma, float* g_beta, float* gq_amax, hipStream_t st) {
   int& resident = g_node_bwd_resident[NT];
   if (resident == 0) {
     int per_cu = 0;
@@ -348,7 +360,7 @@ int node_bwd_launch(const float* g_out, const float* h_out, int nrows, int K, bl
   const int grid = ntiles < resident ? ntiles : resident;
   hipLaunchKernelGGL((node_bwd_kernel<NT>), dim3(grid), dim3(256), 0, st, g_out, h_out, nrows, K, drop,
                      reinterpret_cast<uint4*>(gz_packed), g_bias, reinterpret_cast<const uint4*>(wd_packed_bwd), agg, mean, rstd, gamma,
-                     dact, gq_f32, reinterpret_cast<uint32_t*>(gq_packed), g_gamma, g_beta, ntiles);
+                     dact, gq_f32, reinterpret_cast<uint32_t*>(gq_packed), g_gamma, g_beta, ntiles, gq_amax);
   return BL_OK;
 }
 }  // namespace
@@ -361,6 +373,15 @@ extern "C" int bl_node_update_bwd(const float* g_out, const float* h_out, int32_
                                   const uint16_t* wd_packed_bwd, const float* agg, const float* mean, const float* rstd,
                                   const float* ln_g, const float* dact, int32_t Dm, uint16_t* g_z_packed, float* g_bias,
                                   float* gq, uint16_t* gq_packed, float* g_ln_g, float* g_ln_b, void* stream) {
+  return bl_node_update_bwd_impl(g_out, h_out, nrows, Dout, drop, wd_packed_bwd, agg, mean, rstd, ln_g, dact, Dm, g_z_packed, g_bias, gq,
+                                 gq_packed, g_ln_g, g_ln_b, nullptr, stream);
+}
+
+// + gq_amax (optional, device float, zeroed by the caller): max |gq| is added to it with one atomic max per workgroup
+int bl_node_update_bwd_impl(const float* g_out, const float* h_out, int32_t nrows, int32_t Dout, bl_dropout_t drop,
+                            const uint16_t* wd_packed_bwd, const float* agg, const float* mean, const float* rstd, const float* ln_g,
+                            const float* dact, int32_t Dm, uint16_t* g_z_packed, float* g_bias, float* gq, uint16_t* gq_packed,
+                            float* g_ln_g, float* g_ln_b, float* gq_amax, void* stream) {
   if (nrows == 0) return BL_OK;
   BL_CHECK_ARG(g_out && h_out && wd_packed_bwd && agg && mean && rstd && ln_g && g_z_packed && (gq || gq_packed) && g_ln_g && g_ln_b,
                "bl_node_update_bwd: null pointer");
@@ -375,10 +396,10 @@ extern "C" int bl_node_update_bwd(const float* g_out, const float* h_out, int32_
   int rc;
   if (Dm == 128)
     rc = node_bwd_launch<1>(g_out, h_out, nrows, Dout, d, g_z_packed, g_bias, wd_packed_bwd, agg, mean, rstd, ln_g, dact, gq, gq_packed,
-                            g_ln_g, g_ln_b, st);
+                            g_ln_g, g_ln_b, gq_amax, st);
   else
     rc = node_bwd_launch<2>(g_out, h_out, nrows, Dout, d, g_z_packed, g_bias, wd_packed_bwd, agg, mean, rstd, ln_g, dact, gq, gq_packed,
-                            g_ln_g, g_ln_b, st);
+                            g_ln_g, g_ln_b, gq_amax, st);
   BL_LAUNCH_CHECK("bl_node_update_bwd");
   return rc;
 }

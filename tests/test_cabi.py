@@ -85,6 +85,19 @@ def test_layer_weight_image_rule_is_a_pure_function_of_the_shape(built_lib):
     from buglab.models import hip_ops
 
     lib = hip_ops.load_library()
+    # the message GEMMs' operand split decides first: f16x3 (the default) has one image for every shape
+    was = hip_ops.set_msg_gemm_mode("f16x3")
+    try:
+        assert [lib.bl_mp_layer_weight_image(a, b, d) for a, b in ((128, 128), (256, 256), (96, 160)) for d in (0, 1)] == [2] * 6
+        assert lib.bl_mp_layer_packed_weight_elems(16, 128, 128, 0) == lib.bl_packed_weight_elems_h3(16, 256, 128) == 16 * (256 // 32) * 8192
+        assert lib.bl_mp_layer_packed_weight_elems(16, 256, 256, 1) == lib.bl_packed_weight_elems_h3(16, 256, 512)
+        assert hip_ops.msg_gemm_mode() == "f16x3" and hip_ops.set_msg_gemm_mode("bf16x6") == "f16x3"
+        _check_bf16x6_image_rule(lib, hip_ops)
+    finally:
+        hip_ops.set_msg_gemm_mode(was)
+
+
+def _check_bf16x6_image_rule(lib, hip_ops):
     assert lib.bl_set_rows_tile(256) in (128, 256)
     # (Din, Dm): forward GEMM N = Dm, K = 2 Din; input-gradient GEMM N = 2 Din, K = Dm
     assert [lib.bl_mp_layer_weight_image(128, 128, d) for d in (0, 1)] == [0, 0]   # hidden-128 plain layer: Dm = 128 / K = 128

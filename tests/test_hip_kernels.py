@@ -380,6 +380,109 @@ def test_gemm_rows_bf16x6_is_fp32_accurate(ops, Din, Dm, sizes):
     assert err < 2e-5 and err < 4 * err32 + 1e-6, (float(err), float(err32))
 
 
+def _unpack_f16x2(p, D):
+    """fp64 value of a bl_pack_f16x2 row-packed int16 tensor [R, 2 D]: hi + lo"""
+    h = torch.from_numpy(p.cpu().numpy().view(np.float16).astype(np.float64)).view(p.shape[0], 2, D)
+    return h.sum(1)
+
+
+@pytest.mark.parametrize("Din,Dm,sizes", [(64, 96, [130, 0, 1, 257, 64]), (32, 128, [5, 300]), (128, 256, [129, 128, 127]), (128, 128, [3000, 1, 900])])
+def test_gemm_rows_f16x3_is_fp32_accurate(ops, Din, Dm, sizes):
+    """fp32-accurate GEMM on the fp16 matrix cores (csrc/bl_gemm_h3.hip): two fp16 planes per operand with a power-of-two tensor
+    scale, three MFMA terms.  The packing reproduces the fp32 values to 2^-24 (relative, where both planes are normal) or
+    2^-25 / scale (absolute); the product's error against fp64 is in the class of the exact-fp32 MFMA kernel's."""
+    rng = np.random.default_rng(0)
+    N, T, E = 211, len(sizes), int(sum(sizes))
+    h = torch.tanh(torch.randn(N, Din)) * 1.25  # a layer input: tanh x dropout scale
+    h[0, :5] = torch.tensor([0.0, 1e-9, -3e-5, 1.25, -1.25])
+    W = torch.randn(T, 2 * Din, Dm) / math.sqrt(2 * Din)
+    src, tgt = rng.integers(0, N, E).astype(np.int32), rng.integers(0, N, E).astype(np.int32)
+    ptr = _groups(rng, sizes)
+    ref = torch.zeros(E, Dm, dtype=torch.float64)
+    for t in range(T):
+        lo, hi = ptr[t], ptr[t + 1]
+        ref[lo:hi] = torch.cat([h[src[lo:hi]], h[tgt[lo:hi]]], -1).double() @ W[t].double()
+    hp = ops.pack_f16x2(_dev(h), ops.H3_ROW_SCALE)
+    recon = _unpack_f16x2(hp, Din) / ops.H3_ROW_SCALE
+    tol = torch.maximum(h.double().abs() * 2.0 ** -23, torch.full_like(h.double(), 2.0 ** -25 / ops.H3_ROW_SCALE))
+    assert ((recon - h.double()).abs() <= tol).all()
+    out = ops.gemm_rows_h3([(hp, _dev(src), Din), (hp, _dev(tgt), Din)], ops.pack_weights_h3(_dev(W), True), E, Dm,
+                           out_scale=1.0 / (ops.H3_ROW_SCALE * ops.H3_W_SCALE), group_ptr=_dev(ptr), G=T)
+    err = (out.cpu().double() - ref).abs().max()
+    exact = ops.gemm_rows([(_dev(h), _dev(src)), (_dev(h), _dev(tgt))], _dev(W), E, Dm, b_group_stride=2 * Din * Dm, ldb=Dm, group_ptr=_dev(ptr), G=T)
+    err32 = (exact.cpu().double() - ref).abs().max()
+    x6 = ops.gemm_rows_x6([(ops.pack_bf16x3(_dev(h)), _dev(src), Din), (ops.pack_bf16x3(_dev(h)), _dev(tgt), Din)],
+                          ops.pack_weights_x6(_dev(W), True), E, Dm, group_ptr=_dev(ptr), G=T)
+    err6 = (x6.cpu().double() - ref).abs().max()
+    print(f"f16x3 {float(err):.2e}  bf16x6 {float(err6):.2e}  exact fp32 MFMA {float(err32):.2e}")
+    assert err < 2e-5 and err < 4 * err32 + 1e-6, (float(err), float(err32))
+    # saturation instead of inf, NaN propagation
+    wild = torch.tensor([[1e30, -1e30, float("nan"), 3.0e2] + [0.0] * (Din - 4)])
+    wp = _unpack_f16x2(ops.pack_f16x2(_dev(wild), ops.H3_ROW_SCALE), Din)[0]
+    assert wp[0] == 65504.0 and wp[1] == -65504.0 and torch.isnan(wp[2]) and wp[3] == 65504.0  # (300 x 256 > 65504: saturated)
+
+
+@pytest.mark.parametrize("Din,Dm,sizes", [(32, 64, [130, 0, 1, 700, 64]), (128, 128, [2100, 5, 300]), (64, 256, [129, 128, 1500]),
+                                           (256, 256, [700, 33, 0, 1]), (128, 96, [31, 2000])])
+def test_routed_gemms_f16x3_match_fp64(ops, Din, Dm, sizes):
+    """f16x3 input-gradient and weight-gradient GEMMs of the max-aggregated messages: the gradient operand is packed with a scale
+    derived ON THE DEVICE from its amax (its magnitude -- here ~1e-6 -- is not known in advance), the consumers divide it out."""
+    rng = np.random.default_rng(1)
+    N, T, E = 97, len(sizes), int(sum(sizes))
+    h = torch.tanh(torch.randn(N, Din)) * 1.25
+    W = torch.randn(T, 2 * Din, Dm) / math.sqrt(2 * Din)
+    gq = torch.randn(N, Dm) * torch.exp(torch.randn(N, 1) * 2.0) * 1e-6  # tiny, heavy-tailed over the rows
+    src, tgt = rng.integers(0, N, E).astype(np.int32), rng.integers(0, N, E).astype(np.int32)
+    ptr = _groups(rng, sizes)
+    arg = np.full((N, Dm), -1, dtype=np.int32)
+    for n in range(N):
+        inc = np.nonzero(tgt == n)[0]
+        if len(inc):
+            arg[n] = rng.choice(inc, Dm)
+    e_ids = torch.arange(E)[:, None]
+    Gm = torch.where(torch.from_numpy(arg)[tgt.astype(np.int64)].long() == e_ids, gq[tgt.astype(np.int64)].double(), torch.zeros(E, Dm, dtype=torch.float64))
+    A = torch.cat([h[src.astype(np.int64)], h[tgt.astype(np.int64)]], -1).double()
+    ref_dW = torch.zeros(T, 2 * Din, Dm, dtype=torch.float64)
+    ref_dA = torch.zeros(E, 2 * Din, dtype=torch.float64)
+    for t in range(T):
+        lo, hi = ptr[t], ptr[t + 1]
+        ref_dW[t] = A[lo:hi].T @ Gm[lo:hi]
+        ref_dA[lo:hi] = Gm[lo:hi] @ W[t].double().T
+    d_gq = _dev(gq)
+    am = ops.amax(d_gq)
+    assert float(am) == float(gq.abs().max())
+    hp, gqp = ops.pack_f16x2(_dev(h), ops.H3_ROW_SCALE), ops.pack_f16x2(d_gq, 1.0, amax=am)
+    # the device-derived scale put the largest entry into [2^13, 2^14]
+    top = float(_unpack_f16x2(gqp, Dm).abs().max())
+    assert 2.0 ** 13 <= top <= 2.0 ** 14
+    d_src, d_tgt, d_ptr = _dev(src), _dev(tgt), _dev(ptr)
+    won = (arg[tgt] == np.arange(E)[:, None])
+    bits = np.packbits(won.reshape(E, Dm // 32, 32), axis=-1, bitorder="little").view(np.uint32).reshape(E, Dm // 32)
+    d_bits = _dev(bits.view(np.int32))
+    gw = torch.zeros(T, 2 * Din, Dm, device="cuda")
+    ops.gemm_wgrad_h3([(hp, d_src, Din), (hp, d_tgt, Din)], gqp, E, Dm, gw, out_scale=1.0 / ops.H3_ROW_SCALE, g_idx=d_tgt, win_bits=d_bits,
+                      g_amax=am, gw_group_stride=2 * Din * Dm, group_ptr=d_ptr, G=T)
+    gw6 = torch.zeros_like(gw)
+    ops.gemm_wgrad_routed_x6([(ops.pack_bf16x3(_dev(h)), d_src, Din), (ops.pack_bf16x3(_dev(h)), d_tgt, Din)], ops.pack_bf16x3(d_gq), d_tgt, d_bits,
+                             E, Dm, gw6, gw_group_stride=2 * Din * Dm, group_ptr=d_ptr, G=T)
+    scale = float(ref_dW.abs().max())
+    err, err6 = float((gw.cpu().double() - ref_dW).abs().max()), float((gw6.cpu().double() - ref_dW).abs().max())
+    print(f"wgrad: f16x3 {err / scale:.2e}  bf16x6 {err6 / scale:.2e} (relative to the largest entry {scale:.2e})")
+    assert err < 4e-6 * scale, (err, err6, scale)
+    dA = ops.gemm_rows_h3([(gqp, d_tgt, Dm)], ops.pack_weights_h3(_dev(W), False), E, 2 * Din, out_scale=1.0 / ops.H3_W_SCALE, a_amax=am,
+                          group_ptr=d_ptr, G=T, win_bits=d_bits)
+    sA = float(ref_dA.abs().max())
+    assert float((dA.cpu().double() - ref_dA).abs().max()) < 4e-6 * sA, (float((dA.cpu().double() - ref_dA).abs().max()), sA)
+    # unrouted weight gradient (plain rows): the dense form
+    g2 = torch.randn(E, Dm) * 1e-3
+    am2 = ops.amax(_dev(g2))
+    gw2 = torch.zeros(T, 2 * Din, Dm, device="cuda")
+    ops.gemm_wgrad_h3([(hp, d_src, Din), (hp, d_tgt, Din)], ops.pack_f16x2(_dev(g2), 1.0, amax=am2), E, Dm, gw2, out_scale=1.0 / ops.H3_ROW_SCALE,
+                      g_amax=am2, gw_group_stride=2 * Din * Dm, group_ptr=d_ptr, G=T)
+    ref2 = torch.stack([A[ptr[t]:ptr[t + 1]].T @ g2[ptr[t]:ptr[t + 1]].double() for t in range(T)])
+    assert float((gw2.cpu().double() - ref2).abs().max()) < 4e-6 * float(ref2.abs().max())
+
+
 @pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 256, 64), (130, 64, 96), (2500, 256, 160)])
 def test_dense_bf16x6_gemms_match_fp64(ops, M, K, N):
     """The dense node update on the bf16 matrix cores: bl_gemm_rows_x6_epi (bias + tanh + counter-hash dropout epilogue, the
@@ -640,9 +743,14 @@ def test_fused_layer_call_equals_kernel_by_kernel_path(placement):
     torch.manual_seed(0)
     module = build_gnn_mlp_module(64, 8, 6, vocabulary_size=500, dropout_rate=0.1, message_activation_placement=placement).cuda().train()
     res = {}
-    for fused in (True, False):
-        hip_ops.FUSED_LAYER = fused
+    # (the kernel-by-kernel path runs its message GEMMs as bf16x6: the fused call is put on the same split, so that "same kernels,
+    # same order" holds bit for bit; the default f16x3 split of the fused call is compared with it at the end)
+    prev_split = hip_ops.set_msg_gemm_mode("bf16x6")
+    for fused in (True, False, "f16x3"):
+        hip_ops.FUSED_LAYER = bool(fused)
         hip_ops.DENSE_X6 = False  # the kernel-by-kernel path runs the dense node update on the exact-fp32 GEMMs
+        if fused == "f16x3":
+            hip_ops.set_msg_gemm_mode("f16x3")
         try:
             module.zero_grad(set_to_none=True)
             loss = module(**mb, dropout_seed=11)
@@ -653,10 +761,17 @@ def test_fused_layer_call_equals_kernel_by_kernel_path(placement):
         finally:
             hip_ops.FUSED_LAYER = True
             hip_ops.DENSE_X6 = True
+            if fused == "f16x3":
+                hip_ops.set_msg_gemm_mode(prev_split)
     assert res[True][0] == res[False][0]  # same kernels, same order: bit-identical forward
     for k, g in res[True][1].items():
         ref = res[False][1][k]
         assert float((g - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-7, k  # atomics reorder sums
+    # the f16x3 split: another fp32-accurate evaluation of the same products (a near-tie of the routed max may flip: 1e-3)
+    assert abs(res["f16x3"][0] - res[False][0]) < 1e-5
+    for k, g in res["f16x3"][1].items():
+        ref = res[False][1][k]
+        assert float((g - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-7, k
 
 
 def _unpack_bf16x3(p, D):

@@ -82,10 +82,33 @@ def test_forward_backward_matches_oracle_small(placement):
     assert abs(m["Localization Accuracy"] - out["loc_stats"]["num_correct"] / 4) < 1e-9
 
 
+@pytest.fixture
+def bf16x6_message_gemms():
+    """the message GEMMs of the fused layer calls on the bf16x6 split (three bf16 planes, six MFMA terms) instead of the default
+    f16x3 one for the duration of a test"""
+    from buglab.models import hip_ops
+
+    prev = hip_ops.set_msg_gemm_mode("bf16x6")
+    yield
+    hip_ops.set_msg_gemm_mode(prev)
+
+
 @pytest.mark.parametrize("placement", PLACEMENTS)
 def test_forward_backward_matches_oracle_8_layers_h128(placement):
     cfg, _, mb = Hh.make_case(B=3, n=150, E=800, T=16, H=128, layers=8, C=10, seed=3, msg_act_placement=placement)
     _check_against_oracle(cfg, mb)
+
+
+def test_bf16x6_message_gemms_still_match_the_oracle(bf16x6_message_gemms):
+    """The default split of the message GEMMs is f16x3 since round 6 (every other test of this file runs it); the bf16x6 kernels
+    (128 x 128 and wide tiles) stay selectable and keep their parity: hidden 128 with dropout, and the c3 / c4 widths."""
+    from buglab.models import hip_ops
+
+    assert hip_ops.msg_gemm_mode() == "bf16x6"
+    cfg, _, mb = Hh.make_case(B=3, n=150, E=800, T=16, H=128, layers=8, C=10, seed=3, dropout=0.2)
+    _check_tie_aware(cfg, mb, seed=11)
+    cfg, _, mb = Hh.make_case(B=2, n=300, E=1500, T=16, H=256, layers=8, C=10, seed=11)
+    _check_tie_aware(cfg, mb)
 
 
 @pytest.mark.parametrize("placement", PLACEMENTS)

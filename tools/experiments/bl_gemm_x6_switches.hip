@@ -36,6 +36,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef X6_PLANES
+#define X6_PLANES 3  // 2 (timing proxy only, results WRONG): what a two-plane (fp16 hi + lo) operand split with three MFMA terms would cost
+#endif
 #define XBM 128
 #define XBN 128
 // LDS row of a stage image: [plane (3)][k-group slot (4)] x 16 B, in one of two layouts:
@@ -220,12 +223,12 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
       const uint4* src_ = base_ + (size_t)gr_ * 3 * (wj_ >> 3) + (kl_ >> 3);                                  \
       ra[i][0] = src_[0];                                                                                     \
       ra[i][1] = src_[wj_ >> 3];                                                                              \
-      ra[i][2] = src_[2 * (wj_ >> 3)];                                                                        \
+      if (X6_PLANES > 2) ra[i][2] = src_[2 * (wj_ >> 3)];                                                     \
       if (MASKED) ma[i] = win_bits[(size_t)(row0 + min(row_, nrows - 1)) * ld_bits + (kc_ >> 5)];              \
       const uint4* bsrc_ = Bt + (size_t)((k0_) >> 5) * 1536 + i * 768;                                        \
       rb[i][0] = bsrc_[0];                                                                                    \
       rb[i][1] = bsrc_[256];                                                                                  \
-      rb[i][2] = bsrc_[512];                                                                                  \
+      if (X6_PLANES > 2) rb[i][2] = bsrc_[512];                                                               \
     }                                                                                                         \
   }
 #define X6_STORE_STAGE(k0_)                                                                                   \
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
       if (MASKED) keep_ = keep_from_bits(ma[i] >> (8 * p_kg)); /* k0 is a multiple of 32 */                  \
       if (!kok_) keep_ = make_uint4(0u, 0u, 0u, 0u);                                                          \
       const bool nok_ = kok_ && (n0 + row_ < N);                                                              \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                         \
+      _Pragma("unroll") for (int p = 0; p < X6_PLANES; ++p) {                                                 \
         uint4 a_ = ra[i][p];                                                                                  \
         a_.x &= keep_.x; a_.y &= keep_.y; a_.z &= keep_.z; a_.w &= keep_.w;                                   \
         As[row_ * XROW + p * 4 + XSLOT(row_, p_kg)] = a_;                                                     \
@@ -270,14 +273,14 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
         const uint4* p = &As[(wm * 64 + ti * 32 + li) * XROW + XSLOT(li, kg)];
         ah[ti] = __builtin_bit_cast(bf16x8, p[0]);
         am[ti] = __builtin_bit_cast(bf16x8, p[4]);
-        al[ti] = __builtin_bit_cast(bf16x8, p[8]);
+        if (X6_PLANES > 2) al[ti] = __builtin_bit_cast(bf16x8, p[8]);
       }
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
         const uint4* p = &Bs[(wn * 64 + tj * 32 + li) * XROW + XSLOT(li, kg)];
         bh[tj] = __builtin_bit_cast(bf16x8, p[0]);
         bm[tj] = __builtin_bit_cast(bf16x8, p[4]);
-        bl[tj] = __builtin_bit_cast(bf16x8, p[8]);
+        if (X6_PLANES > 2) bl[tj] = __builtin_bit_cast(bf16x8, p[8]);
       }
       // swapped operands (B fragment in the A slot): the accumulator holds the transposed tile, so
       // a lane owns 4 consecutive columns of one row.  Small terms first.  The six terms of one accumulator are written back to
@@ -301,9 +304,11 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
         for (int tj = 0; tj < 2; ++tj) {
           f32x16 a = acc[ti][tj];
           if (X6_ABLATE & 2) { asm volatile("" ::"v"(bm[tj]), "v"(am[ti]), "v"(bl[tj]), "v"(ah[ti]), "v"(bh[tj]), "v"(al[ti])); continue; }
+          if (X6_PLANES > 2) {
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[tj], am[ti], a, 0, 0, 0);
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[tj], ah[ti], a, 0, 0, 0);
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], al[ti], a, 0, 0, 0);
+          }
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[tj], ah[ti], a, 0, 0, 0);
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], am[ti], a, 0, 0, 0);
           a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[tj], ah[ti], a, 0, 0, 0);
@@ -456,11 +461,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
       const uint4* a_ = abase + (size_t)arow[i] * 3 * awg;                                       \
       ra[i][0] = a_[0];                                                                          \
       ra[i][1] = a_[awg];                                                                        \
-      ra[i][2] = a_[2 * awg];                                                                    \
+      if (X6_PLANES > 2) ra[i][2] = a_[2 * awg];                                                 \
       const uint4* g_ = gbase + (size_t)grow[i] * 3 * gwg;                                       \
       rb[i][0] = g_[0];                                                                          \
       rb[i][1] = g_[gwg];                                                                        \
-      rb[i][2] = g_[2 * gwg];                                                                    \
+      if (X6_PLANES > 2) rb[i][2] = g_[2 * gwg];                                                 \
       mk[i] = ROUTED ? mbase[(size_t)mrow[i] * ld_bits] : 0u;                                    \
     }                                                                                            \
   }
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
       uint4 keep_ = ROUTED ? keep_from_bits(mk[i] >> mshift) : make_uint4(~0u, ~0u, ~0u, ~0u);   \
       if (!(eok_ && b_ok)) keep_ = make_uint4(0u, 0u, 0u, 0u);                                   \
       const int slot_ = (msg0 + 16 * i) * WRS + 8 * fg;                                          \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
+      _Pragma("unroll") for (int p = 0; p < X6_PLANES; ++p) {                                    \
         *reinterpret_cast<uint4*>(&As[p * WPLANE + slot_]) = (eok_ && a_ok) ? ra[i][p] : make_uint4(0u, 0u, 0u, 0u); \
         uint4 b_ = rb[i][p];                                                                     \
         b_.x &= keep_.x; b_.y &= keep_.y; b_.z &= keep_.z; b_.w &= keep_.w;                      \
@@ -513,14 +518,18 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_x6_kernel(
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < X6_PLANES; ++p) {
           af[t][p] = tr_frag(a_tr + p * WPLANE + s * 16 * WRS + t * 32);
           bf[t][p] = tr_frag(b_tr + p * WPLANE + s * 16 * WRS + t * 32);
         }
 #define WX6_TERM(pa_, pb_)                                                                            \
   _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)   \
       acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti][pa_], bf[tj][pb_], acc[ti][tj], 0, 0, 0);
+#if X6_PLANES > 2
       WX6_TERM(1, 1) WX6_TERM(2, 0) WX6_TERM(0, 2) WX6_TERM(1, 0) WX6_TERM(0, 1) WX6_TERM(0, 0)
+#else
+      WX6_TERM(1, 0) WX6_TERM(0, 1) WX6_TERM(0, 0)
+#endif
     }
     __syncthreads();
     if (kt + 1 < nk) {

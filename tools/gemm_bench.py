@@ -136,6 +136,18 @@ def main():
         same = torch.equal(fns["nk_x6w"](), fns["nk_x6"]())
         print(f"nk_x6w == nk_x6 bit for bit: {same}", flush=True)
         assert same
+    # f16x3 (csrc/bl_gemm_h3.hip): two fp16 planes per operand, three MFMA terms
+    hp16, wtp16, wp16 = ops.pack_f16x2(h, ops.H3_ROW_SCALE), ops.pack_weights_h3(W, True), ops.pack_weights_h3(W, False)
+    gq_am = ops.amax(gq)
+    gqp16 = ops.pack_f16x2(gq, 1.0, amax=gq_am)
+    gw16 = torch.zeros_like(W)
+    fns["fwd_h3"] = lambda: ops.gemm_rows_h3([(hp16, src, Din), (hp16, tgt, Din)], wtp16, E, Dm, out_scale=1.0 / (ops.H3_ROW_SCALE * ops.H3_W_SCALE),
+                                             group_ptr=ptr, G=T_groups, group_w=gw_t)
+    fns["nk_h3"] = lambda: ops.gemm_rows_h3([(gqp16, tgt, Dm)], wp16, E, 2 * Din, out_scale=1.0 / ops.H3_W_SCALE, a_amax=gq_am, group_ptr=ptr,
+                                            G=T_groups, group_w=gw_t, win_bits=bits_real)
+    fns["wgrad_h3"] = lambda: ops.gemm_wgrad_h3([(hp16, src, Din), (hp16, tgt, Din)], gqp16, E, Dm, gw16, out_scale=1.0 / ops.H3_ROW_SCALE, g_idx=tgt,
+                                                win_bits=bits_real, g_amax=gq_am, gw_group_stride=2 * Din * Dm, group_ptr=ptr, G=T_groups, group_w=gw_t)
+    fns["pack_h16"] = lambda: ops.pack_f16x2(h, ops.H3_ROW_SCALE)
     fns["pack_h"] = lambda: ops.pack_bf16x3(h)
     fns["pack_wt"] = lambda: ops.pack_weights_x6(W, True)
     names = [n for n in a.which.split(",") if n in fns or print(f"(skipping {n}: shape not supported)")] + [f"wgrad_x6_cap{cap}" for cap in caps]
