@@ -70,19 +70,23 @@ typedef struct {
  * M0  node embedder: out[n,:] = Dropout(max_{s < lens[n]} table[ids[n,s], :]), argsub = winning s.
  * Replaces ptgnn StrElementRepresentationModel (configured at buglab/models/modelregistry.py:59-82:
  * subtoken splitting, <= 6 subtokens, "max" combination).
- * bwd: g_table[ids[n, argsub[n,h]], h] += g_out[n,h] (masked by the same dropout), fp32 atomics. */
+ * bwd: g_table[ids[n, argsub[n,h]], h] += g_out[n,h] (masked by the same dropout), fp32 atomics.
+ * drop_before_pool: 0 (default spec) = dropout on the pooled rows, out = drop(max_s emb); 1 = dropout on the embedded subtokens
+ * before the pooling, out = max_s drop(emb)[n, s, :] with mask index (n S + s) H + h (the other placement ptgnn's
+ * SubtokenUnitEmbedder may have: DESIGN.md section 2); backward scales by the winner's mask bit. */
 int bl_embed_subtoken_max_fwd(const float* table, int32_t V, int32_t H, const int32_t* ids, const int32_t* lens,
-                              int32_t N, int32_t S, bl_dropout_t drop, float* out, int32_t ld_out, int8_t* argsub,
-                              void* stream);
+                              int32_t N, int32_t S, bl_dropout_t drop, int32_t drop_before_pool, float* out, int32_t ld_out,
+                              int8_t* argsub, void* stream);
 int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const int32_t* ids, const int8_t* argsub, int32_t N,
-                              int32_t S, int32_t H, int32_t V, bl_dropout_t drop, float* g_table, void* stream);
+                              int32_t S, int32_t H, int32_t V, bl_dropout_t drop, int32_t drop_before_pool, float* g_table,
+                              void* stream);
 /* The same gradient from a token-sorted occurrence list: occ[i] = n * S + s (every valid subtoken slot),
  * sorted by ids[n, s] and cut in chunks of one token each (chunk_ptr [nchunks + 1], chunk_tok [nchunks];
  * the collator uses <= 256 occurrences per chunk).  One atomic per (chunk, channel) instead of one per
  * (node, channel): subtoken frequencies are Zipfian and same-address atomics serialise. */
 int bl_embed_subtoken_max_bwd_sorted(const float* g_out, int32_t ld_g, const int32_t* occ, const int32_t* chunk_ptr,
                                      const int32_t* chunk_tok, int32_t nchunks, const int8_t* argsub, int32_t S,
-                                     int32_t H, bl_dropout_t drop, float* g_table, void* stream);
+                                     int32_t H, bl_dropout_t drop, int32_t drop_before_pool, float* g_table, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Grouped, gathered fp32 GEMM on MFMA (v_mfma_f32_32x32x2_f32, exact fp32).

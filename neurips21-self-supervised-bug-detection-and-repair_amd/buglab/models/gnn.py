@@ -307,7 +307,8 @@ def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_
                          buggy_samples_weight: float = 1.0, dropout_base_seed: int = 0, model: str = "gnn-mlp",
                          edge_feature_size: int = 0, edge_vocabulary_size: int = 0,
                          embedder_dropout_rate: Optional[float] = None,
-                         message_activation_placement: str = "aggregated") -> GnnBugLabModule:
+                         message_activation_placement: str = "aggregated",
+                         embedder_dropout_placement: str = "after_pooling") -> GnnBugLabModule:
     """Device module for given hyper-parameters without a metadata pass (bench / tests / synthetic
     runs).  `GnnBugLabModel.build_neural_module()` goes through the same constructors.
     `embedder_dropout_rate`: dropout of the node embedder; None = `dropout_rate` (the oracle's single-rate
@@ -319,7 +320,7 @@ def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_
     from buglab.models.layers.messagepassing import SubtokenEmbedder, TokenEmbedder
 
     embed = SubtokenEmbedder(vocabulary_size, hidden_state_size, max_num_subtokens,
-                             dropout_rate if embedder_dropout_rate is None else embedder_dropout_rate)
+                             dropout_rate if embedder_dropout_rate is None else embedder_dropout_rate, embedder_dropout_placement)
     edge_embed = TokenEmbedder(edge_vocabulary_size, edge_feature_size) if edge_feature_size > 0 else None
     if model == "ggnn":
         assert edge_embed is None

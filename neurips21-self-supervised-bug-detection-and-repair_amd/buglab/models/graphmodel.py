@@ -23,7 +23,7 @@ from buglab.runtime.vocabulary import Vocabulary, split_identifier_into_parts
 class StrElementRepresentationModel:
     def __init__(self, *, token_splitting: str = "subtoken", embedding_size: int = 128, vocabulary_size: int = 15000,
                  max_num_subtokens: int = 6, subtoken_combination: str = "max", dropout_rate: float = 0.0,
-                 min_freq_threshold: int = 5):
+                 min_freq_threshold: int = 5, dropout_placement: str = "after_pooling"):
         if token_splitting not in ("subtoken", "token") or (token_splitting == "subtoken" and subtoken_combination != "max"):
             raise NotImplementedError("the HIP embedders implement subtoken / max (the node model, modelregistry.py:61-67) and "
                                       "token (the edge-feature model, modelregistry.py:70-74)")
@@ -31,6 +31,9 @@ class StrElementRepresentationModel:
         self.embedding_size, self.vocabulary_size = embedding_size, vocabulary_size
         self.max_num_subtokens, self.dropout_rate = max_num_subtokens, dropout_rate
         self.min_freq_threshold = min_freq_threshold
+        # "after_pooling" (default) / "before_pooling": where the subtoken embedder's dropout sits relative to the max over
+        # subtokens -- the second point ptgnn leaves unpinned; reaches gnn() through `node_representations`
+        self.dropout_placement = dropout_placement
         self._counter: Optional[Counter] = Counter()
         self.vocabulary: Optional[Vocabulary] = None
         self._cache: Dict[str, np.ndarray] = {}
@@ -52,7 +55,8 @@ class StrElementRepresentationModel:
 
         if self.token_splitting == "token":
             return TokenEmbedder(len(self.vocabulary), self.embedding_size)
-        return SubtokenEmbedder(len(self.vocabulary), self.embedding_size, self.max_num_subtokens, self.dropout_rate)
+        return SubtokenEmbedder(len(self.vocabulary), self.embedding_size, self.max_num_subtokens, self.dropout_rate,
+                                getattr(self, "dropout_placement", "after_pooling"))
 
     def tensorize_tokens(self, strs) -> np.ndarray:
         """token mode: one vocabulary id per string (the pad token is a vocabulary entry; unseen strings -> unk)."""

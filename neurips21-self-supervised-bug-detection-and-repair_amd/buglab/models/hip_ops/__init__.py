@@ -83,9 +83,9 @@ _SIGNATURES = {
                             c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_set_fused_node_bwd": ([c_int32], c_int32),
     "bl_last_error": ([], ctypes.c_char_p),
-    "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
-    "bl_embed_subtoken_max_bwd_sorted": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
+    "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_embed_subtoken_max_bwd_sorted": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gemm_rows": ([POINTER(bl_rows_t), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
@@ -865,7 +865,7 @@ class GraphIndex(NamedTuple):
 
 class _EmbedSubtokenMax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, ids, lens, drop: Dropout, tok_csr):
+    def forward(ctx, table, ids, lens, drop: Dropout, tok_csr, before_pool: bool):
         _f32(table, "embedding table")
         N, S = ids.shape
         V, H = table.shape
@@ -873,14 +873,14 @@ class _EmbedSubtokenMax(torch.autograd.Function):
         argsub = torch.empty((N, H), dtype=torch.int8, device=table.device)
         _check(
             load_library().bl_embed_subtoken_max_fwd(table.data_ptr(), V, H, _i32(ids).data_ptr(), _i32(lens).data_ptr(), N, S,
-                                                     drop.c(), out.data_ptr(), out.stride(0), argsub.data_ptr(), _stream()),
+                                                     drop.c(), int(bool(before_pool)), out.data_ptr(), out.stride(0), argsub.data_ptr(), _stream()),
             "bl_embed_subtoken_max_fwd")
-        ctx.saved = (table, ids, argsub, drop, V, H, tok_csr)
+        ctx.saved = (table, ids, argsub, drop, V, H, tok_csr, int(bool(before_pool)))
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        table, ids, argsub, drop, V, H, tok_csr = _take_saved(ctx)
+        table, ids, argsub, drop, V, H, tok_csr, before_pool = _take_saved(ctx)
         g_out = g_out.contiguous()
         N, S = ids.shape
         direct = _direct_small(table)
@@ -890,21 +890,22 @@ class _EmbedSubtokenMax(torch.autograd.Function):
             _check(
                 load_library().bl_embed_subtoken_max_bwd_sorted(g_out.data_ptr(), g_out.stride(0), _i32(occ).data_ptr(),
                                                                 _i32(chunk_ptr).data_ptr(), _i32(chunk_tok).data_ptr(),
-                                                                int(chunk_tok.shape[0]), argsub.data_ptr(), S, H, drop.c(),
+                                                                int(chunk_tok.shape[0]), argsub.data_ptr(), S, H, drop.c(), before_pool,
                                                                 g_table.data_ptr(), _stream()),
                 "bl_embed_subtoken_max_bwd_sorted")
         else:
             _check(
                 load_library().bl_embed_subtoken_max_bwd(g_out.data_ptr(), g_out.stride(0), ids.data_ptr(), argsub.data_ptr(), N, S, H,
-                                                         V, drop.c(), g_table.data_ptr(), _stream()),
+                                                         V, drop.c(), before_pool, g_table.data_ptr(), _stream()),
                 "bl_embed_subtoken_max_bwd")
-        return (None if direct is not None else g_table), None, None, None, None
+        return (None if direct is not None else g_table), None, None, None, None, None
 
 
-def embed_subtoken_max(table, ids, lens, drop: Dropout = NO_DROPOUT, tok_csr=None):
+def embed_subtoken_max(table, ids, lens, drop: Dropout = NO_DROPOUT, tok_csr=None, dropout_before_pooling: bool = False):
     """tok_csr = (occ, chunk_ptr, chunk_tok) from the collator (token-sorted subtoken occurrences): backward
-    then sums per token in registers instead of issuing one atomic per (node, channel)."""
-    return _EmbedSubtokenMax.apply(table, ids, lens, drop, tok_csr)
+    then sums per token in registers instead of issuing one atomic per (node, channel).
+    dropout_before_pooling: dropout on the embedded subtokens (then max) instead of on the pooled rows."""
+    return _EmbedSubtokenMax.apply(table, ids, lens, drop, tok_csr, bool(dropout_before_pooling))
 
 
 class _MpLayer(torch.autograd.Function):
@@ -1216,7 +1217,16 @@ def _packed_message_weights(W: torch.Tensor, Din: int, need_bwd: bool):
 # The routed input gradient of a message-passing layer from the NON-ZEROS of the message gradient, on the vector units, node
 # sums fused in (csrc/bl_routed_dgrad.hip), instead of the matrix-core GEMM over all E x Dm entries + bl_mp_scatter_grad.
 # BL_DGRAD_VEC=0: matrix cores.  Needs W transposed ([T, Dm, 2 Din]); cached per parameter value like the packed forms.
-DGRAD_VEC = os.environ.get("BL_DGRAD_VEC", "1") != "0"
+# Default (BL_DGRAD_VEC unset): vector units while the message GEMMs run as bf16x6 (0.404 vs 0.550 ms per hidden-128 layer), matrix
+# cores when they run as f16x3 -- the routed f16x3 GEMM + segmented sums cost the same exclusive time as the vector kernel + its
+# sums (4.24 vs 4.33 ms per c2 step) and overlap better with the free-running weight gradients (the vector kernel holds a CU's
+# whole LDS with one 1024-thread workgroup): 13.12 vs 13.68 ms per step (profiles/r06h_bench*.json).
+DGRAD_VEC = {"1": True, "0": False}.get(os.environ.get("BL_DGRAD_VEC", ""), None)
+
+
+def _use_vector_dgrad(lib, E: int, Dm: int, K2: int) -> bool:
+    want = DGRAD_VEC if DGRAD_VEC is not None else not lib.bl_get_msg_gemm_mode()
+    return bool(want) and E > 0 and bool(lib.bl_routed_dgrad_vec_ok(Dm, K2))
 
 
 def _transposed_layer_weights(W: torch.Tensor) -> torch.Tensor:
@@ -1258,7 +1268,7 @@ class _MpLayerFused(torch.autograd.Function):
         # (grad mode is always off inside Function.forward: whether a backward pass will follow is in needs_input_grad)
         need_bwd = any(ctx.needs_input_grad[:7])
         # which form of W the input gradient will read: its fp32 transpose (vector-unit path) or the packed C = G . W^T form
-        use_vec = DGRAD_VEC and E > 0 and bool(lib.bl_routed_dgrad_vec_ok(Dm, K2))
+        use_vec = _use_vector_dgrad(lib, E, Dm, K2)
         wkn, wnk = _packed_message_weights(W, Din, need_bwd and not use_vec)
         wt = _transposed_layer_weights(W) if (need_bwd and use_vec) else None
         dev = h_lo.device
@@ -1297,7 +1307,7 @@ class _MpLayerFused(torch.autograd.Function):
         Din, Dout = w_lo + w_hi, Wd.shape[1]
         dev = out.device
         g_out = g_out.contiguous()
-        use_vec = DGRAD_VEC and E > 0 and bool(lib.bl_routed_dgrad_vec_ok(Dm, 2 * Din))
+        use_vec = _use_vector_dgrad(lib, E, Dm, 2 * Din)
         if use_vec and wt is None:
             wt = _transposed_layer_weights(W)
         if wnk is None and not use_vec:  # forward ran without grad mode knowing a backward would follow

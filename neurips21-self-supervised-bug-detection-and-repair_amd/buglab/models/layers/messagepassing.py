@@ -59,15 +59,22 @@ def _uniform_(t: torch.Tensor, bound: float) -> torch.Tensor:
 class SubtokenEmbedder(nn.Module):
     """StrElementRepresentationModel in "subtoken"/"max" mode (modelregistry.py:59-82)."""
 
-    def __init__(self, vocabulary_size: int, embedding_size: int, max_num_subtokens: int = 6, dropout_rate: float = 0.0):
+    def __init__(self, vocabulary_size: int, embedding_size: int, max_num_subtokens: int = 6, dropout_rate: float = 0.0,
+                 dropout_placement: str = "after_pooling"):
         super().__init__()
+        if dropout_placement not in ("after_pooling", "before_pooling"):
+            raise ValueError(f"dropout_placement must be 'after_pooling' or 'before_pooling' (got {dropout_placement!r})")
         self.embedding_size = embedding_size
         self.max_num_subtokens = max_num_subtokens
         self.dropout_rate = dropout_rate
+        # where the embedder's dropout sits relative to the max over subtokens: on the pooled rows (default -- the last statement
+        # of ptgnn's SubtokenUnitEmbedder.forward as recollected, DESIGN.md section 2) or on the embedded subtokens before it
+        self.dropout_placement = dropout_placement
         self.table = nn.Parameter(torch.randn(vocabulary_size, embedding_size))
 
     def forward(self, token_ids, token_lens, drop: Dropout, tok_csr=None):
-        return hip_ops.embed_subtoken_max(self.table, token_ids, token_lens, drop, tok_csr)
+        before = getattr(self, "dropout_placement", "after_pooling") == "before_pooling"  # (older pickles: after)
+        return hip_ops.embed_subtoken_max(self.table, token_ids, token_lens, drop, tok_csr, dropout_before_pooling=before)
 
 
 class TokenEmbedder(nn.Module):

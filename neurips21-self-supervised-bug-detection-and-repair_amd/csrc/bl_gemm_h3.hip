@@ -486,8 +486,8 @@ extern "C" int bl_gemm_rows_h3(const bl_rows_packed_t* a, const uint32_t* win_bi
   return BL_OK;
 }
 
+int g_h3_kchunk_cap = 4096;  // rows per workgroup flush; follows bl_set_wgrad_kchunk_cap (csrc/bl_gemm_x6.hip)
 namespace {
-int g_h3_kchunk_cap = 4096;  // rows per workgroup flush (see bl_set_wgrad_kchunk_cap)
 template <bool ROUTED>
 int wgrad_h3_resident() {
   static int resident = 0;

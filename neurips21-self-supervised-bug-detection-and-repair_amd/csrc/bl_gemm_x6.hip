@@ -878,6 +878,9 @@ int gemm_rows_x6_impl(const char* who, const bl_rows_packed_t* a, const uint32_t
   return BL_OK;
 }
 
+}  // namespace
+extern int g_h3_kchunk_cap;  // csrc/bl_gemm_h3.hip
+namespace {
 bool g_wgrad_wide = true;  // bl_set_wgrad_tile: A/B switch between the 256 x 128 and the 128 x 128 weight-gradient tile
 // Largest number of rows one workgroup reduces before it flushes its output tile (bl_set_wgrad_kchunk_cap).  Every flush is
 // tile-size fp32 atomics, and the chip retires ~312 G of those per second whatever the addresses (tools/atomic_bench.py):
@@ -980,7 +983,7 @@ extern "C" int32_t bl_set_wgrad_tile(int32_t rows) {
 // of resident workgroups and is <= cap rows.  Returns the previous cap.
 extern "C" int32_t bl_set_wgrad_kchunk_cap(int32_t rows) {
   const int32_t prev = g_wgrad_kchunk_cap;
-  if (rows >= 256) g_wgrad_kchunk_cap = rows;
+  if (rows >= 256) g_wgrad_kchunk_cap = g_h3_kchunk_cap = rows;  // (the f16x3 weight gradient follows the same cap)
   return prev;
 }
 

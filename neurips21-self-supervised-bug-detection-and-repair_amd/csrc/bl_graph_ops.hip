@@ -19,23 +19,40 @@
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, int H,
                                                         const int* __restrict__ ids, const int* __restrict__ lens,
                                                         int N, int S, bl_drop_dev drop, float* __restrict__ out,
-                                                        int ld_out, int8_t* __restrict__ argsub) {
+                                                        int ld_out, int8_t* __restrict__ argsub, int drop_before_pool) {
   const int h4n = H >> 2;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)N * h4n) return;
   const int n = (int)(t / h4n), h = (int)(t % h4n) * 4;
   int len = lens[n];
   len = len < 1 ? 1 : (len > S ? S : len);
+  // drop_before_pool: dropout on the EMBEDDED SUBTOKENS [N, S, H] (mask index (n S + s) H + h) and the max over what is left
+  // (a dropped element is a 0 that can win); default: dropout on the pooled [N, H] rows (the frozen spec)
+  const bool pre = drop_before_pool && drop.thresh;
   float4 best = *reinterpret_cast<const float4*>(table + (size_t)ids[(size_t)n * S] * H + h);
+  if (pre) {
+    const uint32_t i = (uint32_t)n * (uint32_t)S * (uint32_t)H + (uint32_t)h;
+    best.x = bl_keep(drop, i) ? best.x * drop.scale : 0.f;
+    best.y = bl_keep(drop, i + 1) ? best.y * drop.scale : 0.f;
+    best.z = bl_keep(drop, i + 2) ? best.z * drop.scale : 0.f;
+    best.w = bl_keep(drop, i + 3) ? best.w * drop.scale : 0.f;
+  }
   int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   for (int s = 1; s < len; ++s) {
-    const float4 v = *reinterpret_cast<const float4*>(table + (size_t)ids[(size_t)n * S + s] * H + h);
+    float4 v = *reinterpret_cast<const float4*>(table + (size_t)ids[(size_t)n * S + s] * H + h);
+    if (pre) {
+      const uint32_t i = ((uint32_t)n * (uint32_t)S + (uint32_t)s) * (uint32_t)H + (uint32_t)h;
+      v.x = bl_keep(drop, i) ? v.x * drop.scale : 0.f;
+      v.y = bl_keep(drop, i + 1) ? v.y * drop.scale : 0.f;
+      v.z = bl_keep(drop, i + 2) ? v.z * drop.scale : 0.f;
+      v.w = bl_keep(drop, i + 3) ? v.w * drop.scale : 0.f;
+    }
     if (v.x > best.x) { best.x = v.x; a0 = s; }
     if (v.y > best.y) { best.y = v.y; a1 = s; }
     if (v.z > best.z) { best.z = v.z; a2 = s; }
     if (v.w > best.w) { best.w = v.w; a3 = s; }
   }
-  if (drop.thresh) {
+  if (drop.thresh && !pre) {
     const uint32_t i = (uint32_t)n * (uint32_t)H + (uint32_t)h;
     best.x = bl_keep(drop, i) ? best.x * drop.scale : 0.f;
     best.y = bl_keep(drop, i + 1) ? best.y * drop.scale : 0.f;
@@ -48,17 +65,22 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
   *reinterpret_cast<char4*>(argsub + (size_t)n * H + h) = a;
 }
 
+// index of the dropout mask bit that scales the gradient of (node n, channel h) whose winning subtoken slot is s
+__device__ __forceinline__ uint32_t embed_mask_index(int n, int s, int h, int S, int H, int drop_before_pool) {
+  return drop_before_pool ? ((uint32_t)n * (uint32_t)S + (uint32_t)s) * (uint32_t)H + (uint32_t)h : (uint32_t)n * (uint32_t)H + (uint32_t)h;
+}
+
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g_out, int ld_g,
                                                         const int* __restrict__ ids,
                                                         const int8_t* __restrict__ argsub, int N, int S, int H,
-                                                        bl_drop_dev drop, float* __restrict__ g_table) {
+                                                        bl_drop_dev drop, float* __restrict__ g_table, int drop_before_pool) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)N * H) return;
   const int n = (int)(t / H), h = (int)(t % H);
   float g = g_out[(size_t)n * ld_g + h];
-  if (drop.thresh) g = bl_keep(drop, (uint32_t)n * (uint32_t)H + (uint32_t)h) ? g * drop.scale : 0.f;
+  const int s = argsub[(size_t)n * H + h];
+  if (drop.thresh) g = bl_keep(drop, embed_mask_index(n, s, h, S, H, drop_before_pool)) ? g * drop.scale : 0.f;
   if (g != 0.f) {
-    const int s = argsub[(size_t)n * H + h];
     unsafeAtomicAdd(&g_table[(size_t)ids[(size_t)n * S + s] * H + h], g);
   }
 }
@@ -66,13 +88,14 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 // deterministic mode: thread h owns column h and walks the nodes in order (slow; the token-sorted kernel is the fast path)
 __global__ __launch_bounds__(256) void embed_bwd_serial_kernel(const float* __restrict__ g_out, int ld_g, const int* __restrict__ ids,
                                                                const int8_t* __restrict__ argsub, int N, int S, int H, bl_drop_dev drop,
-                                                               float* __restrict__ g_table) {
+                                                               float* __restrict__ g_table, int drop_before_pool) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   for (int n = 0; n < N; ++n) {
     float g = g_out[(size_t)n * ld_g + h];
-    if (drop.thresh) g = bl_keep(drop, (uint32_t)n * (uint32_t)H + (uint32_t)h) ? g * drop.scale : 0.f;
-    if (g != 0.f) g_table[(size_t)ids[(size_t)n * S + argsub[(size_t)n * H + h]] * H + h] += g;
+    const int s = argsub[(size_t)n * H + h];
+    if (drop.thresh) g = bl_keep(drop, embed_mask_index(n, s, h, S, H, drop_before_pool)) ? g * drop.scale : 0.f;
+    if (g != 0.f) g_table[(size_t)ids[(size_t)n * S + s] * H + h] += g;
   }
 }
 
@@ -87,7 +110,7 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
                                                                const int* __restrict__ chunk_ptr,
                                                                const int* __restrict__ chunk_tok, int nchunks,
                                                                const int8_t* __restrict__ argsub, int S, int H,
-                                                               bl_drop_dev drop, float* __restrict__ g_table) {
+                                                               bl_drop_dev drop, float* __restrict__ g_table, int drop_before_pool) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= nchunks) return;
@@ -118,7 +141,8 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           float v = g[u][j];
-          if (drop.thresh) v = bl_keep(drop, (uint32_t)n[u] * (uint32_t)H + (uint32_t)(lane + 64 * j)) ? v * drop.scale : 0.f;
+          // (only the slot that won contributes, so the mask bit of (n, sl, h) is the winner's when it matters)
+          if (drop.thresh) v = bl_keep(drop, embed_mask_index(n[u], sl[u] < 0 ? 0 : sl[u], lane + 64 * j, S, H, drop_before_pool)) ? v * drop.scale : 0.f;
           if (a[u][j] == sl[u]) acc[j] += v;
         }
     }
@@ -777,31 +801,32 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restri
   else { constexpr int NV = 8; __VA_ARGS__; }
 
 extern "C" int bl_embed_subtoken_max_fwd(const float* table, int32_t V, int32_t H, const int32_t* ids,
-                                         const int32_t* lens, int32_t N, int32_t S, bl_dropout_t drop, float* out,
-                                         int32_t ld_out, int8_t* argsub, void* stream) {
+                                         const int32_t* lens, int32_t N, int32_t S, bl_dropout_t drop, int32_t drop_before_pool,
+                                         float* out, int32_t ld_out, int8_t* argsub, void* stream) {
   if (N == 0) return BL_OK;
   BL_CHECK_ARG(table && ids && lens && out && argsub, "bl_embed_subtoken_max_fwd: null pointer");
   BL_CHECK_ARG(H > 0 && H % 4 == 0 && ld_out % 4 == 0 && S >= 1 && S <= 127 && V > 0, "bl_embed_subtoken_max_fwd: H %% 4, 1 <= S <= 127");
   BL_CHECK_ARG(bl_aligned16(table) && bl_aligned16(out), "bl_embed_subtoken_max_fwd: misaligned");
+  BL_CHECK_ARG(!drop_before_pool || (uint64_t)N * (uint64_t)S * (uint64_t)H < (1ull << 32), "bl_embed_subtoken_max_fwd: dropout index space is 32 bit");
   const long long total = (long long)N * (H / 4);
   hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, H,
-                     ids, lens, N, S, bl_make_drop(drop), out, ld_out, argsub);
+                     ids, lens, N, S, bl_make_drop(drop), out, ld_out, argsub, drop_before_pool);
   BL_LAUNCH_CHECK("bl_embed_subtoken_max_fwd");
   return BL_OK;
 }
 
 extern "C" int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const int32_t* ids, const int8_t* argsub,
-                                         int32_t N, int32_t S, int32_t H, int32_t V, bl_dropout_t drop, float* g_table,
-                                         void* stream) {
+                                         int32_t N, int32_t S, int32_t H, int32_t V, bl_dropout_t drop, int32_t drop_before_pool,
+                                         float* g_table, void* stream) {
   if (N == 0) return BL_OK;
   BL_CHECK_ARG(g_out && ids && argsub && g_table && V > 0, "bl_embed_subtoken_max_bwd: null pointer");
   const long long total = (long long)N * H;
   if (bl_get_deterministic())
     hipLaunchKernelGGL(embed_bwd_serial_kernel, dim3((H + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_out, ld_g, ids, argsub, N,
-                       S, H, bl_make_drop(drop), g_table);
+                       S, H, bl_make_drop(drop), g_table, drop_before_pool);
   else
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out,
-                       ld_g, ids, argsub, N, S, H, bl_make_drop(drop), g_table);
+                       ld_g, ids, argsub, N, S, H, bl_make_drop(drop), g_table, drop_before_pool);
   BL_LAUNCH_CHECK("bl_embed_subtoken_max_bwd");
   return BL_OK;
 }
@@ -809,13 +834,13 @@ extern "C" int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const
 extern "C" int bl_embed_subtoken_max_bwd_sorted(const float* g_out, int32_t ld_g, const int32_t* occ,
                                                const int32_t* chunk_ptr, const int32_t* chunk_tok, int32_t nchunks,
                                                const int8_t* argsub, int32_t S, int32_t H, bl_dropout_t drop,
-                                               float* g_table, void* stream) {
+                                               int32_t drop_before_pool, float* g_table, void* stream) {
   if (nchunks == 0) return BL_OK;
   BL_CHECK_ARG(g_out && occ && chunk_ptr && chunk_tok && argsub && g_table, "bl_embed_subtoken_max_bwd_sorted: null pointer");
   BL_CHECK_ARG(H > 0 && H <= 512 && S >= 1 && S <= 127, "bl_embed_subtoken_max_bwd_sorted: H in 1..512, 1 <= S <= 127");
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NV(H, hipLaunchKernelGGL((embed_bwd_sorted_kernel<NV>), dim3((nchunks + 3) / 4), dim3(256), 0, st, g_out, ld_g, occ,
-                                     chunk_ptr, chunk_tok, nchunks, argsub, S, H, bl_make_drop(drop), g_table))
+                                     chunk_ptr, chunk_tok, nchunks, argsub, S, H, bl_make_drop(drop), g_table, drop_before_pool))
   BL_LAUNCH_CHECK("bl_embed_subtoken_max_bwd_sorted");
   return BL_OK;
 }

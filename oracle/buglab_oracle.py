@@ -132,6 +132,7 @@ class OracleConfig:
     dropout: float = 0.0
     msg_act: str = "gelu"
     msg_act_placement: str = "aggregated"  # see MpSpec
+    embed_dropout_placement: str = "after_pooling"  # or "before_pooling": see embed_nodes
     buggy_samples_weight: float = 1.0
     abstain_weight: float = 0.0  # LocalizationModule(abstain_weight=...), localizationmodule.py:15,95-100
     use_all_gnn_layer_outputs: bool = False  # gnn.py:68-74,118-121
@@ -244,15 +245,21 @@ def scatter_log_softmax(src: torch.Tensor, index: torch.Tensor, eps: float = 1e-
 # M0  node embedder  (ptgnn StrElementRepresentationModel, configured at
 #     reference modelregistry.py:59-82: subtoken splitting, <=6 subtokens, "max")
 # ----------------------------------------------------------------------------
-def embed_nodes(table, token_ids, token_lens, p_drop, seed):
+def embed_nodes(table, token_ids, token_lens, p_drop, seed, dropout_placement="after_pooling"):
+    """dropout_placement "after_pooling" (default): drop(max_s emb) -- the last statement of ptgnn's SubtokenUnitEmbedder.forward as
+    recollected (`return self.__dropout_layer(embedded)` after the combination); "before_pooling": max_s drop(emb) with the mask
+    over the [N, S, H] embedded subtokens (a dropped element is a 0 that can win the max).  Eval-mode outputs do not depend on it."""
+    assert dropout_placement in ("after_pooling", "before_pooling")
     ids = torch.as_tensor(token_ids, dtype=torch.int64)
     lens = torch.as_tensor(token_lens, dtype=torch.int64).clamp(min=1)
     emb = table[ids]  # [N, S, H]
+    if dropout_placement == "before_pooling":
+        emb = apply_dropout(emb, p_drop, seed, stream=0)
     S = ids.shape[1]
     pad = torch.arange(S).view(1, S) >= lens.view(-1, 1)
     emb = emb.masked_fill(pad.unsqueeze(-1), -math.inf)
     h = emb.max(dim=1).values
-    return apply_dropout(h, p_drop, seed, stream=0)
+    return h if dropout_placement == "before_pooling" else apply_dropout(h, p_drop, seed, stream=0)
 
 
 def _gelu(x):
@@ -322,7 +329,7 @@ def gated_mp_layer(h, W, Wi, bi, Wh, bh, msg_src, msg_tgt, type_ptr, p_drop, see
 def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None, force_arg=None):
     """force_arg: optional list (one int64 [N, Dm] table per MP layer) of winners to use instead of the
     layer's own arg-max -- the tie-aware parity tests inject the HIP path's routing (see mp_layer)."""
-    h = embed_nodes(params["embed.table"], gd["token_ids"], gd["token_lens"], cfg.dropout, seed)
+    h = embed_nodes(params["embed.table"], gd["token_ids"], gd["token_lens"], cfg.dropout, seed, cfg.embed_dropout_placement)
     if trace is not None:
         trace.append({"embed": h})
     all_states = [h]

@@ -66,7 +66,7 @@ def test_argument_errors_are_reported_without_touching_the_gpu(built_lib):
     assert rc != 0 and b"multiple of 32" in lib.bl_last_error()
     rc = lib.bl_layernorm_bwd(None, None, None, None, None, 4, 8, None, None, None, None, None, None)
     assert rc != 0 and b"null" in lib.bl_last_error()
-    rc = lib.bl_embed_subtoken_max_bwd_sorted(None, 0, None, None, None, 3, None, 6, 64, hip_ops.Dropout(0.0, 0, 0).c(), None, None)
+    rc = lib.bl_embed_subtoken_max_bwd_sorted(None, 0, None, None, None, 3, None, 6, 64, hip_ops.Dropout(0.0, 0, 0).c(), 0, None, None)
     assert rc != 0 and b"null" in lib.bl_last_error()
     rc = lib.bl_segment_max_fwd(None, 0, None, None, 5, 1024, 0, None, None, None, None, 1e-5, None, None, None, None, None, None, None)
     assert rc != 0

@@ -117,6 +117,14 @@ def test_dropout_parity_same_counter_mask(placement):
     _check_against_oracle(cfg, mb, seed=777)
 
 
+def test_embedder_dropout_before_pooling_same_counter_mask():
+    """The second placement the spec hedges: the subtoken embedder's dropout on the embedded subtokens
+    [N, S, H] before the max instead of on the pooled rows -- forward, loss and every gradient against the oracle with the
+    same counter-hash mask (a dropped element is a 0 that may win the max; the table gradient follows the winner's mask bit)."""
+    cfg, _, mb = Hh.make_case(B=3, n=60, E=300, T=4, H=64, layers=4, dropout=0.3, seed=5, embed_dropout_placement="before_pooling")
+    _check_against_oracle(cfg, mb, seed=4242)
+
+
 def test_message_activation_none_and_weighted_loss():
     cfg, _, mb = Hh.make_case(B=4, n=70, E=350, T=3, H=32, layers=4, msg_act="none", buggy_samples_weight=0.6, seed=7)
     _check_against_oracle(cfg, mb)

@@ -112,6 +112,25 @@ def test_message_activation_placement_hand_checked():
     assert O.OracleConfig().msg_act_placement == "aggregated" and O.MpSpec(1, 1, 1).msg_act_placement == "aggregated"
 
 
+def test_embedder_dropout_placement_hand_checked():
+    """Dropout of the subtoken embedder before or after the max over subtokens (oracle.embed_nodes): with every subtoken of a node
+    kept the two placements give the same values; a dropped winner lets another subtoken (or the 0 of a dropped one) win only
+    under "before_pooling"; eval mode (no seed) does not depend on the placement."""
+    table = torch.tensor([[0.0, 0.0], [1.0, -1.0], [2.0, -3.0], [-5.0, 4.0]])
+    ids, lens = np.array([[1, 2, 3], [3, 0, 0]]), np.array([3, 1])
+    for pl in ("after_pooling", "before_pooling"):
+        np.testing.assert_array_equal(O.embed_nodes(table, ids, lens, 0.5, None, pl).numpy(), [[2.0, 4.0], [-5.0, 4.0]])
+    seed, p = 3, 0.5
+    keep_rows = O.dropout_keep_mask(seed, 0, 4, p).reshape(2, 2)
+    keep_subs = O.dropout_keep_mask(seed, 0, 12, p).reshape(2, 3, 2)
+    after = O.embed_nodes(table, ids, lens, p, seed, "after_pooling").numpy()
+    np.testing.assert_allclose(after, np.array([[2.0, 4.0], [-5.0, 4.0]]) * keep_rows / (1 - p))
+    emb = table.numpy()[ids] * keep_subs / (1 - p)
+    emb[1, 1:] = -np.inf  # padding slots of the one-subtoken node
+    np.testing.assert_allclose(O.embed_nodes(table, ids, lens, p, seed, "before_pooling").numpy(), emb.max(axis=1))
+    assert O.OracleConfig().embed_dropout_placement == "after_pooling"
+
+
 def test_config_c1_plumbing_on_cpu_oracle():
     """BASELINE.json configs[0]: gnn-mlp, hidden 128, 4 layers, ONE graph of ~500 nodes, CPU.  The product has no CPU path
     (it fails loudly without the GPU), so the CPU-runnable case is the oracle's: a few clip + Adam steps on that batch

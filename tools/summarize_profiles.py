@@ -27,7 +27,7 @@ for f in ("bench.json", "bench_seq.json", "bench_kernel_stats.csv", "bench_seria
         shutil.copy(f"{G}/{tag}_{f}", f"{P}/{tag}_{f}")
 if os.path.exists(f"{G}/{tag}_sq_pmc.json"):  # SQ counter passes of the serial run (tools/pmc_passes.sh): keep the layer kernels
     sq = json.load(open(f"{G}/{tag}_sq_pmc.json"))["kernels"]
-    keep = {k: v for k, v in sq.items() if any(s in k for s in ("x6", "segment_max", "routed_dgrad", "node_bwd", "mp_scatter", "pack_rows"))}
+    keep = {k: v for k, v in sq.items() if any(s in k for s in ("x6", "h3", "segment_max", "routed_dgrad", "node_bwd", "mp_scatter", "pack_rows"))}
     json.dump({"command": "rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-predict --no-also",
                "note": "per-dispatch averages; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); l2_hit_rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)",
                "kernels": keep}, open(f"{P}/{tag}_pmc_sq.json", "w"), indent=1, sort_keys=True)
