@@ -11,346 +11,23 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
+import types
 from ctypes import POINTER, Structure, c_float, c_int8, c_int32, c_int64, c_uint32, c_void_p
 from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GELU, ACT_GELU_AGG = 0, 1, 2, 3, 4, 5
-# "gelu_aggregated": GELU on the aggregate of a segmented max (gelu(max x)) instead of on every item (max gelu(x)) -- only
-# meaningful as a message-passing layer's `msg_act` / segment_max's `act`
-_ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH, "gelu": ACT_GELU,
-         "gelu_aggregated": ACT_GELU_AGG}
-
-
-def message_activation_code(activation: str, placement: str = "aggregated") -> str:
-    """(message_activation, message_activation_placement) of an MlpMessagePassingLayer -> the `msg_act` name of mp_layer()."""
-    if activation not in ("gelu", "none"):
-        raise ValueError(f"message_activation must be 'gelu' or 'none' (got {activation!r})")
-    if placement not in ("aggregated", "message"):
-        raise ValueError(f"message_activation_placement must be 'aggregated' or 'message' (got {placement!r})")
-    return "gelu_aggregated" if (activation == "gelu" and placement == "aggregated") else activation
-LIB_NAME = "libbuglab_hip.so"
-LIB_PATH = os.environ.get("BL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)  # BL_HIP_LIB: tuning builds
-
-
-class HipOpsUnavailable(RuntimeError):
-    pass
-
-
-class bl_rows_t(Structure):
-    _fields_ = [("x", c_void_p * 3), ("idx", c_void_p * 3), ("ld", c_int32 * 3), ("width", c_int32 * 3), ("nsrc", c_int32)]
-
-
-class bl_rows_packed_t(Structure):
-    _fields_ = [("xp", c_void_p * 3), ("idx", c_void_p * 3), ("width", c_int32 * 3), ("nsrc", c_int32)]
-
-
-class bl_dropout_t(Structure):
-    _fields_ = [("p", c_float), ("seed", c_uint32), ("stream", c_uint32)]
-
-
-class bl_mp_layer_t(Structure):
-    _fields_ = [("N", c_int32), ("E", c_int32), ("T", c_int32), ("Din", c_int32), ("Dm", c_int32), ("Dout", c_int32),
-                ("msg_src", c_void_p), ("msg_tgt", c_void_p), ("type_ptr", c_void_p), ("tgt_ptr", c_void_p), ("tgt_msgs", c_void_p),
-                ("src_ptr", c_void_p), ("src_msgs", c_void_p), ("node_order", c_void_p),
-                ("W", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p), ("Wd", c_void_p), ("bd", c_void_p),
-                ("msg_act", c_int32), ("ln_eps", c_float), ("drop", bl_dropout_t), ("Wt", c_void_p),
-                ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p), ("num_hub_slots", c_int32)]
-
-
-class bl_pack_job_t(Structure):
-    _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", c_int32), ("G", c_int32), ("K", c_int32), ("N", c_int32),
-                ("first_block", c_int32), ("pad_", c_int32)]
-
-
-class bl_bug_loss_t(Structure):
-    _fields_ = [("B", c_int32), ("C", c_int32), ("Rt", c_int32), ("Rv", c_int32), ("Rs", c_int32), ("G", c_int32),
-                ("loc_scores", c_void_p), ("repair_logits", c_void_p), ("loc_group_ptr", c_void_p), ("loc_group_items", c_void_p),
-                ("candidate_ptr", c_void_p), ("has_bug", c_void_p), ("correct_candidate_idxs", c_void_p),
-                ("repair_group_ptr", c_void_p), ("repair_group_items", c_void_p), ("logit_group", c_void_p * 3),
-                ("target", c_void_p * 3), ("ntarget", c_int32 * 3), ("w_buggy", c_float), ("abstain_weight", c_float)]
-
-
-_SIGNATURES = {
-    "bl_version": ([], ctypes.c_int),
-    "bl_set_deterministic": ([c_int32], None),
-    "bl_get_deterministic": ([], c_int32),
-    "bl_set_wgrad_tile": ([c_int32], c_int32),
-    "bl_set_wgrad_kchunk_cap": ([c_int32], c_int32),
-    "bl_node_update_bwd_ok": ([c_int32, c_int32], c_int32),
-    "bl_node_update_bwd": ([c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                            c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_set_fused_node_bwd": ([c_int32], c_int32),
-    "bl_last_error": ([], ctypes.c_char_p),
-    "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_embed_subtoken_max_bwd_sorted": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_gemm_rows": ([POINTER(bl_rows_t), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_rows_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_pack_bf16x3": ([c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_pack_weights_x6": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_pack_job_blocks": ([c_int32, c_int32, c_int32, c_int32], c_int64),
-    "bl_pack_weights_multi": ([c_void_p, c_int32, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_rows_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_rows_x6w_ok": ([c_int32, c_int32], c_int32),
-    "bl_set_rows_tile": ([c_int32], c_int32),
-    "bl_packed_weight_elems_x6w": ([c_int32, c_int32, c_int32], c_int64),
-    "bl_pack_weights_x6w": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_gemm_rows_x6w": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_rows_x6_epi": ([POINTER(bl_rows_packed_t), c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32,
-                             bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_wgrad_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
-                          c_int32, c_void_p], ctypes.c_int),
-    "bl_routed_dgrad_vec_ok": ([c_int32, c_int32], c_int32),
-    "bl_routed_dgrad_vec": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_routed_dgrad_nodes": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
-                               c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_routed_dgrad_nodes_rows": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
-                                    c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_wgrad_routed_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_wgrad": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_wgrad_routed": ([POINTER(bl_rows_t), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
-    "bl_pack_bf16x3_cols": ([c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_mp_scatter_grad_split": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_mp_layer_saved_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
-    "bl_mp_layer_workspace_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
-    "bl_mp_layer_packed_weight_elems": ([c_int32, c_int32, c_int32, c_int32], c_int64),
-    "bl_mp_layer_weight_image": ([c_int32, c_int32, c_int32], c_int32),
-    "bl_mp_layer_fwd": ([POINTER(bl_mp_layer_t), c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_mp_layer_bwd": ([POINTER(bl_mp_layer_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32,
-                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32], ctypes.c_int),
-    "bl_gather_concat_mlp_score_fwd": ([POINTER(bl_rows_t), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_gather_concat_mlp_score_workspace_bytes": ([c_int32, c_int32, c_int32], c_int64),
-    "bl_gather_concat_mlp_score_bwd": ([POINTER(bl_rows_t), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_int32), c_void_p], ctypes.c_int),
-    "bl_localization_scores_saved_bytes": ([c_int32, c_int32, c_int32], c_int64),
-    "bl_localization_scores_workspace_bytes": ([c_int32, c_int32, c_int32, c_int32], c_int64),
-    "bl_localization_scores_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_localization_scores_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_bug_loss_fwd": ([POINTER(bl_bug_loss_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_bug_loss_bwd": ([POINTER(bl_bug_loss_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_add_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_rel_attn_bias_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_rel_attn_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_masked_softmax_fwd": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_void_p], ctypes.c_int),
-    "bl_rel_attn_probs_ok": ([c_int32, c_int32, c_int32], c_int32),
-    "bl_rel_attn_probs_fwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
-                               c_void_p, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_rel_attn_probs_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
-                               c_void_p, c_void_p, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_attn_mm32_ok": ([c_int32, c_int32], c_int32),
-    "bl_attn_rows_times": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_float, c_void_p, c_void_p], ctypes.c_int),
-    "bl_attn_transposed_times": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_masked_softmax_dropout_fwd": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
-    "bl_softmax_dropout_bwd": ([c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_void_p], ctypes.c_int),
-    "bl_rel_value_bias_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_rel_value_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_dropout_inplace": ([c_void_p, c_int64, bl_dropout_t, c_void_p], ctypes.c_int),
-    "bl_pack_f16x2": ([c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_amax": ([c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
-    "bl_packed_weight_elems_h3": ([c_int32, c_int32, c_int32], c_int64),
-    "bl_pack_weights_h3": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p], ctypes.c_int),
-    "bl_gemm_rows_h3": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32,
-                         c_int32, c_float, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_gemm_wgrad_h3": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
-                          c_int32, c_float, c_void_p, c_void_p, c_int64, c_int32, c_void_p], ctypes.c_int),
-    "bl_set_msg_gemm_mode": ([c_int32], c_int32),
-    "bl_get_msg_gemm_mode": ([], c_int32),
-    "bl_calib_mfma_bf16": ([c_int32, c_int32, c_void_p, POINTER(ctypes.c_double), c_void_p], ctypes.c_int),
-    "bl_calib_stream_copy": ([c_void_p, c_void_p, c_int64, c_void_p], ctypes.c_int),
-    "bl_prof_enable": ([c_int32], ctypes.c_int),
-    "bl_prof_reset": ([], ctypes.c_int),
-    "bl_prof_num_kinds": ([], ctypes.c_int),
-    "bl_prof_kind_name": ([c_int32], ctypes.c_char_p),
-    "bl_prof_read": ([c_int32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), POINTER(c_int32)], ctypes.c_int),
-    "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_act_bwd_packed": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_gru_cell_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
-    "bl_gru_cell_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_segment_log_softmax_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p], ctypes.c_int),
-    "bl_segment_log_softmax_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_rowdot_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "bl_rowdot_bwd": ([c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_scatter_add_rows": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_gather_rows": ([c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
-    "bl_sqnorm_scratch_bytes": ([], ctypes.c_int64),
-    "bl_sqnorm": ([c_void_p, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "bl_adam_clip_step_dp": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p], ctypes.c_int),
-    "bl_adam_clip_step": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p], ctypes.c_int),
-}
-EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-
-_lib = None
-
-
-def load_library(path: Optional[str] = None):
-    """dlopen libbuglab_hip.so and declare every prototype.  Loud failure, never a fallback."""
-    global _lib
-    if _lib is not None and path is None:
-        return _lib
-    p = path or LIB_PATH
-    if not os.path.exists(p):
-        raise HipOpsUnavailable(
-            f"{p} not found: build it with `make -C neurips21-self-supervised-bug-detection-and-repair_amd/csrc` "
-            "(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback for the hot path."
-        )
-    lib = ctypes.CDLL(p)
-    for name, (argtypes, restype) in _SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
-        fn.argtypes = argtypes
-        fn.restype = restype
-    if path is None:
-        _lib = lib
-    return lib
-
-
-CALL_COUNT = 0  # calls into the library so far (bench.py reports calls per training step)
-
-
-def _check(rc: int, what: str):
-    global CALL_COUNT
-    CALL_COUNT += 1
-    if rc != 0:
-        msg = load_library().bl_last_error()
-        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
-
-
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
-
-
-def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
-
-
-def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
-    if not t.is_cuda:
-        raise HipOpsUnavailable(f"{name}: tensor is on {t.device}; the BugLab hot path only runs on a ROCm GPU (no CPU fallback)")
-    if t.dtype != dtype:
-        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
-        raise ValueError(f"{name}: must be contiguous")
-    return t
-
-
-def _f32(t, name="tensor"):
-    return _req(t, torch.float32, name)
-
-
-def _i32(t, name="index"):
-    return _req(t, torch.int32, name)
-
-
-class Dropout(NamedTuple):
-    p: float = 0.0
-    seed: int = 0
-    stream: int = 0
-
-    def c(self) -> bl_dropout_t:
-        return bl_dropout_t(float(self.p), int(self.seed) & 0xFFFFFFFF, int(self.stream) & 0xFFFFFFFF)
-
-
-NO_DROPOUT = Dropout()
-
-RowSource = Tuple[torch.Tensor, Optional[torch.Tensor]]  # (matrix [*, width], row index or None)
-
-
-def _rows(sources: Sequence[RowSource]) -> Tuple[bl_rows_t, int]:
-    r = bl_rows_t()
-    assert 1 <= len(sources) <= 3
-    K = 0
-    for j, (x, idx) in enumerate(sources):
-        _f32(x, f"rows source {j}")
-        assert x.dim() == 2
-        r.x[j] = x.data_ptr()
-        r.idx[j] = _i32(idx, f"rows index {j}").data_ptr() if idx is not None else None
-        r.ld[j] = x.stride(0)
-        r.width[j] = x.shape[1]
-        K += x.shape[1]
-    r.nsrc = len(sources)
-    return r, K
-
-
-# ------------------------------------------------------------------------------------------------
-# optional live kernel timing (bench.py): HIP events recorded on the launch stream around each GEMM
-class KernelTimer:
-    """`with KernelTimer() as t:` brackets every bl_gemm_* launch with a pair of HIP events on the
-    stream the kernel is launched on (torch's current stream is the one handed to the C ABI).
-    `t.summary()` (after a device sync) -> {kind: {"launches", "ms", "flop"}}."""
-
-    active: Optional["KernelTimer"] = None
-
-    def __init__(self):
-        self.records = []
-
-    def __enter__(self):
-        KernelTimer.active = self
-        lib = load_library()
-        lib.bl_prof_reset()
-        lib.bl_prof_enable(1)  # kernels launched inside the fused per-layer calls are timed on the C side
-        return self
-
-    def __exit__(self, *exc):
-        KernelTimer.active = None
-        load_library().bl_prof_enable(0)
-
-    def summary(self):
-        """{kind: {launches, ms, flop, overlapped}}.  `overlapped` kinds were launched while a kernel
-        of the same layer ran on the side stream: their event spans share the GPU and must not be
-        read as exclusive kernel time (the enclosing "*_pair" span is the exclusive one)."""
-        out = {}
-        for kind, flop, e0, e1, overlapped, nbytes in self.records:
-            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flop": 0.0, "overlapped": False})
-            d["overlapped"] = d["overlapped"] or overlapped
-            d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["flop"] += flop
-            if nbytes:
-                d["bytes"] = d.get("bytes", 0.0) + nbytes  # algorithmic bytes of a memory-bound kind
-        lib = load_library()
-        for k in range(lib.bl_prof_num_kinds()):
-            ms, flop, n, ov = ctypes.c_double(), ctypes.c_double(), c_int64(), c_int32()
-            _check(lib.bl_prof_read(k, ctypes.byref(ms), ctypes.byref(flop), ctypes.byref(n), ctypes.byref(ov)), "bl_prof_read")
-            if n.value:
-                out[lib.bl_prof_kind_name(k).decode()] = {"launches": int(n.value), "ms": ms.value, "flop": flop.value,
-                                                           "overlapped": bool(ov.value)}
-        return out
-
+from . import _lib as _lib_module
+from . import _streams
+from ._lib import *  # noqa: F401,F403  (ACT_* codes, structures, Dropout, load_library, HipOpsUnavailable, ...)
+from ._lib import _ACTS, _SIGNATURES, _check, _f32, _i32, _p, _req, _rows, _stream  # noqa: F401
+from ._streams import (KernelTimer, _direct_grad_target, _direct_small, _on_side_stream, _opted_in_for_direct_grad, _timed,  # noqa: F401
+                       join_side_stream, side_stream_if_any, use_step_stream)
 
 # Debug tap for the parity tests: when set to a list, every message-passing layer's forward appends its
 # winner table (int32 [N, Dm]: id of the message that won each channel's max at each node, -1 = none).
 WINNER_SINK: Optional[list] = None
-
-_overlap_depth = 0
-_free_running = False  # weight-gradient GEMMs of earlier layers may still be running on the side stream
-
-
-class _timed:
-    def __init__(self, kind, flop, span=False, nbytes=0.0):
-        self.t = KernelTimer.active
-        self.kind, self.flop, self.span, self.nbytes = kind, flop, span, nbytes
-
-    def __enter__(self):
-        if self.t is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-
-    def __exit__(self, *exc):
-        if self.t is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            self.t.records.append((self.kind, self.flop, self.e0, e1, (not self.span) and (_overlap_depth > 0 or _free_running), self.nbytes))
-
 
 # ------------------------------------------------------------------------------------------------
 # raw (non-autograd) entry points
@@ -696,144 +373,6 @@ def scatter_add_rows(src, col_off, width, idx, out):
 
 
 # ------------------------------------------------------------------------------------------------
-# side stream: weight-gradient GEMMs run next to the input-gradient chain of the same layer (both
-# only read the node gradient), so one kernel's prologue / epilogue / last-round tail is filled by
-# the other kernel's workgroups.  BL_SIDE_STREAM=0 disables.
-_side_streams = {}
-USE_SIDE_STREAM = os.environ.get("BL_SIDE_STREAM", "1") != "0"
-# Weight gradients of the message-passing layers are accumulated (fp32 atomics in the kernel)
-# straight into `param.grad` for parameters whose owner OPTED IN (`param._bl_direct_grad = True`, set by
-# FlatAdam, which pre-binds every .grad to a view of its flat gradient buffer), on the side stream, WITHOUT
-# joining at the end of the layer's backward: the side stream runs one weight-gradient GEMM after the other
-# behind the main chain and is joined once, by `join_side_stream()`, before the gradients are consumed
-# (FlatAdam.zero_grad / .step).  Parameters of any other optimiser get ordinary autograd gradients, complete
-# when backward() returns (the side stream is joined inside the layer's backward).
-DIRECT_PARAM_GRAD = os.environ.get("BL_DIRECT_GRAD", "1") != "0"
-
-
-_held_for_side_stream: list = []  # tensors the free-running side-stream GEMMs read: kept alive until the join
-
-
-# Priority of the side stream that carries the weight-gradient GEMMs (lower number = higher priority; out-of-range values are
-# mapped to the nearest valid one).  BL_SIDE_STREAM_PRIORITY: A/B knob.
-SIDE_STREAM_PRIORITY = int(os.environ.get("BL_SIDE_STREAM_PRIORITY", "0"))
-
-
-def _new_side_stream():
-    return torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY) if SIDE_STREAM_PRIORITY != 0 else torch.cuda.Stream()
-
-
-# The training step's dependent chain (forward, the backward's input-gradient chain, clip + Adam) runs on a HIGH-priority stream,
-# the weight-gradient GEMMs that run beside it on a normal-priority one (the chip has two levels: 0 and -1): when both have
-# workgroups to place, the chain's kernels get the CUs first and the weight gradients fill what they leave -- 17.50 -> 17.33 ms
-# per step on one box, two A/B pairs (profiles/r04o_*).  BUGLAB_STEP_STREAM_PRIORITY=0 keeps the caller's stream.
-_step_streams = {}
-
-
-def use_step_stream(device=None):
-    """Make a high-priority stream the current stream of this thread (once per device; later calls re-select it).  Work queued on
-    the previous current stream is waited for.  -> the stream, or None when switched off / no GPU."""
-    if not torch.cuda.is_available() or os.environ.get("BUGLAB_STEP_STREAM_PRIORITY", "-1") == "0":
-        return None
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if dev.type != "cuda":
-        return None
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _step_streams.get(key)
-    if st is None:
-        st = _step_streams[key] = torch.cuda.Stream(dev, priority=int(os.environ.get("BUGLAB_STEP_STREAM_PRIORITY", "-1")))
-    cur = torch.cuda.current_stream(dev)
-    if cur != st:
-        st.wait_stream(cur)
-        torch.cuda.set_stream(st)
-    return st
-
-
-def join_side_stream():
-    """Make the current stream wait for every weight-gradient GEMM still running on the side stream.  What those GEMMs
-    read is released only now, i.e. behind the wait in this stream's order: the allocator may hand the blocks to the next
-    step at once (with `record_stream` instead they stayed unusable until their events completed, and a run settled
-    at ~100 GiB reserved for a 6 GiB peak)."""
-    global _free_running
-    if torch.cuda.is_available():
-        key = torch.cuda.current_device()
-        if key in _side_streams:
-            torch.cuda.current_stream().wait_stream(_side_streams[key])
-    _held_for_side_stream.clear()
-    _free_running = False
-
-
-def _opted_in_for_direct_grad(param) -> bool:
-    """THE CONTRACT of direct gradient accumulation (every Function of this module that owns parameters: the message-passing
-    layers, gather_linear, mlp_score, localization_scores, rowdot, the relational attention's bias tables): a parameter
-    whose owner set `param._bl_direct_grad = True` and bound `param.grad` to a preallocated fp32 buffer (FlatAdam does both for
-    the parameters it owns, zeroing the flat buffer in zero_grad()) gets its gradient ADDED INTO `param.grad` by the kernels,
-    and backward returns None for it.  Consequences: `torch.autograd.grad(...)` sees no gradient for such a parameter and
-    tensor hooks registered on it would never fire -- so a parameter that has hooks (or post-accumulate-grad hooks) is treated
-    as not opted in and receives its gradient through autograd as usual.  Parameters without the flag always take that
-    path."""
-    if not (DIRECT_PARAM_GRAD and getattr(param, "_bl_direct_grad", False)):
-        return False
-    if getattr(param, "_backward_hooks", None) or getattr(param, "_post_accumulate_grad_hooks", None):
-        return False
-    return True
-
-
-def _direct_small(param):
-    """.grad of a small (bias / LayerNorm) parameter when the kernels may accumulate into it directly
-    (FlatAdam's flat gradient buffer): no zero-fill, no autograd accumulation kernel.  Contract: _opted_in_for_direct_grad."""
-    g = getattr(param, "grad", None)
-    if _opted_in_for_direct_grad(param) and g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
-        return g
-    return None
-
-
-def _direct_grad_target(param):
-    g = getattr(param, "grad", None)
-    if (USE_SIDE_STREAM and _opted_in_for_direct_grad(param) and g is not None and g.is_cuda
-            and g.dtype == torch.float32 and g.is_contiguous()):
-        return g
-    return None
-
-
-class _on_side_stream:
-    def __init__(self, device):
-        self.enabled = USE_SIDE_STREAM
-        if self.enabled:
-            key = torch.cuda.current_device()
-            if key not in _side_streams:
-                _side_streams[key] = _new_side_stream()
-            self.side = _side_streams[key]
-            self.main = torch.cuda.current_stream()
-
-    def __enter__(self):
-        global _overlap_depth
-        if self.enabled:
-            _overlap_depth += 1
-            self.side.wait_stream(self.main)
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.enabled:
-            self.ctx.__exit__(*exc)
-
-    def join(self):
-        global _overlap_depth
-        if self.enabled:
-            self.main.wait_stream(self.side)
-            _overlap_depth -= 1
-
-    def detach(self, *tensors):
-        """Leave the side-stream work running: the tensors it reads stay referenced until `join_side_stream()`."""
-        global _overlap_depth
-        if self.enabled:
-            _held_for_side_stream.extend(t for t in tensors if t is not None)
-            _overlap_depth -= 1
-
-
-# ------------------------------------------------------------------------------------------------
 # autograd wrappers
 def _take_saved(ctx):
     """What a Function's forward kept in `ctx.saved`, handed over ONCE: backward drops the references at once (activations are
@@ -1020,8 +559,7 @@ class _MpLayer(torch.autograd.Function):
             "bl_mp_scatter_grad")
         if W_direct is not None and Wd_direct is not None:
             # gradients land in param.grad behind the main chain; joined by join_side_stream()
-            global _free_running
-            _free_running = True
+            _streams.mark_free_running()
             side2.detach(h, gq, arg, bits, hp, gqp)
             side1.detach(ln_out, g_z)
             pair.__exit__(None, None, None)
@@ -1328,12 +866,7 @@ class _MpLayerFused(torch.autograd.Function):
         ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, ws_mode),), dtype=torch.uint8, device=dev)
         g_lo = torch.empty((N, w_lo), dtype=torch.float32, device=dev)
         g_hi = torch.empty((N, w_hi), dtype=torch.float32, device=dev) if w_hi else None
-        side = None
-        if USE_SIDE_STREAM:
-            key = torch.cuda.current_device()
-            if key not in _side_streams:
-                _side_streams[key] = _new_side_stream()
-            side = _side_streams[key]
+        side = _streams.side_stream_for_current_device()
         free_running = side is not None and direct[3] is not None and direct[4] is not None
         _check(lib.bl_mp_layer_bwd(ctypes.byref(L), out.data_ptr(), g_out.data_ptr(), _p(wnk), saved.data_ptr(), ws.data_ptr(),
                                    g_lo.data_ptr(), g_lo.stride(0), w_lo, _p(g_hi), g_hi.stride(0) if g_hi is not None else 0,
@@ -1342,9 +875,7 @@ class _MpLayerFused(torch.autograd.Function):
         if free_running:
             # the two weight-gradient GEMMs keep running behind the main chain (joined by join_side_stream()):
             # what they read must not be recycled by the allocator before they are done -- held until the join
-            global _free_running
-            _free_running = True
-            _held_for_side_stream.extend((saved, ws))
+            _streams.mark_free_running(saved, ws)
         ret = [None if d is not None else t for d, t in zip(direct, tgt)]
         if all(d is not None for d in direct):  # (gradients returned through autograd are not in place yet)
             _notify_backward_launched((W, ln_g, ln_b, Wd, bd))
@@ -1362,10 +893,6 @@ def set_grad_ready_callback(fn) -> None:
     global GRAD_READY_CALLBACK
     GRAD_READY_CALLBACK = fn
     _pending_uses.clear()
-
-
-def side_stream_if_any():
-    return _side_streams.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
 
 
 def _note_use(params) -> None:
@@ -2199,3 +1726,31 @@ def adam_clip_step_dp(param, grad, m, v, sqn, batch_total, *, clip=0.5, lr=1e-4,
                                             param.numel(), _p(sqn), _f32(batch_total).data_ptr(), float(clip), float(lr), float(beta1),
                                             float(beta2), float(eps), int(step), _stream()),
         "bl_adam_clip_step_dp")
+
+
+# ------------------------------------------------------------------------------------------------
+# Names whose one copy lives in a sub-module but that callers read / set on the package (bench.py, tests, tools):
+#   hip_ops.USE_SIDE_STREAM / DIRECT_PARAM_GRAD / SIDE_STREAM_PRIORITY -> _streams;  hip_ops.CALL_COUNT, hip_ops._lib (the CDLL
+#   handle: tools point it at a tuning build), hip_ops.LIB_PATH -> _lib
+_FORWARDED = {"USE_SIDE_STREAM": _streams, "DIRECT_PARAM_GRAD": _streams, "SIDE_STREAM_PRIORITY": _streams,
+              "CALL_COUNT": _lib_module, "_lib": _lib_module, "LIB_PATH": _lib_module}
+for _name in _FORWARDED:
+    globals().pop(_name, None)  # (`from ._lib import *` copied the values: the package must not hold stale ones)
+
+
+class _HipOpsModule(types.ModuleType):
+    def __getattr__(self, name):
+        owner = _FORWARDED.get(name)
+        if owner is None:
+            raise AttributeError(f"module {self.__name__!r} has no attribute {name!r}")
+        return getattr(owner, name)
+
+    def __setattr__(self, name, value):
+        owner = _FORWARDED.get(name)
+        if owner is not None:
+            setattr(owner, name, value)
+        else:
+            super().__setattr__(name, value)
+
+
+sys.modules[__name__].__class__ = _HipOpsModule
