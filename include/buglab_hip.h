@@ -430,6 +430,9 @@ int bl_prof_read(int32_t kind, double* ms, double* flop, int64_t* launches, int3
  * environment sets the initial value.  Returns the previous mode.  bl_mp_layer_weight_image then returns 2 (f16x3 image). */
 int32_t bl_set_msg_gemm_mode(int32_t f16x3);
 int32_t bl_get_msg_gemm_mode(void);
+/* packing threads that had to saturate a finite value at +-65504 since the last reset, on the current device (synchronises; -1 if
+ * the counter is unavailable): 0 in a healthy run -- the trainer checks it once per epoch (runtime/trainer.py). */
+int64_t bl_h3_saturation_events(int32_t reset);
 int bl_pack_f16x2(const float* x, int32_t ld, int64_t R, int32_t D, int32_t D_total, int32_t col_off, float scale,
                   const float* amax_dev, uint16_t* out, void* stream);
 int bl_amax(const float* x, int64_t n, float* amax_dev, void* stream);

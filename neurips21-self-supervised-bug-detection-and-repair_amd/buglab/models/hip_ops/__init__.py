@@ -150,6 +150,12 @@ def pack_f16x2(x: torch.Tensor, scale: float = H3_ROW_SCALE, amax: Optional[torc
     return out
 
 
+def h3_saturation_events(reset: bool = False) -> int:
+    """f16x2 packing threads that had to saturate a finite value since the last reset on the current device (synchronises): 0 in a
+    healthy run -- a layer input beyond +-255.9 or a weight beyond +-1023 would count (bl_h3_saturation_events)."""
+    return int(load_library().bl_h3_saturation_events(1 if reset else 0))
+
+
 def amax(x: torch.Tensor) -> torch.Tensor:
     """device float [1] = max |x| (bl_amax)"""
     _f32(x, "x")

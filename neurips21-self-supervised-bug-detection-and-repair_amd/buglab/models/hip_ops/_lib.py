@@ -146,6 +146,7 @@ _SIGNATURES = {
     "bl_rel_value_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_dropout_inplace": ([c_void_p, c_int64, bl_dropout_t, c_void_p], ctypes.c_int),
+    "bl_h3_saturation_events": ([c_int32], c_int64),
     "bl_pack_f16x2": ([c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_amax": ([c_void_p, c_int64, c_void_p, c_void_p], ctypes.c_int),
     "bl_packed_weight_elems_h3": ([c_int32, c_int32, c_int32], c_int64),

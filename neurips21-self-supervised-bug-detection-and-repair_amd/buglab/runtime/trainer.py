@@ -339,11 +339,27 @@ class ModelTrainer:
             it.close()  # a rank that stops before its loader is exhausted shuts the loader processes down
         metrics = nn.report_metrics()
         elapsed = time.time() - t0
+        self._check_f16x3_saturation(device, epoch)
         LOGGER.info("Epoch %s: %s steps, %.1f graphs/s (this rank). Train metrics: %s", epoch, step, num_graphs / max(elapsed, 1e-9), metrics)
         # where the epoch went on the host side: a large share of `input wait` means the loaders, not the device, set the pace
         self.last_epoch_timing = {"elapsed_s": elapsed, "steps": step, "first_minibatch_s": first_wait or 0.0, "input_wait_s": waited}
         LOGGER.info("Epoch %s timing: first minibatch after %.2f s, %.2f s of %.2f s blocked on input", epoch, first_wait or 0.0, waited, elapsed)
         return metrics
+
+    @staticmethod
+    def _check_f16x3_saturation(device, epoch) -> None:
+        """The f16x3 message GEMMs pack layer inputs and weights into fp16 planes with fixed power-of-two scales (hip_ops,
+        csrc/bl_gemm_h3.hip): a value beyond the range saturates instead of overflowing.  Once per epoch the device-side counter
+        of such events is read (one synchronising 4-byte copy) -- a healthy run has none; a diverging one should say so."""
+        if torch.device(device).type != "cuda":
+            return
+        from buglab.models import hip_ops
+
+        n = hip_ops.h3_saturation_events(reset=True)
+        if n > 0:
+            LOGGER.warning("Epoch %s: %s f16x2 packing threads saturated a value (a layer input beyond +-255.9 or a weight beyond +-1023): "
+                           "the f16x3 message GEMMs clipped it.  If the run is not diverging, train with the bf16x6 split "
+                           "(BL_MSG_GEMM=x6 / hip_ops.set_msg_gemm_mode('bf16x6')).", epoch, n)
 
     def _run_validation(self, validation_tensors, epoch, best_target_metric, device, parallelize, show_progress_bar):
         """-> (target metric, improved?)   (overridden by the reference's detector trainer,

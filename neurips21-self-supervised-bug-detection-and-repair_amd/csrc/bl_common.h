@@ -15,6 +15,8 @@ int bl_num_cus();  // bl_core.hip
 int bl_max_lds_per_block();  // bl_core.hip: LDS bytes a workgroup may declare on the current device
 // n zeroed turn counters for one launch on `stream`, or nullptr when the deterministic mode is off (bl_core.hip)
 unsigned* bl_order_counters(int n, void* stream);
+// per-device counter of f16x2 packing threads that had to saturate a value (csrc/bl_gemm_h3.hip); NULL if it cannot be allocated
+unsigned* bl_h3_sat_counter();
 
 // internal forms of two exported entry points with an extra bf16x3-packed output (csrc/bl_graph_ops.hip; used by the
 // fused layer calls, whose dense node-update GEMMs run as bf16x6)
@@ -154,8 +156,12 @@ __device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& m, uint16
 // (|x| >= 2^-3); below that the error is absolute, <= 2^-25.  The caller has multiplied x by the tensor's power-of-two scale.
 // A finite value beyond fp16's range saturates at +-65504; +-inf / NaN: hi = x's fp16 image, lo = 0 (inf - inf would be NaN
 // anyway: the product is NaN or inf either way, as in split3).
-__device__ __forceinline__ void split2h(float x, uint16_t& h, uint16_t& l) {
-  if (fabsf(x) > 65504.f && fabsf(x) <= 3.402823466e38f) x = copysignf(65504.f, x);
+// sat is SET (never cleared) when a finite value was clamped: the packers count those events (bl_h3_saturation_events).
+__device__ __forceinline__ void split2h(float x, uint16_t& h, uint16_t& l, bool& sat) {
+  if (fabsf(x) > 65504.f && fabsf(x) <= 3.402823466e38f) {
+    x = copysignf(65504.f, x);
+    sat = true;
+  }
   const _Float16 hh = (_Float16)x;  // round to nearest even
   h = __builtin_bit_cast(uint16_t, hh);
   if ((h & 0x7C00u) == 0x7C00u) {  // inf / NaN

@@ -57,7 +57,8 @@ __device__ __forceinline__ float h3_scale_from_amax(float amax) {
 // rows: out[r][plane][kg][j] = plane(x[r, 8 kg + j] * scale), planes back to back (row = 2 D halves)
 // (kg_total, kg_off) as in pack_rows_kernel: a ConcatResidual pair is packed without a concatenated copy
 __global__ __launch_bounds__(256) void pack_rows_h_kernel(const float* __restrict__ x, int ld, long long R, int D, uint4* __restrict__ out,
-                                                          int kg_total, int kg_off, float scale, const float* __restrict__ amax_dev) {
+                                                          int kg_total, int kg_off, float scale, const float* __restrict__ amax_dev,
+                                                          unsigned* __restrict__ sat_counter) {
   const int kgs = D >> 3;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= R * kgs) return;
@@ -70,8 +71,10 @@ __global__ __launch_bounds__(256) void pack_rows_h_kernel(const float* __restric
   const float4 b = *reinterpret_cast<const float4*>(x + r * ld + 8 * kg + 4);
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   uint16_t h[8], l[8];
+  bool sat = false;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) split2h(v[j] * scale, h[j], l[j]);
+  for (int j = 0; j < 8; ++j) split2h(v[j] * scale, h[j], l[j], sat);
+  if (sat && sat_counter) atomicAdd(sat_counter, 1u);  // (rare by construction: the scales leave 2^6 - 2^8 of headroom)
   uint4* o = out + r * 2 * kgn + kg;
 #define PK(a_, b_) ((uint32_t)(a_) | ((uint32_t)(b_) << 16))
   o[0] = make_uint4(PK(h[0], h[1]), PK(h[2], h[3]), PK(h[4], h[5]), PK(h[6], h[7]));
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(256) void pack_rows_h_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void pack_weights_h_kernel(const float* __restrict__ w, int G, int K, int N, int w_is_kn,
-                                                             uint4* __restrict__ out, float scale) {
-  pack_weights_h_thread(w, G, K, N, w_is_kn, out, (long long)blockIdx.x * blockDim.x + threadIdx.x, scale);
+                                                             uint4* __restrict__ out, float scale, unsigned* __restrict__ sat_counter) {
+  pack_weights_h_thread(w, G, K, N, w_is_kn, out, (long long)blockIdx.x * blockDim.x + threadIdx.x, scale, sat_counter);
 }
 
 // ---- row GEMM --------------------------------------------------------------------------------------
@@ -410,6 +413,30 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
 }
 
+// ---- saturation events ----------------------------------------------------------------------------------
+// One unsigned per device, allocated on first use and never freed (like the ordered-flush ring of bl_core.hip): a packing thread
+// that had to clamp a finite value to +-65504 adds 1.  The fixed scales leave 2^6 - 2^8 of headroom over every bounded tensor, so a
+// non-zero count means a layer input beyond +-255.9 or a weight beyond +-1023 -- a diverging run, or a model this split does not fit.
+unsigned* bl_h3_sat_counter() {
+  static unsigned* ctr[BL_MAX_DEVICES] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BL_MAX_DEVICES) return nullptr;
+  if (ctr[dev] == nullptr) {
+    if (hipMalloc((void**)&ctr[dev], sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(ctr[dev], 0, sizeof(unsigned)) != hipSuccess) return nullptr;
+  }
+  return ctr[dev];
+}
+
+// number of saturation events on the current device since the last reset (synchronises the device); -1 if unavailable
+extern "C" int64_t bl_h3_saturation_events(int32_t reset) {
+  unsigned* c = bl_h3_sat_counter();
+  unsigned v = 0;
+  if (c == nullptr || hipMemcpy(&v, c, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (reset && hipMemset(c, 0, sizeof(unsigned)) != hipSuccess) return -1;
+  return (int64_t)v;
+}
+
 // ================================================================================================
 extern "C" int bl_pack_f16x2(const float* x, int32_t ld, int64_t R, int32_t D, int32_t D_total, int32_t col_off, float scale,
                              const float* amax_dev, uint16_t* out, void* stream) {
@@ -420,7 +447,7 @@ extern "C" int bl_pack_f16x2(const float* x, int32_t ld, int64_t R, int32_t D, i
   BL_CHECK_ARG(scale > 0.f, "bl_pack_f16x2: scale must be positive (a power of two)");
   const long long total = (long long)R * (D / 8);
   hipLaunchKernelGGL(pack_rows_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, (long long)R, D,
-                     reinterpret_cast<uint4*>(out), D_total / 8, col_off / 8, scale, amax_dev);
+                     reinterpret_cast<uint4*>(out), D_total / 8, col_off / 8, scale, amax_dev, bl_h3_sat_counter());
   BL_LAUNCH_CHECK("bl_pack_f16x2");
   return BL_OK;
 }
@@ -444,7 +471,7 @@ extern "C" int bl_pack_weights_h3(const float* w, int32_t G, int32_t K, int32_t 
   BL_CHECK_ARG(K > 0 && K % 32 == 0 && N > 0 && scale > 0.f, "bl_pack_weights_h3: K must be a multiple of 32 (got %d), scale positive", K);
   const long long total = (long long)G * ((N + 127) / 128) * (K / 32) * 512;
   hipLaunchKernelGGL(pack_weights_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, G, K, N, w_is_kn,
-                     reinterpret_cast<uint4*>(out), scale);
+                     reinterpret_cast<uint4*>(out), scale, bl_h3_sat_counter());
   BL_LAUNCH_CHECK("bl_pack_weights_h3");
   return BL_OK;
 }

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 //   kind 0 / 1: bl_pack_weights_x6 with w_is_kn = kind;  kind 2: out[g][n][k] = w[g][k][n] in fp32 (W transposed, the
 //   operand of bl_routed_dgrad_nodes);  kind 3 / 4: bl_pack_weights_x6w (the wide row GEMM's image) with w_is_kn = kind - 3;
 //   kind 5 / 6: bl_pack_weights_h3 (the f16x3 image) with w_is_kn = kind - 5.
-__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_job_t* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_job_t* __restrict__ jobs, int njobs,
+                                                                 unsigned* __restrict__ h3_sat_counter) {
   int j = 0;
   while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;  // (a few dozen jobs: a linear walk of a cached table)
   const bl_pack_job_t job = jobs[j];
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const bl_pack_j
   if (job.kind <= 1) {
     pack_weights_thread(job.w, job.G, job.K, job.N, job.kind, reinterpret_cast<uint4*>(job.out), t);
   } else if (job.kind >= 5) {  // 5 / 6: bl_pack_weights_h3 (the f16x3 image, scale BL_H3_W_SCALE) with w_is_kn = kind - 5
-    pack_weights_h_thread(job.w, job.G, job.K, job.N, job.kind - 5, reinterpret_cast<uint4*>(job.out), t, BL_H3_W_SCALE);
+    pack_weights_h_thread(job.w, job.G, job.K, job.N, job.kind - 5, reinterpret_cast<uint4*>(job.out), t, BL_H3_W_SCALE, h3_sat_counter);
   } else if (job.kind >= 3) {
     pack_weights_wide_thread(job.w, job.G, job.K, job.N, job.kind - 3, reinterpret_cast<uint4*>(job.out), t);
   } else {
@@ -821,7 +822,8 @@ extern "C" int64_t bl_pack_job_blocks(int32_t kind, int32_t G, int32_t K, int32_
 extern "C" int bl_pack_weights_multi(const bl_pack_job_t* jobs_device, int32_t njobs, int32_t total_blocks, void* stream) {
   if (njobs == 0 || total_blocks == 0) return BL_OK;
   BL_CHECK_ARG(jobs_device && njobs > 0 && total_blocks > 0, "bl_pack_weights_multi: bad arguments");
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs,
+                     bl_h3_sat_counter());
   BL_LAUNCH_CHECK("bl_pack_weights_multi");
   return BL_OK;
 }

@@ -420,10 +420,17 @@ def test_gemm_rows_f16x3_is_fp32_accurate(ops, Din, Dm, sizes):
     err6 = (x6.cpu().double() - ref).abs().max()
     print(f"f16x3 {float(err):.2e}  bf16x6 {float(err6):.2e}  exact fp32 MFMA {float(err32):.2e}")
     assert err < 2e-5 and err < 4 * err32 + 1e-6, (float(err), float(err32))
-    # saturation instead of inf, NaN propagation
+    # saturation instead of inf, NaN propagation -- and the events are counted on the device (the trainer reads the counter per epoch)
+    hp = ops.pack_f16x2(_dev(h), ops.H3_ROW_SCALE)
+    ops.h3_saturation_events(reset=True)
+    ops.pack_f16x2(_dev(h), ops.H3_ROW_SCALE), ops.pack_weights_h3(_dev(W), True)
+    assert ops.h3_saturation_events() == 0  # the operands above fit
     wild = torch.tensor([[1e30, -1e30, float("nan"), 3.0e2] + [0.0] * (Din - 4)])
     wp = _unpack_f16x2(ops.pack_f16x2(_dev(wild), ops.H3_ROW_SCALE), Din)[0]
     assert wp[0] == 65504.0 and wp[1] == -65504.0 and torch.isnan(wp[2]) and wp[3] == 65504.0  # (300 x 256 > 65504: saturated)
+    assert ops.h3_saturation_events(reset=True) == 1 and ops.h3_saturation_events() == 0  # one packing thread (8 values) clamped
+    ops.pack_weights_h3(_dev(torch.full((1, 32, 128), 2000.0)), True)  # weights beyond +-1023
+    assert ops.h3_saturation_events(reset=True) == 32 * 128 // 8
 
 
 @pytest.mark.parametrize("Din,Dm,sizes", [(32, 64, [130, 0, 1, 700, 64]), (128, 128, [2100, 5, 300]), (64, 256, [129, 128, 1500]),

@@ -252,6 +252,48 @@ def test_baseline_graph_size_matches_fp64_oracle(H, degree, B, placement):
     print(f"H={H} {degree} B={B} {placement}: {flips} near-tie routing differences out of {total} (node, channel) entries")
 
 
+def test_training_trajectories_of_the_two_message_gemm_splits_agree():
+    """Thirty optimiser steps (dropout on, clip + Adam) with the message GEMMs as f16x3 and as bf16x6 from the same initial weights:
+    two fp32-accurate evaluations of the same products give the same loss curve (a near-tie of the routed max may flip between
+    them: 1e-3), the loss goes down, and the f16x2 packers never had to saturate a value."""
+    from buglab.data.collate import to_device
+    from buglab.models import hip_ops
+    from buglab.runtime.optim import FlatAdam
+
+    cfg, _, mb_np = Hh.make_case(B=4, n=300, E=1500, T=8, H=128, layers=8, vocab=400, C=10, dropout=0.2, seed=31)
+    mb = to_device(mb_np, "cuda")
+    params = O.init_params(cfg, seed=0)
+    curves = {}
+    hip_ops.h3_saturation_events(reset=True)
+    for mode in ("f16x3", "bf16x6"):
+        prev = hip_ops.set_msg_gemm_mode(mode)
+        try:
+            module = Hh.build_module_like(cfg, params).train()
+            opt = FlatAdam(module.parameters(), lr=1e-3, num_warmup_steps=0)
+            curve = []
+            for step in range(30):
+                opt.zero_grad()
+                loss = module(**mb, dropout_seed=1000 + step)
+                loss.backward()
+                opt.step()
+                curve.append(float(loss.detach()))
+            curves[mode] = curve
+        finally:
+            hip_ops.set_msg_gemm_mode(prev)
+    a, b = np.array(curves["f16x3"]), np.array(curves["bf16x6"])
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    # Adam's first steps move every coordinate by ~lr * sign(g): coordinates with |g| at rounding level amplify ANY two evaluations'
+    # differences (1e-7) into 1e-3-sized parameter differences, so the curves agree statistically, not digit for digit: step 0 is
+    # equal to 1e-5, later steps within 10 % (+ 0.02) -- two runs of the SAME split differ by a few per cent mid-curve too (fp32
+    # atomics order the weight-gradient sums differently from run to run) --, the final losses within 10 %
+    assert abs(a[0] - b[0]) < 1e-5 and abs(a[1] - b[1]) < 1e-3, (a[:2], b[:2])
+    worst = int(np.argmax(np.abs(a - b) - 0.10 * np.maximum(a, b)))
+    assert (np.abs(a - b) <= 0.10 * np.maximum(a, b) + 0.02).all(), (worst, a[worst], b[worst])
+    assert abs(a[-1] - b[-1]) <= 0.10 * max(a[-1], b[-1]) + 0.005, (a[-1], b[-1])
+    assert a[-5:].mean() < a[:5].mean() - 0.05
+    assert hip_ops.h3_saturation_events(reset=True) == 0
+
+
 def test_no_buggy_graphs_and_empty_edge_types():
     """Zero-length repair heads (reference gnn.py:261-293 zero-length branches) and edge types
     with no edges at all."""
