@@ -33,6 +33,7 @@ MFMA_X6_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 # peak equals the bf16 one's): ceiling = peak / 3.
 MFMA_H3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0
+REF_SCLK_MHZ, CLOCK_EXPONENT = 2250.0, 0.4  # box.value_at_ref_sclk (calibrate_rooflines)
 
 
 # rocprofv3 kernel names of the timed GEMM kinds (for the committed PMC traffic file)
@@ -180,6 +181,12 @@ def calibrate_rooflines(box, roof, also, per_gpu_rate):
     for entry in (also or {}).values():
         one(entry.get("roofline"))
     box["value_per_calibrated_pflops"] = round(per_gpu_rate / (box["mfma_calib_tflops"] / 1e3), 1)
+    # the headline at a reference step clock: the step's kernels follow the shader clock with an exponent of ~0.4 (round 5 measured
+    # 7.6 % more clock -> 2.9 % less GEMM time, profiles/r05x_mixed_clock.log; four boxes of round 6 with a 2.4 % raw spread agree to
+    # 1.2 % this way)
+    if box.get("sclk_mhz_step"):
+        box["ref_sclk_mhz"] = REF_SCLK_MHZ
+        box["value_at_ref_sclk"] = round(per_gpu_rate * (REF_SCLK_MHZ / box["sclk_mhz_step"]) ** CLOCK_EXPONENT, 1)
     box["mfma_calib_frac_of_paper_peak"] = round(box["mfma_calib_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)
     box["hbm_calib_frac_of_paper_peak"] = round(1e3 * box["hbm_calib_tbs"] / HBM_PEAK_GBS, 4)
 

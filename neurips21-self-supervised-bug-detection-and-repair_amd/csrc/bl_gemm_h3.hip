@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_h3_kernel(
   }
 }
 
+
 // ---- weight-gradient GEMM (128 x 128 tile) ---------------------------------------------------------
 // gW_g[i, n] += out_scale * sum_{e in group g} A[e, i] * Gr[e, n]   (bl_gemm_x6.hip::gemm_wgrad_x6_kernel with two planes:
 // operands stored in LDS as they arrive, [plane][message][feature] rows of 320 B, fragments by ds_read_b64_tr_b16)
