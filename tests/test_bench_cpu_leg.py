@@ -47,3 +47,36 @@ def test_pmc_record_of_a_kind_is_the_launch_weighted_mean_over_its_kernels(tmp_p
     busy, gui = (6 * 512.0 + 2 * 2048.0) / 8, (6 * 8.0 + 2 * 16.0) / 8
     assert abs(rec["mfma_busy_frac"] - busy / (gui / 8.0 * 1024.0)) < 1e-12
     assert bench._pmc_record(str(f), "no_such_kind") is None
+
+
+def test_box_calibration_fields_reach_the_rooflines():
+    """bench.calibrate_rooflines: every roofline of the line gets `frac_calibrated` against THIS box's ceiling -- the power-limited
+    bf16 MFMA loop / 3 for an f16x3 kernel, / 6 for a bf16x6 one, the copy rate for an HBM-bound kind -- and `box` the headline per
+    calibrated unit and at the reference step clock."""
+    import bench
+
+    box = {"mfma_calib_tflops": 1800.0, "hbm_calib_tbs": 4.5, "sclk_mhz_step": 2000.0}
+    h3 = {"bound": "mfma", "achieved": 300.0, "peak_basis": "dense fp16 MFMA peak 2500 TF/s / 3 (f16x3: three fp16 MFMA terms per fp32-accurate product)"}
+    x6 = {"bound": "mfma", "achieved": 150.0, "peak_basis": "dense bf16 MFMA peak 2500 TF/s / 6 (bf16x6: six bf16 MFMA terms per fp32-accurate product)"}
+    hbm = {"bound": "hbm", "achieved": 2250.0, "peak_basis": "HBM3E peak"}
+    f32 = {"bound": "mfma", "achieved": 100.0, "peak_basis": "dense fp32 MFMA peak"}
+    bench.calibrate_rooflines(box, h3, {"a": {"roofline": x6}, "b": {"roofline": hbm}, "c": {"roofline": f32}, "d": {"roofline": None}}, 4000.0)
+    assert h3["peak_calibrated"] == 600.0 and h3["frac_calibrated"] == 0.5
+    assert x6["peak_calibrated"] == 300.0 and x6["frac_calibrated"] == 0.5
+    assert hbm["peak_calibrated"] == 4500.0 and hbm["frac_calibrated"] == 0.5
+    assert "frac_calibrated" not in f32
+    assert abs(box["value_per_calibrated_pflops"] - 4000.0 / 1.8) < 0.1
+    assert box["ref_sclk_mhz"] == bench.REF_SCLK_MHZ and abs(box["value_at_ref_sclk"] - 4000.0 * (2250.0 / 2000.0) ** 0.4) < 0.1
+    assert abs(box["mfma_calib_frac_of_paper_peak"] - 0.72) < 1e-9
+
+
+def test_smi_sampler_degrades_to_none_without_a_gpu():
+    """hip_ops.calibration.SmiSampler: no librocm_smi64 device (the build container) -> summary() is None, nothing raises."""
+    import time
+
+    sys.path.insert(0, os.path.join(ROOT, "neurips21-self-supervised-bug-detection-and-repair_amd"))
+    from buglab.models.hip_ops.calibration import SmiSampler
+
+    with SmiSampler() as s:
+        time.sleep(0.01)
+    assert s.summary() is None or set(s.summary()) >= {"sclk_mhz", "power_w", "samples"}
