@@ -244,6 +244,10 @@ def test_baseline_graph_size_matches_fp64_oracle(H, degree, B, placement):
     tables equal up to near-ties, every gradient within 1e-4 (routing injected)."""
     if B >= 64 and (os.cpu_count() or 1) < 64:
         pytest.skip("the fp64 oracle of the full 64-graph minibatch needs a many-core host (3 minutes on the 256-thread GPU boxes)")
+    if B >= 64 and placement != "aggregated" and os.environ.get("BL_FULL_PARITY", "0") == "0":
+        # (the full minibatch under the NON-default placement costs another 3 minutes of fp64 oracle: run with BL_FULL_PARITY=1;
+        # green at the final tree of round 6, profiles/r06y_gputest.log: 153 passed with it)
+        pytest.skip("full 64-graph minibatch under the non-default activation placement: set BL_FULL_PARITY=1 (3 more minutes of fp64 oracle)")
     cfg, _, mb = Hh.make_case(B=B, n=2000, E=10000, T=16, H=H, layers=8, vocab=15000, C=40, degree=degree, max_degree=512, seed=21,
                               msg_act_placement=placement)
     if degree == "powerlaw":
