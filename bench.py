@@ -99,6 +99,35 @@ def algorithmic_work_per_graph(H, layers, N, E, T, B):
     return flop, byts
 
 
+def message_gemm_bytes_per_step(H, layers, N, E, T, packed_bytes_per_elem):
+    """Algorithmic HBM bytes per training step of the three message-GEMM kinds (operands read once, results written once), summed
+    over the layers: packed rows of the layer input / of the node gradient (`packed_bytes_per_elem`: 4 for f16x2, 6 for bf16x3),
+    the per-type weights, the index arrays, the routing bitmask, and the fp32 result -- [E, Dm] pre-activations (forward),
+    [E, 2 Din] input-gradient rows (routed input gradient), [T, 2 Din, Dm] weight gradient."""
+    out = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    for li in range(layers):
+        din, dm = (2 * H, 2 * H) if li % 4 == 3 else (H, H)
+        w = 4.0 * T * 2 * din * dm
+        out["fwd"] += packed_bytes_per_elem * N * din + w + 8.0 * E + 4.0 * E * dm
+        out["dgrad"] += packed_bytes_per_elem * N * dm + w + 4.0 * E + E * dm / 8.0 + 4.0 * E * 2 * din
+        out["wgrad"] += packed_bytes_per_elem * N * (din + dm) + 12.0 * E + E * dm / 8.0 + w
+    return out
+
+
+def attach_message_gemm_bytes(kern, a, prof_steps):
+    """gives the message-GEMM kinds of a profile table their algorithmic bytes, so that build_roofline can price them against BOTH
+    ceilings and report the one that binds (with f16x3 the routed input gradient -- 57 FLOP/B -- is below the 104 FLOP/B ridge)"""
+    if getattr(a, "model", "gnn-mlp") != "gnn-mlp":
+        return kern
+    for split, per_elem in (("h3", 4.0), ("x6", 6.0)):
+        by = message_gemm_bytes_per_step(a.hidden, a.layers, a.nodes * a.graphs, a.messages * a.graphs, a.types, per_elem)
+        for kind, key in ((f"msg_gemm_{split}", "fwd"), (f"msg_dgrad_{split}", "dgrad"), (f"msg_wgrad_{split}", "wgrad")):
+            # (only when the kind ran for every layer: in bf16x6 mode the vector-unit path takes six of the eight input gradients)
+            if kind in kern and kern[kind]["launches"] == prof_steps * a.layers:
+                kern[kind]["alg_bytes"] = by[key] * prof_steps
+    return kern
+
+
 def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, fwd_flop, fwd_bytes, brief=False):
     """The `roofline` object of a bench line from the HIP-event tables of the profiling passes (hip_ops.KernelTimer).
     Dominant kernel = largest EXCLUSIVE time per step among the MFMA GEMM kinds of the serial pass (msg_dgrad_nodes runs
@@ -110,10 +139,22 @@ def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, 
         return None
     dom = max(gemm, key=lambda k: gemm[k]["ms"])
     d = kern[dom]
-    hbm = d.get("bytes", 0) > 0
-    achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if hbm else d["flop"] / (d["ms"] * 1e-3) / 1e12
     x6, h3 = "x6" in dom, "h3" in dom
-    peak = HBM_PEAK_GBS if hbm else (MFMA_H3_PEAK_TFLOPS if h3 else MFMA_X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS)
+    mfma_peak = MFMA_H3_PEAK_TFLOPS if h3 else MFMA_X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS
+    hbm = d.get("bytes", 0) > 0
+    both = None
+    if not hbm and d["flop"] > 0 and d.get("alg_bytes", 0) > 0:
+        # a GEMM kind with known algorithmic bytes: the ceiling that binds is the one whose minimum time is larger
+        t_mfma, t_hbm = d["flop"] / (mfma_peak * 1e12), d["alg_bytes"] / (HBM_PEAK_GBS * 1e9)
+        both = {"flop_per_byte": round(d["flop"] / d["alg_bytes"], 1), "ridge_flop_per_byte": round(mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
+                "frac_of_mfma_ceiling": round(d["flop"] / (d["ms"] * 1e-3) / 1e12 / mfma_peak, 4),
+                "frac_of_hbm_ceiling": round(d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": round(d["alg_bytes"] / d["launches"])}
+        if t_hbm > t_mfma:
+            hbm = True
+            d = dict(d, bytes=d["alg_bytes"])
+    achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if hbm else d["flop"] / (d["ms"] * 1e-3) / 1e12
+    peak = HBM_PEAK_GBS if hbm else mfma_peak
     traffic, traffic_src = measured_traffic(dom)
     per_step = lambda table: {k: {"ms_per_step": round(v["ms"] / prof_steps, 3),
                                   **({"tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flop"] > 0 and v["ms"] > 0 else {}),
@@ -130,6 +171,7 @@ def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, 
                        if x6 else "dense fp32 MFMA peak"),
         "unit": "GB/s" if hbm else "TFLOP/s",
         "frac": round(achieved / peak, 4),
+        **({"both_ceilings": both} if both else {}),
         **({} if hbm else {"frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                             "frac_of_bf16x6_ceiling": round(achieved / MFMA_X6_PEAK_TFLOPS, 4)}),
         "avg_launch_ms": round(d["ms"] / d["launches"], 4),
@@ -495,7 +537,8 @@ def main():
         rate_ = a.graphs * world * args.steps / el_
         return {"value": round(rate_, 2), "unit": unit, "ms_per_step": round(1e3 * el_ / args.steps, 3),
                 "per_gpu": a.graphs, "n_gpus": world,
-                "roofline": build_roofline(kern_, {}, prof_steps, serial_s_, rate_ / world, *fwd_work(a), brief=True)}
+                "roofline": build_roofline(attach_message_gemm_bytes(kern_, a, prof_steps), {}, prof_steps, serial_s_, rate_ / world, *fwd_work(a),
+                                           brief=True)}
 
     if not args.default_stream:
         hip_ops.use_step_stream(device)  # what ModelTrainer.train does before its first step
@@ -600,7 +643,8 @@ def main():
         total_graphs = args.graphs * world * args.steps
         fwd_flop, fwd_bytes = fwd_work(args)
         value = total_graphs / elapsed
-        roof = build_roofline(kern, kern_overlap, prof_steps, serial_step_s, value / world, fwd_flop, fwd_bytes)
+        roof = build_roofline(attach_message_gemm_bytes(kern, args, prof_steps), kern_overlap, prof_steps, serial_step_s, value / world,
+                              fwd_flop, fwd_bytes)
         if box is not None:
             calibrate_rooflines(box, roof, also, value / world)
         line = {

@@ -80,3 +80,26 @@ def test_smi_sampler_degrades_to_none_without_a_gpu():
     with SmiSampler() as s:
         time.sleep(0.01)
     assert s.summary() is None or set(s.summary()) >= {"sclk_mhz", "power_w", "samples"}
+
+
+def test_roofline_reports_the_ceiling_that_binds():
+    """A GEMM kind with known algorithmic bytes is priced against both ceilings; `bound` names the one whose minimum time is larger.
+    With f16x3 (833 TF/s) the routed input gradient of configs[1] (80 FLOP/B) is below the 104 FLOP/B ridge: HBM-bound."""
+    import bench
+
+    a = argparse.Namespace(model="gnn-mlp", hidden=128, layers=8, nodes=2000, messages=10000, graphs=64, types=16)
+    flop = sum(2.0 * 640000 * (2 * d) * d for d in [128] * 6 + [256] * 2)
+    kern = {"msg_dgrad_h3": {"launches": 8, "ms": 2.8, "flop": flop, "overlapped": False},
+            "msg_wgrad_h3": {"launches": 8, "ms": 2.0, "flop": flop, "overlapped": False},
+            "segment_max_ln": {"launches": 8, "ms": 1.6, "flop": 0.0, "overlapped": False}}
+    kern = bench.attach_message_gemm_bytes(kern, a, 1)
+    assert abs(kern["msg_dgrad_h3"]["alg_bytes"] - 7.36e9) < 0.05e9 and abs(kern["msg_wgrad_h3"]["alg_bytes"] - 1.5e9) < 0.05e9
+    r = bench.build_roofline(kern, {}, 1, 0.014, 4800.0, 9.83e9, 19.5e6, brief=True)
+    assert r["kernel"] == "msg_dgrad_h3" and r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] - 7.36e9 / 2.8e-3 / 1e9) < 20 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    both = r["both_ceilings"]
+    assert both["flop_per_byte"] < both["ridge_flop_per_byte"] and both["frac_of_hbm_ceiling"] > both["frac_of_mfma_ceiling"]
+    # the weight gradient (390 FLOP/B) stays MFMA-bound
+    del kern["msg_dgrad_h3"]
+    r2 = bench.build_roofline(kern, {}, 1, 0.014, 4800.0, 9.83e9, 19.5e6, brief=True)
+    assert r2["kernel"] == "msg_wgrad_h3" and r2["bound"] == "mfma" and r2["peak"] == round(bench.MFMA_H3_PEAK_TFLOPS, 1)
