@@ -10,7 +10,11 @@
 One "step" = forward + backward + gradient all-reduce (N > 1) + clip + Adam on one minibatch of
 synthetic PyPI-shaped code graphs that is already resident in HBM.  Workload at every N (weak
 scaling): BASELINE.json configs[1] per GPU -- gnn-mlp, hidden 128, 8 MP layers, 16 edge types,
-64 graphs x (2000 nodes, 10000 messages), dropout 0.2, fp32.  Rank 0 prints ONE JSON line.
+64 graphs x (2000 nodes, 10000 messages), dropout 0.2, fp32.  Rank 0 prints ONE JSON line:
+the contract's fields + `roofline` (dominant kernel kind of a serial profiling pass, priced against the
+ceiling that binds), `box` (what this chip delivers: step clock / power, calibration kernels),
+`also` (configs[2] shard, the reference's 30 000-node regime, the other activation placement, the
+bf16x6 split, configs[4] seq-great), `cpu_baseline` (CPU oracle through ModelTrainer.train).
 """
 import argparse
 import json

@@ -494,6 +494,39 @@ def test_routed_gemms_f16x3_match_fp64(ops, Din, Dm, sizes):
     assert float((gw2.cpu().double() - ref2).abs().max()) < 4e-6 * float(ref2.abs().max())
 
 
+@pytest.mark.parametrize("magnitude", [0.0, 1e-30, 1e-12, 1.0, 1e12, 1e30])
+def test_f16x3_gradient_operand_scale_follows_any_magnitude(ops, magnitude):
+    """The gradient operand of the f16x3 GEMMs is packed with a scale derived on the device from its amax: results are equally
+    accurate RELATIVE to the tensor's size whether it is 1e-30 or 1e30 large (fp16's own range is 6e-8 ... 65504), an all-zero
+    gradient gives exact zeros, and nothing saturates."""
+    rng = np.random.default_rng(5)
+    N, E, Din, Dm, T = 64, 700, 64, 96, 2
+    h = torch.tanh(torch.randn(N, Din)) * 1.25
+    W = torch.randn(T, 2 * Din, Dm) / math.sqrt(2 * Din)
+    g = torch.randn(E, Dm) * magnitude
+    src, tgt = rng.integers(0, N, E).astype(np.int32), rng.integers(0, N, E).astype(np.int32)
+    ptr = np.array([0, 300, E], dtype=np.int32)
+    ops.h3_saturation_events(reset=True)
+    am = ops.amax(_dev(g))
+    gp = ops.pack_f16x2(_dev(g), 1.0, amax=am)
+    hp = ops.pack_f16x2(_dev(h), ops.H3_ROW_SCALE)
+    gw = torch.zeros(T, 2 * Din, Dm, device="cuda")
+    ops.gemm_wgrad_h3([(hp, _dev(src), Din), (hp, _dev(tgt), Din)], gp, E, Dm, gw, out_scale=1.0 / ops.H3_ROW_SCALE, g_amax=am,
+                      gw_group_stride=2 * Din * Dm, group_ptr=_dev(ptr), G=T)
+    dA = ops.gemm_rows_h3([(gp, None, Dm)], ops.pack_weights_h3(_dev(W), False), E, 2 * Din, out_scale=1.0 / ops.H3_W_SCALE, a_amax=am,
+                          group_ptr=_dev(ptr), G=T)
+    A = torch.cat([h[src.astype(np.int64)], h[tgt.astype(np.int64)]], -1).double()
+    ref_w = torch.stack([A[ptr[t]:ptr[t + 1]].T @ g[ptr[t]:ptr[t + 1]].double() for t in range(T)])
+    ref_a = torch.cat([g[ptr[t]:ptr[t + 1]].double() @ W[t].double().T for t in range(T)])
+    assert ops.h3_saturation_events(reset=True) == 0
+    if magnitude == 0.0:
+        assert float(am) == 0.0 and not gw.any() and not dA.any()
+        return
+    assert torch.isfinite(gw).all() and torch.isfinite(dA).all()
+    assert float((gw.cpu().double() - ref_w).abs().max()) < 4e-6 * float(ref_w.abs().max())
+    assert float((dA.cpu().double() - ref_a).abs().max()) < 4e-6 * float(ref_a.abs().max())
+
+
 @pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 256, 64), (130, 64, 96), (2500, 256, 160)])
 def test_dense_bf16x6_gemms_match_fp64(ops, M, K, N):
     """The dense node update on the bf16 matrix cores: bl_gemm_rows_x6_epi (bias + tanh + counter-hash dropout epilogue, the
