@@ -173,6 +173,35 @@ int bl_gemm_rows_x6w(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_
 int bl_gemm_rows_x6_epi(const bl_rows_packed_t* a, const uint16_t* bp, int64_t b_group_stride, const int32_t* group_ptr,
                         const int32_t* group_w, int32_t G, int32_t M, int32_t N, int32_t K, const float* bias, int32_t act,
                         bl_dropout_t drop, float* c, int32_t ldc, void* stream);
+/* Extended epilogues of the plain (one group) bf16x6 row GEMM: what the Linear layers of the relational transformer block
+ * (reference buglab/models/layers/relational_transformer.py:104-124, multihead_attention.py:27-35) hand to the next kernel
+ * without an elementwise pass in between (csrc/bl_great_layer.hip).
+ *   BL_X6_EPI_ACT        c = drop(act(A . B + bias)), fp32                                     (= bl_gemm_rows_x6_epi)
+ *   BL_X6_EPI_ACT_PACK   the same, written ONLY in bl_pack_bf16x3's form to c_packed [M, 3 N]  (act = relu: linear1 -> linear2)
+ *   BL_X6_EPI_RES        c = A . B + res[row, 0:N], fp32                    (input gradient + the residual branch's gradient)
+ *   BL_X6_EPI_MASK_PACK  c = (y != 0) ? A . B x mask_scale : 0 with y = drop(relu(z)) given by its packed form y_packed [M, 3 N]
+ *                        (only the hi plane is read: y != 0 <=> kept and z > 0), written only packed to c_packed;
+ *                        colsum[0:N] (optional) += the column sums of c (unordered atomics: not in deterministic mode)
+ *                        -- the gradient through dropout(relu(.)) of linear1, its bias gradient and the operand of its
+ *                        weight / input gradient GEMMs in the epilogue of linear2's input gradient. */
+#define BL_X6_EPI_ACT 0
+#define BL_X6_EPI_ACT_PACK 1
+#define BL_X6_EPI_RES 2
+#define BL_X6_EPI_MASK_PACK 3
+typedef struct {
+  int32_t form;
+  const float* bias; /* ACT forms: [N] or NULL */
+  int32_t act;
+  bl_dropout_t drop;
+  const float* res; /* RES */
+  int32_t ld_res;
+  const uint16_t* y_packed; /* MASK_PACK */
+  float mask_scale;
+  float* colsum;
+  uint16_t* c_packed; /* ACT_PACK, MASK_PACK */
+} bl_x6_epi_t;
+int bl_gemm_rows_x6_epi2(const bl_rows_packed_t* a, const uint16_t* bp, int32_t M, int32_t N, int32_t K, const bl_x6_epi_t* epi,
+                         float* c, int32_t ldc, void* stream);
 /* bf16x6 form of bl_gemm_wgrad_routed (below): `a` packed rows, g_node_packed = bl_pack_bf16x3 of the
  * node gradient [*, N]; the message-major operands are transposed on the fly by gfx950's transposing
  * LDS read (ds_read_b64_tr_b16).  N and the source widths must be multiples of 32. */
@@ -243,6 +272,15 @@ int bl_segment_max_bwd(const float* g_out, const int32_t* arg, const float* x, i
 int bl_layernorm_bwd(const float* g_y, const float* x, const float* mean, const float* rstd, const float* gamma,
                      int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta, const float* post_scale,
                      uint16_t* g_x_packed, void* stream);
+
+/* LayerNorm backward where the normalised tensor was  x + dropout(branch)  (the two sublayers of the relational transformer
+ * block, reference relational_transformer.py:104-124): g_x (fp32, unmasked) is the residual's gradient, and the BRANCH's
+ * gradient -- g_x through the dropout mask of the branch, element index row * D + d -- leaves in bl_pack_bf16x3's form
+ * (g_branch_packed [nrows, 3 D], the operand of the branch Linear's two gradient GEMMs) with its column sums added to
+ * g_bias (the Linear's bias gradient; may be NULL).  D a multiple of 8 up to 512.  branch_drop.p == 0: no mask. */
+int bl_layernorm_bwd_branch(const float* g_y, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta, bl_dropout_t branch_drop,
+                            float* g_bias, uint16_t* g_branch_packed, void* stream);
 
 /* activation(+dropout) backward from the OUTPUT y of y = drop(act(z + bias)); g_bias (if not NULL)
  * accumulates column sums of g_z with fp32 atomics.  g_z may alias g_y.  (GELU is not supported
@@ -405,6 +443,7 @@ int bl_prof_reset(void);
 int bl_prof_num_kinds(void);
 const char* bl_prof_kind_name(int32_t kind);
 int bl_prof_read(int32_t kind, double* ms, double* flop, int64_t* launches, int32_t* overlapped);
+double bl_prof_read_bytes(int32_t kind); /* algorithmic bytes recorded with a memory-bound kind's launches (0: none) */
 
 /* ---------------------------------------------------------------------------------------------
  * fp32-accurate GEMMs on the fp16 matrix cores ("f16x3", csrc/bl_gemm_h3.hip): the second operand split of the message-passing
@@ -597,6 +636,28 @@ int32_t bl_attn_mm32_ok(int32_t L, int32_t dk);
 int bl_attn_rows_times(const float* A, const float* M, int32_t G, int32_t L, int32_t dk, const float* add, float scale, float* out,
                        void* stream);
 int bl_attn_transposed_times(const float* A, const float* Bm, int32_t G, int32_t L, int32_t dk, float* out, void* stream);
+/* The same four kernels on HEAD VIEWS: a [B, H, L, dk] operand given by a base pointer and three strides (element (b, h, l, d) at
+ * p[b sb + h sh + l sl + d]; 16-byte aligned base, strides multiples of 4), so that q / k / v are read straight from the QKV
+ * projection's [B L, H 3 dk] output (per head [q | k | v], multihead_attention.py:46-50: p = qkv + which dk, sb = L 3 H dk,
+ * sh = 3 dk, sl = 3 H dk), the context is written as [B L, H dk] and the gradients land in the layout the projection's
+ * gradient GEMMs read -- no permuted copies.  q_scale / bm_scale multiply q where it is loaded (the reference's pre-scaled
+ * queries, multihead_attention.py:54: same rounding as a scaled copy).  P, Pd, dS, gq_edge, add stay [B H L, *] contiguous. */
+typedef struct {
+  float* p;
+  int64_t sb;
+  int32_t sh, sl;
+} bl_head_view_t;
+int bl_rel_attn_probs_fwd_v(const bl_head_view_t* q, float q_scale, const bl_head_view_t* k, const int32_t* row_ptr, const int32_t* ekey,
+                            const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, const float* bias_f,
+                            const float* bias_r, const int32_t* lens, bl_dropout_t drop, float* P, float* Pd, void* stream);
+int bl_rel_attn_probs_bwd_v(const bl_head_view_t* g_ctx, const bl_head_view_t* v, const float* P, const bl_head_view_t* q, float q_scale,
+                            const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk,
+                            int32_t T, const float* bias_f, const float* bias_r, bl_dropout_t drop, float* dS, float* gq_edge,
+                            float* g_bias_f, float* g_bias_r, void* stream);
+int bl_attn_rows_times_v(const float* A, const bl_head_view_t* M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add, float scale,
+                         const bl_head_view_t* out, void* stream);
+int bl_attn_transposed_times_v(const float* A, const bl_head_view_t* Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk,
+                               const bl_head_view_t* out, void* stream);
 /* `rat` edge value biases (relational_multihead_attention.py:155-178): ctx[b, h, i, :] += P[(b, h, i), key] * vb[code][h, :] */
 int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
                           int32_t dk, const float* P, const float* vb_f, const float* vb_r, float* ctx, void* stream);
@@ -605,6 +666,60 @@ int bl_rel_value_bias_bwd(const int32_t* row_ptr, const int32_t* ekey, const int
                           float* dP, float* g_vb_f, float* g_vb_r, void* stream);
 /* in-place counter-hash dropout (forward and backward are the same call) */
 int bl_dropout_inplace(float* x, int64_t n, bl_dropout_t drop, void* stream);
+
+/* bl_add_layernorm_fwd with a lane owning four consecutive channels (D a multiple of 4, 16-byte aligned pointers) and,
+ * if y_packed != NULL, the result also in bl_pack_bf16x3's form [nrows, 3 D]: the next Linear's operand without a packing pass */
+int bl_add_layernorm_fwd_packed(const float* x, const float* r, const float* gamma, const float* beta, float eps, int32_t nrows,
+                                int32_t D, float* z_out, float* y, float* mean, float* rstd, uint16_t* y_packed, void* stream);
+
+/* One relational transformer encoder layer per call (csrc/bl_great_layer.hip): reference
+ * buglab/models/layers/relational_transformer.py:104-124 in the configuration `seq-great` runs -- normalisation "postnorm"
+ * (both sublayers normalised by norm1, :123-124), rezero off, relu feed-forward, vector query edge bias
+ * (relational_multihead_attention.py:135-152), no edge value biases; head dimension 32.
+ *   x1  = norm1(x + dropout(out_proj(attention(qkv_proj(x)))))       out = norm1(x1 + dropout(linear2(dropout(relu(linear1(x1))))))
+ * Weights come packed (bl_pack_weights_x6 of the [in, out] matrices: w_is_kn = 1 for forward, the *_bwd images w_is_kn = 0 for the
+ * input-gradient GEMMs; NULL in a forward-only description).  Activations are [B L, *] row-major fp32; x_packed (optional) is
+ * bl_pack_bf16x3 of x -- the previous layer's out_packed -- and must stay alive until the backward call; out_packed (optional)
+ * receives the packed output.  Dropout counters as the op-by-op path (bl_gemm_rows_x6_epi / bl_rel_attn_probs_fwd): element
+ * index row * width + column of the tensor the mask applies to.
+ * bl_great_layer_ok: dk == 32, bl_rel_attn_probs_ok(L, dk, T), H dk and FF multiples of 32, H dk <= 512, fewer than 2^32 elements
+ * in any dropout index space, deterministic mode off. */
+typedef struct {
+  int32_t B, L, H, dk, T, FF;
+  const int32_t* row_ptr; /* edge CSR over query rows (bl_rel_attn_probs_fwd); all three NULL: no entries */
+  const int32_t* ekey;
+  const int32_t* ecode;
+  const int32_t* lens;  /* [B] */
+  const float* bias_f;  /* [T, H dk] */
+  const float* bias_r;
+  const float* norm_g;  /* [H dk] norm1 */
+  const float* norm_b;
+  const float* lin1_b;  /* [FF] */
+  const float* lin2_b;  /* [H dk] */
+  const uint16_t *qkv_w, *out_w, *lin1_w, *lin2_w;                 /* forward images */
+  const uint16_t *qkv_w_bwd, *out_w_bwd, *lin1_w_bwd, *lin2_w_bwd; /* input-gradient images */
+  float ln_eps;
+  bl_dropout_t drop_attn;      /* on the attention probabilities */
+  bl_dropout_t drop_att_out;   /* dropout1: on the attention branch */
+  bl_dropout_t drop_ff_hidden; /* inside the feed-forward block */
+  bl_dropout_t drop_ff_out;    /* dropout2: on the feed-forward branch */
+} bl_great_layer_t;
+/* gradient buffers, all ACCUMULATED into (fp32 atomics): zeroed buffers or the running gradients */
+typedef struct {
+  float *qkv_w, *out_w, *lin1_w, *lin1_b, *lin2_w, *lin2_b; /* [D, 3 D], [D, D], [D, FF], [FF], [FF, D], [D] */
+  float *norm_g, *norm_b;                                   /* [D] */
+  float *bias_f, *bias_r;                                   /* [T, D] (may be NULL without edge entries) */
+} bl_great_layer_grads_t;
+int32_t bl_great_layer_ok(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, int32_t FF);
+/* `saved` (forward -> backward; own_xp: the call packs x itself because no x_packed is handed in) and workspace bytes
+ * (backward: 0 = forward, 1 = backward, 3 = forward-only call with saved == NULL) */
+int64_t bl_great_layer_saved_bytes(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t FF, int32_t attn_dropout, int32_t own_xp);
+int64_t bl_great_layer_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t FF, int32_t backward);
+int bl_great_layer_fwd(const bl_great_layer_t* d, const float* x, const uint16_t* x_packed, float* out, uint16_t* out_packed, void* saved,
+                       void* ws, void* stream);
+/* side_stream (optional): the four weight-gradient GEMMs run there next to the input-gradient chain; joined before the call returns */
+int bl_great_layer_bwd(const bl_great_layer_t* d, const uint16_t* x_packed, const float* g_out, const void* saved, void* ws, float* g_x,
+                       const bl_great_layer_grads_t* g, void* stream, void* side_stream);
 
 /* ---------------------------------------------------------------------------------------------
  * T1  optimiser on flat fp32 buffers: global-norm clip (buglab/models/train.py:104, clip 0.5) fused

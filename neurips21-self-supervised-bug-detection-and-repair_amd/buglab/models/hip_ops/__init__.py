@@ -1650,6 +1650,94 @@ def rel_attention(qkv, lens, edges: RelEdges, bias_f, bias_r, vb_f, vb_r, B, L, 
                                bool(scalar_bias), drop)
 
 
+# ---- one relational transformer encoder layer per C call (csrc/bl_great_layer.hip) ----------------------------------------
+FUSED_GREAT_LAYER = os.environ.get("BL_FUSED_GREAT_LAYER", "1") != "0"  # A/B switch: 0 = the op-by-op path above
+
+
+def great_layer_ok(B: int, L: int, H: int, dk: int, T: int, FF: int) -> bool:
+    """Whether bl_great_layer_fwd / _bwd take the shape (the caller also checks the layer's configuration: postnorm, rezero
+    off, vector query bias, no value biases)."""
+    return bool(FUSED_GREAT_LAYER and LINEAR_X6 and GEMM_MODE == "bf16x6"
+                and load_library().bl_great_layer_ok(int(B), int(L), int(H), int(dk), int(T), int(FF)))
+
+
+def _great_desc(B, L, H, dk, T, FF, lens, edges: "RelEdges", bias_f, bias_r, norm_g, norm_b, lin1_b, lin2_b, packs, drops) -> bl_great_layer_t:
+    d = bl_great_layer_t()
+    d.B, d.L, d.H, d.dk, d.T, d.FF = int(B), int(L), int(H), int(dk), int(T), int(FF)
+    if edges.num_entries > 0:
+        d.row_ptr, d.ekey, d.ecode = _i32(edges.row_ptr).data_ptr(), _i32(edges.key).data_ptr(), _i32(edges.code).data_ptr()
+    d.lens = _i32(lens).data_ptr()
+    d.bias_f, d.bias_r = _f32(bias_f).data_ptr(), _f32(bias_r).data_ptr()
+    d.norm_g, d.norm_b, d.lin1_b, d.lin2_b = _f32(norm_g).data_ptr(), _f32(norm_b).data_ptr(), _f32(lin1_b).data_ptr(), _f32(lin2_b).data_ptr()
+    (qkv, qkv_b), (out, out_b), (l1, l1_b), (l2, l2_b) = packs
+    d.qkv_w, d.out_w, d.lin1_w, d.lin2_w = qkv.data_ptr(), out.data_ptr(), l1.data_ptr(), l2.data_ptr()
+    d.qkv_w_bwd, d.out_w_bwd, d.lin1_w_bwd, d.lin2_w_bwd = _p(qkv_b), _p(out_b), _p(l1_b), _p(l2_b)
+    d.ln_eps = 1e-5
+    d.drop_attn, d.drop_att_out, d.drop_ff_hidden, d.drop_ff_out = (x.c() for x in drops)
+    return d
+
+
+class _GreatLayer(torch.autograd.Function):
+    """RelationalTransformerEncoderLayer.forward ("postnorm", rezero off, vector query bias) = one C call forward, one backward.
+    `chain` carries the packed form of the activations from layer to layer: chain["packed"] is bl_pack_bf16x3 of THIS layer's
+    input if chain["of"] is that tensor's address (written by the previous layer's call), and is replaced by the packed output."""
+
+    @staticmethod
+    def forward(ctx, x, qkv_W, out_W, bias_f, bias_r, lin1_W, lin1_b, lin2_W, lin2_b, norm_g, norm_b, lens, edges, dims, drops, chain):
+        lib = load_library()
+        _f32(x, "x")
+        B, L, H, dk, T, FF = dims
+        R, D = x.shape
+        dev = x.device
+        need_bwd = any(ctx.needs_input_grad)
+        packs = [_packed_layer_weights(_f32(W, "W"), need_bwd) for W in (qkv_W, out_W, lin1_W, lin2_W)]
+        d = _great_desc(B, L, H, dk, T, FF, lens, edges, bias_f, bias_r, norm_g, norm_b, lin1_b, lin2_b, packs, drops)
+        xp = chain.get("packed") if (chain is not None and chain.get("of") == (x.data_ptr(), x._version)) else None
+        saved = (torch.empty((lib.bl_great_layer_saved_bytes(B, L, H, dk, FF, 1 if drops[0].p > 0 else 0, 1 if xp is None else 0),),
+                             dtype=torch.uint8, device=dev) if need_bwd else None)
+        ws = torch.empty((lib.bl_great_layer_workspace_bytes(B, L, H, dk, FF, 0 if need_bwd else 3),), dtype=torch.uint8, device=dev)
+        out = torch.empty_like(x)
+        outp = torch.empty((R, 3 * D), dtype=torch.int16, device=dev) if chain is not None else None
+        _check(lib.bl_great_layer_fwd(ctypes.byref(d), x.data_ptr(), _p(xp), out.data_ptr(), _p(outp), _p(saved), ws.data_ptr(), _stream()),
+               "bl_great_layer_fwd")
+        if chain is not None:
+            chain["packed"], chain["of"] = outp, (out.data_ptr(), out._version)
+        ctx.saved = (qkv_W, out_W, bias_f, bias_r, lin1_W, lin1_b, lin2_W, lin2_b, norm_g, norm_b, lens, edges, dims, drops, xp, saved, packs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (qkv_W, out_W, bias_f, bias_r, lin1_W, lin1_b, lin2_W, lin2_b, norm_g, norm_b, lens, edges, dims, drops, xp, saved,
+         packs) = _take_saved(ctx)
+        lib = load_library()
+        B, L, H, dk, T, FF = dims
+        dev = g_out.device
+        packs = [p if p[1] is not None else _packed_layer_weights(W, True) for p, W in zip(packs, (qkv_W, out_W, lin1_W, lin2_W))]
+        d = _great_desc(B, L, H, dk, T, FF, lens, edges, bias_f, bias_r, norm_g, norm_b, lin1_b, lin2_b, packs, drops)
+        params = (qkv_W, out_W, lin1_W, lin1_b, lin2_W, lin2_b, norm_g, norm_b, bias_f, bias_r)
+        targets = [_grad_target(p) for p in params]
+        g = bl_great_layer_grads_t()
+        (g.qkv_w, g.out_w, g.lin1_w, g.lin1_b, g.lin2_w, g.lin2_b, g.norm_g, g.norm_b, g.bias_f, g.bias_r) = (t[0].data_ptr() for t in targets)
+        ws = torch.empty((lib.bl_great_layer_workspace_bytes(B, L, H, dk, FF, 1),), dtype=torch.uint8, device=dev)
+        g_x = torch.empty((B * L, H * dk), dtype=torch.float32, device=dev)
+        side = _streams.side_stream_for_current_device()
+        _check(lib.bl_great_layer_bwd(ctypes.byref(d), _p(xp), _f32(g_out.contiguous()).data_ptr(), saved.data_ptr(), ws.data_ptr(), g_x.data_ptr(),
+                                      ctypes.byref(g), _stream(), side.cuda_stream if side is not None else None), "bl_great_layer_bwd")
+        r = {id(p): t[1] for p, t in zip(params, targets)}
+        return (g_x, r[id(qkv_W)], r[id(out_W)], r[id(bias_f)], r[id(bias_r)], r[id(lin1_W)], r[id(lin1_b)], r[id(lin2_W)], r[id(lin2_b)],
+                r[id(norm_g)], r[id(norm_b)], None, None, None, None, None)
+
+
+def great_layer(x, qkv_W, out_W, bias_f, bias_r, lin1_W, lin1_b, lin2_W, lin2_b, norm_g, norm_b, lens, edges: RelEdges, B, L, H, dk, T,
+                drops=(NO_DROPOUT,) * 4, chain: Optional[dict] = None):
+    """out = norm1(x1 + drop(linear2(drop(relu(linear1(x1)))))), x1 = norm1(x + drop(out_proj(rel_attention(qkv_proj(x))))) --
+    reference relational_transformer.py:104-124 (postnorm; both sublayers normalised by norm1).  drops = (attention
+    probabilities, attention branch, inside the feed-forward block, feed-forward branch)."""
+    FF = lin1_W.shape[1]
+    return _GreatLayer.apply(x.contiguous(), qkv_W, out_W, bias_f, bias_r, lin1_W, lin1_b, lin2_W, lin2_b, norm_g, norm_b, lens, edges,
+                             (int(B), int(L), int(H), int(dk), int(T), int(FF)), tuple(drops), chain)
+
+
 def dropout_rows(x, drop: Dropout):
     """Elementwise counter-hash dropout with autograd (embedding dropout of the sequence models)."""
     if drop.p <= 0:

@@ -53,6 +53,30 @@ class bl_mp_layer_t(Structure):
                 ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p), ("num_hub_slots", c_int32)]
 
 
+class bl_x6_epi_t(Structure):
+    _fields_ = [("form", c_int32), ("bias", c_void_p), ("act", c_int32), ("drop", bl_dropout_t), ("res", c_void_p), ("ld_res", c_int32),
+                ("y_packed", c_void_p), ("mask_scale", c_float), ("colsum", c_void_p), ("c_packed", c_void_p)]
+
+
+class bl_head_view_t(Structure):
+    _fields_ = [("p", c_void_p), ("sb", c_int64), ("sh", c_int32), ("sl", c_int32)]
+
+
+class bl_great_layer_t(Structure):
+    _fields_ = [("B", c_int32), ("L", c_int32), ("H", c_int32), ("dk", c_int32), ("T", c_int32), ("FF", c_int32),
+                ("row_ptr", c_void_p), ("ekey", c_void_p), ("ecode", c_void_p), ("lens", c_void_p),
+                ("bias_f", c_void_p), ("bias_r", c_void_p), ("norm_g", c_void_p), ("norm_b", c_void_p), ("lin1_b", c_void_p), ("lin2_b", c_void_p),
+                ("qkv_w", c_void_p), ("out_w", c_void_p), ("lin1_w", c_void_p), ("lin2_w", c_void_p),
+                ("qkv_w_bwd", c_void_p), ("out_w_bwd", c_void_p), ("lin1_w_bwd", c_void_p), ("lin2_w_bwd", c_void_p),
+                ("ln_eps", c_float), ("drop_attn", bl_dropout_t), ("drop_att_out", bl_dropout_t), ("drop_ff_hidden", bl_dropout_t),
+                ("drop_ff_out", bl_dropout_t)]
+
+
+class bl_great_layer_grads_t(Structure):
+    _fields_ = [("qkv_w", c_void_p), ("out_w", c_void_p), ("lin1_w", c_void_p), ("lin1_b", c_void_p), ("lin2_w", c_void_p), ("lin2_b", c_void_p),
+                ("norm_g", c_void_p), ("norm_b", c_void_p), ("bias_f", c_void_p), ("bias_r", c_void_p)]
+
+
 class bl_pack_job_t(Structure):
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", c_int32), ("G", c_int32), ("K", c_int32), ("N", c_int32),
                 ("first_block", c_int32), ("pad_", c_int32)]
@@ -94,6 +118,7 @@ _SIGNATURES = {
     "bl_gemm_rows_x6w": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_rows_x6_epi": ([POINTER(bl_rows_packed_t), c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32,
                              bl_dropout_t, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "bl_gemm_rows_x6_epi2": ([POINTER(bl_rows_packed_t), c_void_p, c_int32, c_int32, c_int32, POINTER(bl_x6_epi_t), c_void_p, c_int32, c_void_p], ctypes.c_int),
     "bl_gemm_wgrad_x6": ([POINTER(bl_rows_packed_t), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
                           c_int32, c_void_p], ctypes.c_int),
     "bl_routed_dgrad_vec_ok": ([c_int32, c_int32], c_int32),
@@ -127,6 +152,25 @@ _SIGNATURES = {
     "bl_bug_loss_fwd": ([POINTER(bl_bug_loss_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_bug_loss_bwd": ([POINTER(bl_bug_loss_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_add_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_add_layernorm_fwd_packed": ([c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p], ctypes.c_int),
+    "bl_layernorm_bwd_branch": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, bl_dropout_t,
+                                 c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_rel_attn_probs_fwd_v": ([POINTER(bl_head_view_t), c_float, POINTER(bl_head_view_t), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                 c_int32, c_int32, c_void_p, c_void_p, c_void_p, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_rel_attn_probs_bwd_v": ([POINTER(bl_head_view_t), POINTER(bl_head_view_t), c_void_p, POINTER(bl_head_view_t), c_float, c_void_p, c_void_p,
+                                 c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, bl_dropout_t, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p], ctypes.c_int),
+    "bl_attn_rows_times_v": ([c_void_p, POINTER(bl_head_view_t), c_int32, c_int32, c_int32, c_int32, c_void_p, c_float, POINTER(bl_head_view_t),
+                              c_void_p], ctypes.c_int),
+    "bl_attn_transposed_times_v": ([c_void_p, POINTER(bl_head_view_t), c_float, c_int32, c_int32, c_int32, c_int32, POINTER(bl_head_view_t),
+                                    c_void_p], ctypes.c_int),
+    "bl_great_layer_ok": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int32),
+    "bl_great_layer_saved_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_great_layer_workspace_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_great_layer_fwd": ([POINTER(bl_great_layer_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "bl_great_layer_bwd": ([POINTER(bl_great_layer_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(bl_great_layer_grads_t), c_void_p,
+                            c_void_p], ctypes.c_int),
     "bl_rel_attn_bias_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_rel_attn_bias_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
@@ -164,6 +208,7 @@ _SIGNATURES = {
     "bl_prof_num_kinds": ([], ctypes.c_int),
     "bl_prof_kind_name": ([c_int32], ctypes.c_char_p),
     "bl_prof_read": ([c_int32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), POINTER(c_int32)], ctypes.c_int),
+    "bl_prof_read_bytes": ([c_int32], ctypes.c_double),
     "bl_segment_max_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_max_bwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_layernorm_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),

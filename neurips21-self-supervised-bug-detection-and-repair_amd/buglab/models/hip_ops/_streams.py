@@ -58,8 +58,15 @@ class KernelTimer:
             ms, flop, n, ov = ctypes.c_double(), ctypes.c_double(), c_int64(), c_int32()
             _check(lib.bl_prof_read(k, ctypes.byref(ms), ctypes.byref(flop), ctypes.byref(n), ctypes.byref(ov)), "bl_prof_read")
             if n.value:
-                out[lib.bl_prof_kind_name(k).decode()] = {"launches": int(n.value), "ms": ms.value, "flop": flop.value,
-                                                           "overlapped": bool(ov.value)}
+                name = lib.bl_prof_kind_name(k).decode()
+                d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0, "overlapped": False})  # (a kind may also be timed from Python)
+                d["launches"] += int(n.value)
+                d["ms"] += ms.value
+                d["flop"] += flop.value
+                d["overlapped"] = d["overlapped"] or bool(ov.value)
+                nbytes = float(lib.bl_prof_read_bytes(k))
+                if nbytes:
+                    d["bytes"] = d.get("bytes", 0.0) + nbytes
         return out
 
 

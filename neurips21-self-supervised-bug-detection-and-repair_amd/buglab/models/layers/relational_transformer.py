@@ -70,13 +70,25 @@ class RelationalTransformerEncoderLayer(nn.Module):
         elif rezero_mode == "vector":
             self.alpha1, self.alpha2 = nn.Parameter(torch.zeros(D)), nn.Parameter(torch.zeros(D))
 
+    def fused_call_ok(self, B: int, L: int) -> bool:
+        """Whether this layer's configuration and the minibatch shape go through the one-call-per-direction form
+        (hip_ops.great_layer, csrc/bl_great_layer.hip): what `seq-great` runs -- postnorm, rezero off, vector query bias, no
+        edge value biases; head dimension 32.  Everything else takes the op-by-op path below (same arithmetic)."""
+        return (self._normalisation_mode == "postnorm" and self._rezero_mode == "off" and not self._scalar_bias and not self._value_biases
+                and hip_ops.great_layer_ok(B, L, self.nhead, self.head_dim, self.num_edge_types, self.lin1_W.shape[1]))
+
     def forward(self, x: torch.Tensor, lens: torch.Tensor, edges: RelEdges, B: int, L: int,
-                dropout_seed: Optional[int] = None, dropout_stream: int = 0) -> torch.Tensor:
+                dropout_seed: Optional[int] = None, dropout_stream: int = 0, chain: Optional[dict] = None) -> torch.Tensor:
         """x [B * L, D]; lens int32 [B] = number of real tokens per sample (keys at positions >= lens are the
-        reference's `src_mask`); edges = CSR of (sample, source, target, type) over query rows."""
+        reference's `src_mask`); edges = CSR of (sample, source, target, type) over query rows.  chain: a dict the encoder
+        shares between its layers (the packed form of the activations travels in it from one fused layer call to the next)."""
         p = self.dropout_rate if (self.training and dropout_seed is not None) else 0.0
         mk = lambda site: Dropout(p, int(dropout_seed or 0), dropout_stream + site)
         post, pre = self._normalisation_mode == "postnorm", self._normalisation_mode == "prenorm"
+        if x.is_cuda and self.fused_call_ok(B, L):
+            return hip_ops.great_layer(x, self.qkv_W, self.out_W, self.edge_bias_f, self.edge_bias_r, self.lin1_W, self.lin1_b, self.lin2_W,
+                                       self.lin2_b, self.norm1_g, self.norm1_b, lens, edges, B, L, self.nhead, self.head_dim,
+                                       self.num_edge_types, drops=(mk(0), mk(1), mk(2), mk(3)), chain=chain)
         # --- sublayer 1: relational self-attention (relational_transformer.py:104-113)
         a_in = hip_ops.add_layernorm(x, None, self.norm1_g, self.norm1_b) if pre else x
         qkv = hip_ops.gather_linear([(a_in, None)], self.qkv_W, None)

@@ -90,8 +90,9 @@ class SequenceEncoder(nn.Module):
         h0 = x
         edges = RelEdges(erow_ptr, ekey, ecode, int(ekey.shape[0]))
         states = [h0]
+        chain = {}  # (packed activations from one fused layer call to the next: hip_ops.great_layer)
         for i, layer in enumerate(self.layers):
-            x = layer(x, seq_lens, edges, B, L, dropout_seed=seed if training else None, dropout_stream=8 * (i + 1))
+            x = layer(x, seq_lens, edges, B, L, dropout_seed=seed if training else None, dropout_stream=8 * (i + 1), chain=chain)
             states.append(x)
         out = torch.cat(states, dim=-1) if return_all_states else x
         return GnnOutput(h0, out, node_to_graph, reference_node_ids, reference_node_graph_idx, int(num_graphs))

@@ -39,6 +39,27 @@ int bl_node_update_bwd_impl(const float* g_out, const float* h_out, int32_t nrow
                             const float* dact, int32_t Dm, uint16_t* g_z_packed, float* g_bias, float* gq, uint16_t* gq_packed,
                             float* g_ln_g, float* g_ln_b, float* gq_amax, void* stream);
 
+// per-kernel timing inside a per-layer entry point (csrc/bl_mp_layer.hip: bl_prof_*): brackets the launches made while it is alive
+// with two HIP events on `stream` when profiling is enabled.  Kinds: indices into bl_prof_kind_name's table.
+struct BlProfScope {
+  void* st;
+  bool on;
+  BlProfScope(int kind, double flop, void* stream, double bytes = 0.0, bool overlapped = false);
+  ~BlProfScope();
+};
+enum {
+  BL_PROF_PACK_ROWS = 0,
+  BL_PROF_LINEAR_FWD = 17,
+  BL_PROF_LINEAR_DGRAD,
+  BL_PROF_LINEAR_WGRAD,
+  BL_PROF_ATTN_PROBS_FWD,
+  BL_PROF_ATTN_PROBS_BWD,
+  BL_PROF_ATTN_ROWS_TIMES,
+  BL_PROF_ATTN_TRANSPOSED_TIMES,
+  BL_PROF_ADD_LAYERNORM,
+  BL_PROF_LAYERNORM_BWD_BRANCH
+};
+
 #define BL_CHECK_ARG(cond, ...)   \
   do {                            \
     if (!(cond)) {                \

@@ -147,6 +147,14 @@ struct X6Epi {
   int act;            // BL_ACT_*
   uint32_t drop_key, drop_thresh;
   float drop_scale;
+  // the extended forms (bl_gemm_rows_x6_epi2: the Linear layers of the relational transformer block, csrc/bl_great_layer.hip)
+  int form;                // BL_X6_EPI_*
+  const float* res;        // RES: c = A . B + res[row, n]
+  int ld_res;
+  const uint2* himask;     // MASK: the packed forward output y [M][3 N] -- c = (y's hi plane != 0) ? A . B x mask_scale : 0
+  float mask_scale;
+  float* colsum;           // MASK: [N] += column sums of c (the bias gradient)
+  uint2* c_packed;         // PACK / MASK: the result in bl_pack_bf16x3's form [M][3 N] instead of fp32
 };
 
 // The plain form fits three workgroups per CU (3 x 52 KB of LDS, <= 168 registers); the routed form
@@ -165,6 +173,10 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
     long long strideB, const int* __restrict__ group_ptr, const int* __restrict__ group_w, int G, int M, int N, int K,
     float* __restrict__ c, int ldc, int xcd_remap, X6Epi epi) {
   // one array: after the last stage the four waves' result tiles are staged in it on their way out (see the epilogue)
+  // EPI: -1 none; 0..15 = activation code (bias / activation / dropout, fp32 result); 16 + code = the same, result PACKED only;
+  // 32 = + residual (fp32 result); 64 = masked by the packed forward output, column sums, result packed only
+  constexpr bool E_ACT = EPI >= 0 && EPI < 32, E_PACK = EPI >= 16 && (EPI < 32 || EPI == 64), E_RES = EPI == 32, E_MASK = EPI == 64;
+  constexpr int ACT = EPI >= 0 ? (EPI & 15) : 0;
   constexpr bool SWZ = X6_SWIZZLED(MASKED);
   constexpr int XROW = SWZ ? 12 : 13;
 #define XSLOT(row_, kg_) (SWZ ? ((kg_) ^ (((row_) >> 2) & 3)) : (kg_))
@@ -300,6 +312,7 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
   // after the last stage's barrier) and leaves as whole 256-byte row pieces, 16 lanes per piece: measured on the node
   // update's backward kernel (same layout, csrc/bl_node_bwd.hip), the direct form cost 2-3x the time of its bytes.
   float* stage = reinterpret_cast<float*>(ABs) + wave * (32 * 68);
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     const int m = wm * 64 + ti * 32 + li;
@@ -309,13 +322,13 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
       for (int gq = 0; gq < 4; ++gq) {
         const int n = n0 + wn * 64 + tj * 32 + 8 * gq + 4 * half;
         float v[4] = {acc[ti][tj][4 * gq + 0], acc[ti][tj][4 * gq + 1], acc[ti][tj][4 * gq + 2], acc[ti][tj][4 * gq + 3]};
-        if (EPI >= 0) {
+        if (E_ACT) {
           float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
           if (epi.bias && n < N) bv = *reinterpret_cast<const float4*>(epi.bias + n);
           v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            v[u] = bl_act(EPI, v[u]);
+            v[u] = bl_act(ACT, v[u]);
             if (epi.drop_thresh) {  // same counter as the fp32 row GEMM: element index row * N + column
               const uint32_t idx = (uint32_t)(row0 + m) * (uint32_t)N + (uint32_t)(n + u);
               v[u] = ((bl_lowbias32(idx + epi.drop_key) >> 8) >= epi.drop_thresh) ? v[u] * epi.drop_scale : 0.f;
@@ -330,8 +343,46 @@ __global__ __launch_bounds__(256, MASKED ? X6_MASKED_WGS : X6_PLAIN_WGS) void ge
     for (int j = 0; j < 8; ++j) {
       const int r = (lane >> 4) + 4 * j;
       const int mm = wm * 64 + ti * 32 + r;
-      const float4 v = *reinterpret_cast<const float4*>(stage + r * 68 + 4 * c4);
-      if (mm < nrows && n < N) *reinterpret_cast<float4*>(c + (size_t)(row0 + mm) * ldc + n) = v;
+      float4 v = *reinterpret_cast<const float4*>(stage + r * 68 + 4 * c4);
+      if (mm < nrows && n < N) {
+        const size_t grow = (size_t)(row0 + mm);
+        if (E_RES) {
+          const float4 rv = *reinterpret_cast<const float4*>(epi.res + grow * epi.ld_res + n);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (E_MASK) {  // y = drop(relu(z)) != 0  <=>  kept and z > 0: the hi plane of a non-zero fp32 is non-zero
+          const uint2 hm = epi.himask[(grow * 3 * N + n) >> 2];
+          v.x = (hm.x & 0x7fffu) ? v.x * epi.mask_scale : 0.f;
+          v.y = (hm.x & 0x7fff0000u) ? v.y * epi.mask_scale : 0.f;
+          v.z = (hm.y & 0x7fffu) ? v.z * epi.mask_scale : 0.f;
+          v.w = (hm.y & 0x7fff0000u) ? v.w * epi.mask_scale : 0.f;
+          csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+        }
+        if (E_PACK) {
+          uint16_t h[4], m[4], l[4];
+          split3(v.x, h[0], m[0], l[0]);
+          split3(v.y, h[1], m[1], l[1]);
+          split3(v.z, h[2], m[2], l[2]);
+          split3(v.w, h[3], m[3], l[3]);
+          uint2* o = epi.c_packed + ((grow * 3 * N + n) >> 2);
+          o[0] = make_uint2(PK(h[0], h[1]), PK(h[2], h[3]));
+          o[N >> 2] = make_uint2(PK(m[0], m[1]), PK(m[2], m[3]));
+          o[N >> 1] = make_uint2(PK(l[0], l[1]), PK(l[2], l[3]));
+        } else {
+          *reinterpret_cast<float4*>(c + grow * ldc + n) = v;
+        }
+      }
+    }
+  }
+  if (E_MASK) {  // column sums of this wave's 64 x 64 block: over the four row groups of the lanes, then one atomic per column
+    csum.x += __shfl_xor(csum.x, 16, 64); csum.y += __shfl_xor(csum.y, 16, 64); csum.z += __shfl_xor(csum.z, 16, 64); csum.w += __shfl_xor(csum.w, 16, 64);
+    csum.x += __shfl_xor(csum.x, 32, 64); csum.y += __shfl_xor(csum.y, 32, 64); csum.z += __shfl_xor(csum.z, 32, 64); csum.w += __shfl_xor(csum.w, 32, 64);
+    const int n = n0 + wn * 64 + 4 * (lane & 15);
+    if (lane < 16 && n < N && epi.colsum) {
+      unsafeAtomicAdd(epi.colsum + n, csum.x);
+      unsafeAtomicAdd(epi.colsum + n + 1, csum.y);
+      unsafeAtomicAdd(epi.colsum + n + 2, csum.z);
+      unsafeAtomicAdd(epi.colsum + n + 3, csum.w);
     }
   }
 }
@@ -854,7 +905,7 @@ int gemm_rows_x6_impl(const char* who, const bl_rows_packed_t* a, const uint32_t
   const uint4* x0 = reinterpret_cast<const uint4*>(a->xp[0]);
   const uint4* x1 = a->nsrc > 1 ? reinterpret_cast<const uint4*>(a->xp[1]) : nullptr;
   const uint4* x2 = a->nsrc > 2 ? reinterpret_cast<const uint4*>(a->xp[2]) : nullptr;
-  X6Epi e = {nullptr, BL_ACT_NONE, 0u, 0u, 1.f};
+  X6Epi e = {nullptr, BL_ACT_NONE, 0u, 0u, 1.f, 0, nullptr, 0, nullptr, 1.f, nullptr, nullptr};
   if (epi) e = *epi;
 #define X6_ARGS                                                                                                          \
   x0, x1, x2, a->idx[0], a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],              \
@@ -862,7 +913,16 @@ int gemm_rows_x6_impl(const char* who, const bl_rows_packed_t* a, const uint32_t
       reinterpret_cast<const uint4*>(bp), (long long)(b_group_stride / 8), group_ptr, group_w, G, M, N, K, c, ldc, xcd, e
   if (win_bits)
     hipLaunchKernelGGL((gemm_rows_x6_kernel<true, -1>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
-  else if (epi == nullptr)
+  else if (epi && e.form == BL_X6_EPI_ACT_PACK && e.act == BL_ACT_RELU)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false, 16 + BL_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else if (epi && e.form == BL_X6_EPI_RES)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false, 32>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else if (epi && e.form == BL_X6_EPI_MASK_PACK)
+    hipLaunchKernelGGL((gemm_rows_x6_kernel<false, 64>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
+  else if (epi && e.form != BL_X6_EPI_ACT) {
+    bl_set_error("%s: epilogue form %d with activation %d is not built (packed result: relu only)", who, e.form, e.act);
+    return BL_EINVAL;
+  } else if (epi == nullptr)
     hipLaunchKernelGGL((gemm_rows_x6_kernel<false, -1>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
   else if (e.act == BL_ACT_TANH)
     hipLaunchKernelGGL((gemm_rows_x6_kernel<false, BL_ACT_TANH>), grid, dim3(256), 0, (hipStream_t)stream, X6_ARGS);
@@ -1002,8 +1062,30 @@ extern "C" int bl_gemm_rows_x6_epi(const bl_rows_packed_t* a, const uint16_t* bp
   BL_CHECK_ARG((uint64_t)M * (uint64_t)N < (1ull << 32) || drop.p <= 0.f, "bl_gemm_rows_x6_epi: dropout index space is 32 bit");
   BL_CHECK_ARG(bias == nullptr || bl_aligned16(bias), "bl_gemm_rows_x6_epi: misaligned bias");
   const bl_drop_dev d = bl_make_drop(drop);
-  X6Epi e = {bias, act, d.key, d.thresh, d.scale};
+  X6Epi e = {bias, act, d.key, d.thresh, d.scale, 0, nullptr, 0, nullptr, 1.f, nullptr, nullptr};
   return gemm_rows_x6_impl("bl_gemm_rows_x6_epi", a, nullptr, 0, bp, b_group_stride, group_ptr, group_w, G, M, N, K, &e, c, ldc, stream);
+}
+
+extern "C" int bl_gemm_rows_x6_epi2(const bl_rows_packed_t* a, const uint16_t* bp, int32_t M, int32_t N, int32_t K, const bl_x6_epi_t* epi,
+                                    float* c, int32_t ldc, void* stream) {
+  BL_CHECK_ARG(epi, "bl_gemm_rows_x6_epi2: null epilogue");
+  BL_CHECK_ARG((uint64_t)M * (uint64_t)N < (1ull << 32) || epi->drop.p <= 0.f, "bl_gemm_rows_x6_epi2: dropout index space is 32 bit");
+  BL_CHECK_ARG(epi->bias == nullptr || bl_aligned16(epi->bias), "bl_gemm_rows_x6_epi2: misaligned bias");
+  const bool packs = epi->form == BL_X6_EPI_ACT_PACK || epi->form == BL_X6_EPI_MASK_PACK;
+  BL_CHECK_ARG(!packs || (epi->c_packed && bl_aligned16(epi->c_packed) && N % 8 == 0),
+               "bl_gemm_rows_x6_epi2: the packed result needs a 16-byte aligned buffer and N %% 8 == 0");
+  BL_CHECK_ARG(epi->form != BL_X6_EPI_RES || (epi->res && bl_aligned16(epi->res) && epi->ld_res % 4 == 0 && epi->ld_res >= N),
+               "bl_gemm_rows_x6_epi2: the residual needs an aligned [M, ld_res >= N] matrix");
+  BL_CHECK_ARG(epi->form != BL_X6_EPI_MASK_PACK || (epi->y_packed && bl_aligned16(epi->y_packed)),
+               "bl_gemm_rows_x6_epi2: the masked form needs the packed forward output");
+  BL_CHECK_ARG(epi->form != BL_X6_EPI_MASK_PACK || epi->colsum == nullptr || !bl_get_deterministic(),
+               "bl_gemm_rows_x6_epi2: the column sums are flushed by unordered atomics (deterministic mode is on)");
+  const bl_drop_dev d = bl_make_drop(epi->drop);
+  X6Epi e = {epi->bias, epi->act, d.key, d.thresh, d.scale, epi->form, epi->res, epi->ld_res,
+             reinterpret_cast<const uint2*>(epi->y_packed), epi->mask_scale, epi->colsum, reinterpret_cast<uint2*>(epi->c_packed)};
+  // (the packed forms never touch c: any non-null aligned pointer passes the common checks)
+  float* cc = packs ? reinterpret_cast<float*>(epi->c_packed) : c;
+  return gemm_rows_x6_impl("bl_gemm_rows_x6_epi2", a, nullptr, 0, bp, 0, nullptr, nullptr, 1, M, N, K, &e, cc, packs ? N : ldc, stream);
 }
 
 extern "C" int bl_gemm_wgrad_routed_x6(const bl_rows_packed_t* a, const uint16_t* g_node_packed, const int32_t* g_idx,

@@ -462,8 +462,11 @@ __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __res
 // channel PAIRS 2*lane + 128*j (+0, +1): float2 loads/stores, and the optional bf16x3-packed copy of
 // the result (the operand form of the bf16x6 GEMMs) is written as 32-bit stores.  Column sums are
 // reduced per block, then atomics -- from few blocks: same-address atomics serialise (~40 ns each).
+// PD (the relational transformer block, csrc/bl_great_layer.hip): the PACKED copy is the gradient of the branch
+// y_branch = dropout(Linear(.)) that was added to the residual before the LayerNorm -- g_x through that dropout's mask (element
+// index row * D + d) -- and g_bias += its column sums (the Linear's bias gradient); the fp32 g_x stays unmasked (the residual).
 #define LN_RIF 4
-template <int NP>
+template <int NP, bool PD = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g_y, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -472,15 +475,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ g_beta,
                                                             const float* __restrict__ post_scale,
                                                             uint32_t* __restrict__ g_x_packed,
-                                                            unsigned* __restrict__ order_ctr) {
-  __shared__ float red[2][4][128 * NP];
+                                                            unsigned* __restrict__ order_ctr, bl_drop_dev pdrop,
+                                                            float* __restrict__ g_bias) {
+  __shared__ float red[PD ? 3 : 2][4][128 * NP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nw = gridDim.x * 4;
-  float2 dg[NP], db[NP], gam[NP];
+  float2 dg[NP], db[NP], gam[NP], dm[PD ? NP : 1];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     dg[j] = make_float2(0.f, 0.f);
     db[j] = make_float2(0.f, 0.f);
+    if (PD) dm[j] = make_float2(0.f, 0.f);
     const int d = 2 * lane + 128 * j;
     gam[j] = d < D ? *reinterpret_cast<const float2*>(gamma + d) : make_float2(0.f, 0.f);
   }
@@ -529,6 +534,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           gx.x = rs[q] * (gy[q][j].x * gam[j].x - a - xh[q][j].x * b) * ps[q][j].x;
           gx.y = rs[q] * (gy[q][j].y * gam[j].y - a - xh[q][j].y * b) * ps[q][j].y;
           if (g_x) *reinterpret_cast<float2*>(g_x + (size_t)r * D + d) = gx;
+          if (PD) {
+            const uint32_t e0 = (uint32_t)r * (uint32_t)D + (uint32_t)d;
+            gx.x = (pdrop.thresh == 0u || bl_keep(pdrop, e0)) ? gx.x * pdrop.scale : 0.f;
+            gx.y = (pdrop.thresh == 0u || bl_keep(pdrop, e0 + 1)) ? gx.y * pdrop.scale : 0.f;
+            dm[j].x += gx.x; dm[j].y += gx.y;
+          }
           if (g_x_packed) {
             uint16_t h0, m0, l0, h1, m1, l1;
             split3(gx.x, h0, m0, l0);
@@ -546,12 +557,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int j = 0; j < NP; ++j) {
     red[0][w][2 * lane + 128 * j] = dg[j].x; red[0][w][2 * lane + 128 * j + 1] = dg[j].y;
     red[1][w][2 * lane + 128 * j] = db[j].x; red[1][w][2 * lane + 128 * j + 1] = db[j].y;
+    if (PD) { red[2][w][2 * lane + 128 * j] = dm[j].x; red[2][w][2 * lane + 128 * j + 1] = dm[j].y; }
   }
   __syncthreads();
   bl_ordered_enter(order_ctr, blockIdx.x);  // deterministic mode: blocks flush in block order
   for (int d = threadIdx.x; d < D; d += 256) {
     unsafeAtomicAdd(&g_gamma[d], red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
     unsafeAtomicAdd(&g_beta[d], red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
+    if (PD && g_bias) unsafeAtomicAdd(&g_bias[d], red[2][0][d] + red[2][1][d] + red[2][2][d] + red[2][3][d]);
   }
   bl_ordered_leave(order_ctr, blockIdx.x);
 }
@@ -914,11 +927,31 @@ extern "C" int bl_layernorm_bwd(const float* g_y, const float* x, const float* m
   const int blocks = min((nrows + 4 * LN_RIF - 1) / (4 * LN_RIF), 512);  // also bounds the same-address atomics on g_gamma / g_beta
   hipStream_t st = (hipStream_t)stream;
   uint32_t* gp = reinterpret_cast<uint32_t*>(g_x_packed);
-#define LN_BWD_GO(NP_) hipLaunchKernelGGL((layernorm_bwd_kernel<NP_>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd, gamma, nrows, D, g_x, g_gamma, g_beta, post_scale, gp, bl_order_counters(1, stream))
+  const bl_drop_dev nodrop = {0u, 0u, 1.f};
+#define LN_BWD_GO(NP_) hipLaunchKernelGGL((layernorm_bwd_kernel<NP_>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd, gamma, nrows, D, g_x, g_gamma, g_beta, post_scale, gp, bl_order_counters(1, stream), nodrop, (float*)nullptr)
   if (D <= 128) LN_BWD_GO(1);
   else if (D <= 256) LN_BWD_GO(2);
   else LN_BWD_GO(4);
   BL_LAUNCH_CHECK("bl_layernorm_bwd");
+  return BL_OK;
+}
+
+extern "C" int bl_layernorm_bwd_branch(const float* g_y, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                       int32_t nrows, int32_t D, float* g_x, float* g_gamma, float* g_beta, bl_dropout_t branch_drop,
+                                       float* g_bias, uint16_t* g_branch_packed, void* stream) {
+  if (nrows == 0) return BL_OK;
+  BL_CHECK_ARG(g_y && x && mean && rstd && gamma && g_x && g_branch_packed && g_gamma && g_beta, "bl_layernorm_bwd_branch: null pointer");
+  BL_CHECK_ARG(D > 0 && D <= 512 && D % 8 == 0, "bl_layernorm_bwd_branch: D must be a multiple of 8 up to 512 (got %d)", D);
+  BL_CHECK_ARG((uint64_t)nrows * (uint64_t)D < (1ull << 32) || branch_drop.p <= 0.f, "bl_layernorm_bwd_branch: dropout index space is 32 bit");
+  const int blocks = min((nrows + 4 * LN_RIF - 1) / (4 * LN_RIF), 512);
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* gp = reinterpret_cast<uint32_t*>(g_branch_packed);
+  const bl_drop_dev pd = bl_make_drop(branch_drop);
+#define LN_BWD_BR(NP_) hipLaunchKernelGGL((layernorm_bwd_kernel<NP_, true>), dim3(blocks), dim3(256), 0, st, g_y, x, mean, rstd, gamma, nrows, D, g_x, g_gamma, g_beta, (const float*)nullptr, gp, bl_order_counters(1, stream), pd, g_bias)
+  if (D <= 128) LN_BWD_BR(1);
+  else if (D <= 256) LN_BWD_BR(2);
+  else LN_BWD_BR(4);
+  BL_LAUNCH_CHECK("bl_layernorm_bwd_branch");
   return BL_OK;
 }
 

@@ -25,13 +25,17 @@ struct ProfRec {
   double flop;
   hipEvent_t e0, e1;
   bool overlapped;
+  double bytes;
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
 const char* kProfNames[] = {"pack_rows",      "msg_gemm_x6",  "segment_max_ln", "dense_fwd",    "act_bwd",       "dense_wgrad",
                             "dense_dgrad",    "layernorm_bwd", "msg_wgrad_x6",   "msg_dgrad_x6", "node_grad_sums", "msg_dgrad_nodes",
-                            "node_update_bwd", "msg_gemm_h3", "msg_wgrad_h3", "msg_dgrad_h3", "pack_gq_h3"};
+                            "node_update_bwd", "msg_gemm_h3", "msg_wgrad_h3", "msg_dgrad_h3", "pack_gq_h3",
+                            // the relational transformer block (csrc/bl_great_layer.hip; BL_PROF_GREAT_* in bl_common.h)
+                            "linear_x6_epi", "linear_dgrad_x6", "gemm_wgrad_x6", "attn_probs_fwd", "attn_probs_bwd", "attn_rows_times",
+                            "attn_transposed_times", "add_layernorm", "layernorm_bwd_branch"};
 constexpr int kProfKinds = sizeof(kProfNames) / sizeof(kProfNames[0]);
 
 hipEvent_t prof_event() {
@@ -50,7 +54,7 @@ struct ProfScope {  // brackets the launches made while it is alive with two eve
   bool on;
   ProfScope(int kind, double flop, hipStream_t s, bool overlapped) : st(s), on(g_prof_on) {
     if (!on) return;
-    ProfRec r{kind, flop, prof_event(), prof_event(), overlapped};
+    ProfRec r{kind, flop, prof_event(), prof_event(), overlapped, 0.0};
     (void)hipEventRecord(r.e0, st);
     g_prof.push_back(r);
   }
@@ -59,6 +63,17 @@ struct ProfScope {  // brackets the launches made while it is alive with two eve
   }
 };
 }  // namespace
+
+// the same for the other per-layer entry points of the library (declared in bl_common.h)
+BlProfScope::BlProfScope(int kind, double flop, void* stream, double bytes, bool overlapped) : st(stream), on(g_prof_on) {
+  if (!on) return;
+  ProfRec r{kind, flop, prof_event(), prof_event(), overlapped, bytes};
+  (void)hipEventRecord(r.e0, (hipStream_t)st);
+  g_prof.push_back(r);
+}
+BlProfScope::~BlProfScope() {
+  if (on) (void)hipEventRecord(g_prof.back().e1, (hipStream_t)st);
+}
 
 extern "C" int bl_prof_enable(int32_t on) {
   g_prof_on = on != 0;
@@ -97,6 +112,13 @@ extern "C" int bl_prof_read(int32_t kind, double* ms, double* flop, int64_t* lau
   if (launches) *launches = n;
   if (overlapped) *overlapped = ov;
   return BL_OK;
+}
+// algorithmic bytes the launches of a (memory-bound) kind were recorded with since the last reset (0 for the GEMM kinds)
+extern "C" double bl_prof_read_bytes(int32_t kind) {
+  double b = 0;
+  for (auto& r : g_prof)
+    if (r.kind == kind) b += r.bytes;
+  return b;
 }
 
 // ---- buffer carving ---------------------------------------------------------------------------------

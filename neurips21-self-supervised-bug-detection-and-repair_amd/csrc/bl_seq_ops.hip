@@ -17,6 +17,24 @@
 
 #define NEG_INF_F (-__builtin_huge_valf())
 
+// A [B, H, L, dk] tensor wherever its rows live (bl_head_view_t): element (b, h, l, d) at p[b sb + h sh + l sl + d].
+// Contiguous [B, H, L, dk]: (H L dk, L dk, dk); the q / k / v column blocks of the QKV projection's own output [B L, H 3 dk]
+// (per head [q | k | v], multihead_attention.py:46-50): p = qkv + which dk, (L 3 H dk, 3 dk, 3 H dk) -- no permuted copies.
+struct HeadView {
+  float* p;
+  long long sb;
+  int sh, sl;
+};
+__device__ __forceinline__ float* hv_mat(const HeadView& v, int b, int h) { return v.p + (size_t)b * v.sb + (size_t)h * v.sh; }
+static inline HeadView hv_contiguous(const float* p, int H, int L, int dk) {
+  HeadView v = {const_cast<float*>(p), (long long)H * L * dk, L * dk, dk};
+  return v;
+}
+static inline HeadView hv_from(const bl_head_view_t* a) {
+  HeadView v = {a->p, (long long)a->sb, a->sh, a->sl};
+  return v;
+}
+
 // ---- y = LayerNorm(x + r) ---------------------------------------------------------------------------
 // one wave per row, D <= 1024; z = x + r is written when z_out != NULL (what backward needs)
 template <int NV>
@@ -54,6 +72,72 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
   for (int j = 0; j < NV; ++j) {
     const int d = lane + 64 * j;
     if (d < D) y[(size_t)row * D + d] = (v[j] - mean) * rstd * gamma[d] + beta[d];
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// the same with a lane owning 4 consecutive channels (d = 4 lane + 256 j; D % 4 == 0) and, optionally, the result also in
+// bl_pack_bf16x3's form y_packed [nrows][3 D] -- the operand of the next Linear's bf16x6 GEMM without a packing pass
+// (csrc/bl_great_layer.hip)
+template <int NV4>
+__global__ __launch_bounds__(256) void add_layernorm_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, int nrows, int D, float* __restrict__ z_out,
+                                                                 float* __restrict__ y, float* __restrict__ mean_out,
+                                                                 float* __restrict__ rstd_out, uint2* __restrict__ y_packed) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  float4 v[NV4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    const int d = 4 * lane + 256 * j;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d < D) {
+      t = *reinterpret_cast<const float4*>(x + (size_t)row * D + d);
+      if (r) {
+        const float4 rv = *reinterpret_cast<const float4*>(r + (size_t)row * D + d);
+        t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
+      }
+      if (z_out) *reinterpret_cast<float4*>(z_out + (size_t)row * D + d) = t;
+    }
+    v[j] = t;
+    s += (t.x + t.y) + (t.z + t.w);
+  }
+  const float mean = bl_wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    if (4 * lane + 256 * j < D) {
+      const float c0 = v[j].x - mean, c1 = v[j].y - mean, c2 = v[j].z - mean, c3 = v[j].w - mean;
+      q += (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3);
+    }
+  }
+  const float rstd = rsqrtf(bl_wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    const int d = 4 * lane + 256 * j;
+    if (d < D) {
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + d), bt = *reinterpret_cast<const float4*>(beta + d);
+      float4 o;
+      o.x = (v[j].x - mean) * rstd * gm.x + bt.x;
+      o.y = (v[j].y - mean) * rstd * gm.y + bt.y;
+      o.z = (v[j].z - mean) * rstd * gm.z + bt.z;
+      o.w = (v[j].w - mean) * rstd * gm.w + bt.w;
+      *reinterpret_cast<float4*>(y + (size_t)row * D + d) = o;
+      if (y_packed) {
+        uint16_t h[4], m[4], l[4];
+        split3(o.x, h[0], m[0], l[0]);
+        split3(o.y, h[1], m[1], l[1]);
+        split3(o.z, h[2], m[2], l[2]);
+        split3(o.w, h[3], m[3], l[3]);
+        uint2* op = y_packed + (((size_t)row * 3 * D + d) >> 2);
+        op[0] = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        op[D >> 2] = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
+        op[D >> 1] = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+      }
+    }
   }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
@@ -257,7 +341,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 #define ATT_WG_ROWS 128 // query rows per workgroup
 #define ATT_ITERS (ATT_WG_ROWS / (16 * ATT_ROWS))  // steps per wave
 template <int DK, int KC>  // KC = 16-byte key chunks per lane: Lp = 256 KC >= L
-__global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const HeadView q, const float q_scale, const HeadView k,
                                                               const int* __restrict__ row_ptr, const int* __restrict__ ekey,
                                                               const int* __restrict__ ecode, int L, int H, int T,
                                                               const float* __restrict__ bias_f, const float* __restrict__ bias_r,
@@ -275,11 +359,12 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __res
 #pragma unroll
   for (int it = 0; it < ATT_ITERS; ++it)
     rpv[it] = (row_ptr && lane <= ATT_ROWS) ? row_ptr[b * L + min(rb + (16 * it + wave) * ATT_ROWS + lane, L)] : 0;
+  const float* __restrict__ qg = hv_mat(q, b, h);
   {
-    const float* __restrict__ kg = k + (size_t)g * L * DK;
+    const float* __restrict__ kg = hv_mat(k, b, h);
     for (int x = tid; x < LP * DK; x += 1024) {
       const int j = x / DK, d = x - j * DK;
-      Kt[d * LS + j] = j < L ? kg[x] : 0.f;
+      Kt[d * LS + j] = j < L ? kg[(size_t)j * k.sl + d] : 0.f;
     }
     for (int x = tid; x < 2 * T * DK; x += 1024) {
       const int c = x / DK, d = x - c * DK;
@@ -294,7 +379,7 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __res
     if (i0 >= re) break;
     float qv[ATT_ROWS];  // lane d < DK: q[i0 + r][d]
 #pragma unroll
-    for (int r = 0; r < ATT_ROWS; ++r) qv[r] = lane < DK ? q[((size_t)g * L + min(i0 + r, L - 1)) * DK + lane] : 0.f;
+    for (int r = 0; r < ATT_ROWS; ++r) qv[r] = lane < DK ? qg[(size_t)min(i0 + r, L - 1) * q.sl + lane] * q_scale : 0.f;
     // the rows' edge entries, up to 64 each, one per lane: requested here, used after the score loop
     int ebeg[ATT_ROWS], ecnt[ATT_ROWS], ek[ATT_ROWS], ec[ATT_ROWS];
 #pragma unroll
@@ -401,8 +486,8 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const float* __res
 // elements lane + 64 k of the [2 T][dk] table), then per workgroup in LDS, then one atomic per element and workgroup.
 #define ATT_TAB_REGS 16  // 2 T dk <= 1024
 template <int DK, int KC>
-__global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __restrict__ g_ctx, const float* __restrict__ v,
-                                                              const float* __restrict__ P, const float* __restrict__ q,
+__global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const HeadView g_ctx, const HeadView v,
+                                                              const float* __restrict__ P, const HeadView q, const float q_scale,
                                                               const int* __restrict__ row_ptr, const int* __restrict__ ekey,
                                                               const int* __restrict__ ecode, int L, int H, int T,
                                                               const float* __restrict__ bias_f, const float* __restrict__ bias_r,
@@ -422,11 +507,13 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __res
 #pragma unroll
   for (int it = 0; it < ATT_ITERS; ++it)
     rpv[it] = (row_ptr && lane <= ATT_ROWS) ? row_ptr[b * L + min(rb + (16 * it + wave) * ATT_ROWS + lane, L)] : 0;
+  const float* __restrict__ gcg = hv_mat(g_ctx, b, h);
+  const float* __restrict__ qg = hv_mat(q, b, h);
   {
-    const float* __restrict__ vg = v + (size_t)g * L * DK;
+    const float* __restrict__ vg = hv_mat(v, b, h);
     for (int x = tid; x < LP * DK; x += 1024) {
       const int j = x / DK, d = x - j * DK;
-      Vt[d * LS + j] = j < L ? vg[x] : 0.f;
+      Vt[d * LS + j] = j < L ? vg[(size_t)j * v.sl + d] : 0.f;
     }
     if (row_ptr) {
       for (int x = tid; x < ntab; x += 1024) {
@@ -447,7 +534,7 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __res
     if (i0 >= re) break;
     float gv[ATT_ROWS];  // lane d < DK: dO[i0 + r][d]
 #pragma unroll
-    for (int r = 0; r < ATT_ROWS; ++r) gv[r] = lane < DK ? g_ctx[((size_t)g * L + min(i0 + r, L - 1)) * DK + lane] : 0.f;
+    for (int r = 0; r < ATT_ROWS; ++r) gv[r] = lane < DK ? gcg[(size_t)min(i0 + r, L - 1) * g_ctx.sl + lane] : 0.f;
     int ebeg[ATT_ROWS], ecnt[ATT_ROWS], ek[ATT_ROWS], ec[ATT_ROWS];
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r) {
@@ -523,7 +610,7 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const float* __res
       }
       if (ecnt[r] > 0) {
         any_edges = true;
-        const float qd = q[row * DK + (lane & (DK - 1))];
+        const float qd = qg[(size_t)i * q.sl + (lane & (DK - 1))] * q_scale;
         float coef = 0.f;  // lane c < 2 T: sum of dS over this row's entries with code c
         for (int p = 0; p < ecnt[r]; ++p) {  // (wave-uniform entry: scalar registers and branches)
           int key, code;
@@ -588,15 +675,15 @@ typedef float att_f32x16 __attribute__((ext_vector_type(16)));
 #define ATT_MM_WAVES 8
 
 // out[(g, i), :] = (sum_k A[(g, i), k] M[g, k, :] (+ add[(g, i), :])) * scale
-__global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const float* __restrict__ A, const float* __restrict__ M, int L,
+__global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const float* __restrict__ A, const HeadView M, int H, int L,
                                                                       const float* __restrict__ add, float scale,
-                                                                      float* __restrict__ out) {
+                                                                      const HeadView out) {
   extern __shared__ __attribute__((aligned(16))) float att_lds[];  // [L][33]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, half = lane >> 5;
-  const int g = blockIdx.x;
+  const int g = blockIdx.x, gb = g / H, gh = g - gb * H;
   {
-    const float* __restrict__ mg = M + (size_t)g * L * 32;
-    for (int x = tid; x < L * 32; x += 64 * ATT_MM_WAVES) att_lds[(x >> 5) * 33 + (x & 31)] = mg[x];
+    const float* __restrict__ mg = hv_mat(M, gb, gh);
+    for (int x = tid; x < L * 32; x += 64 * ATT_MM_WAVES) att_lds[(x >> 5) * 33 + (x & 31)] = mg[(size_t)(x >> 5) * M.sl + (x & 31)];
   }
   __syncthreads();
   const int r0 = (blockIdx.y * ATT_MM_WAVES + wave) * 32;
@@ -624,6 +711,7 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const f
   }
   if (r0 + li < L) {
     const size_t o = ((size_t)g * L + row) * 32;
+    float* __restrict__ orow = hv_mat(out, gb, gh) + (size_t)row * out.sl;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int n = 8 * g4 + 4 * half;
@@ -633,20 +721,20 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const f
         v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
       }
       v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-      *reinterpret_cast<float4*>(out + o + n) = v;
+      *reinterpret_cast<float4*>(orow + n) = v;
     }
   }
 }
 
 // out[g, key, :] = sum_i A[(g, i), key] Bm[g, i, :]
-__global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_tn32_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int L,
-                                                                      float* __restrict__ out) {
+__global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_tn32_kernel(const float* __restrict__ A, const HeadView Bm, float bm_scale,
+                                                                      int H, int L, const HeadView out) {
   extern __shared__ __attribute__((aligned(16))) float att_lds[];  // [L][33]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, half = lane >> 5;
-  const int g = blockIdx.x;
+  const int g = blockIdx.x, gb = g / H, gh = g - gb * H;
   {
-    const float* __restrict__ bg = Bm + (size_t)g * L * 32;
-    for (int x = tid; x < L * 32; x += 64 * ATT_MM_WAVES) att_lds[(x >> 5) * 33 + (x & 31)] = bg[x];
+    const float* __restrict__ bg = hv_mat(Bm, gb, gh);
+    for (int x = tid; x < L * 32; x += 64 * ATT_MM_WAVES) att_lds[(x >> 5) * 33 + (x & 31)] = bg[(size_t)(x >> 5) * Bm.sl + (x & 31)] * bm_scale;
   }
   __syncthreads();
   const int key0 = (blockIdx.y * ATT_MM_WAVES + wave) * 32;
@@ -671,10 +759,10 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_tn32_kernel(const f
     }
   }
   if (key0 + li < L) {
-    const size_t o = ((size_t)g * L + key) * 32;
+    float* __restrict__ orow = hv_mat(out, gb, gh) + (size_t)key * out.sl;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
-      *reinterpret_cast<float4*>(out + o + 8 * g4 + 4 * half) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+      *reinterpret_cast<float4*>(orow + 8 * g4 + 4 * half) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
   }
 }
 
@@ -786,6 +874,26 @@ extern "C" int bl_add_layernorm_fwd(const float* x, const float* r, const float*
   return BL_OK;
 }
 
+extern "C" int bl_add_layernorm_fwd_packed(const float* x, const float* r, const float* gamma, const float* beta, float eps,
+                                           int32_t nrows, int32_t D, float* z_out, float* y, float* mean, float* rstd,
+                                           uint16_t* y_packed, void* stream) {
+  if (nrows == 0) return BL_OK;
+  BL_CHECK_ARG(x && gamma && beta && y && mean && rstd && D > 0 && D <= 1024 && D % 4 == 0,
+               "bl_add_layernorm_fwd_packed: null pointer or D not a multiple of 4 in 4..1024");
+  BL_CHECK_ARG(bl_aligned16(x) && (r == nullptr || bl_aligned16(r)) && bl_aligned16(gamma) && bl_aligned16(beta) && bl_aligned16(y) &&
+                   (z_out == nullptr || bl_aligned16(z_out)) && (y_packed == nullptr || bl_aligned16(y_packed)),
+               "bl_add_layernorm_fwd_packed: 16-byte aligned pointers required");
+  hipStream_t st = (hipStream_t)stream;
+  uint2* yp = reinterpret_cast<uint2*>(y_packed);
+#define ALN4_GO(NV4_) hipLaunchKernelGGL((add_layernorm_fwd4_kernel<NV4_>), dim3((nrows + 3) / 4), dim3(256), 0, st, x, r, gamma, beta, eps, nrows, D, z_out, y, mean, rstd, yp)
+  if (D <= 256) ALN4_GO(1);
+  else if (D <= 512) ALN4_GO(2);
+  else ALN4_GO(4);
+#undef ALN4_GO
+  BL_LAUNCH_CHECK("bl_add_layernorm_fwd_packed");
+  return BL_OK;
+}
+
 static int check_rel(const char* who, const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int B, int L, int H, int dk) {
   BL_CHECK_ARG(row_ptr && ekey && ecode, "%s: null edge CSR", who);
   BL_CHECK_ARG(B > 0 && L > 0 && H > 0 && (dk == 8 || dk == 16 || dk == 32 || dk == 64) && H * dk <= 512,
@@ -882,11 +990,11 @@ extern "C" int32_t bl_rel_attn_probs_ok(int32_t L, int32_t dk, int32_t T) {
   return att_lds_bytes(L, dk, T) <= 72 * 1024;
 }
 
-extern "C" int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode,
-                                     int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, const float* bias_f, const float* bias_r,
-                                     const int32_t* lens, bl_dropout_t drop, float* P, float* Pd, void* stream) {
+static int attn_probs_fwd_impl(HeadView q, float q_scale, HeadView k, const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode,
+                               int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, const float* bias_f, const float* bias_r,
+                               const int32_t* lens, bl_dropout_t drop, float* P, float* Pd, void* stream) {
   if (B == 0) return BL_OK;
-  BL_CHECK_ARG(q && k && bias_f && bias_r && lens && P && H > 0, "bl_rel_attn_probs_fwd: null pointer");
+  BL_CHECK_ARG(q.p && k.p && bias_f && bias_r && lens && P && H > 0, "bl_rel_attn_probs_fwd: null pointer");
   BL_CHECK_ARG((row_ptr == nullptr) == (ekey == nullptr) && (ekey == nullptr) == (ecode == nullptr), "bl_rel_attn_probs_fwd: partial edge CSR");
   BL_CHECK_ARG(bl_rel_attn_probs_ok(L, dk, T), "bl_rel_attn_probs_fwd: unsupported shape L=%d dk=%d T=%d", L, dk, T);
   BL_CHECK_ARG(drop.p <= 0.f || (Pd && Pd != P && (long long)B * H * L * L < (1ll << 32)),
@@ -904,7 +1012,7 @@ extern "C" int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32
       bl_set_error("bl_rel_attn_probs_fwd: cannot raise the LDS limit");                                                          \
       return BL_EINVAL;                                                                                                           \
     }                                                                                                                             \
-    hipLaunchKernelGGL((attn_probs_fwd_kernel<DK_, KC_>), grid, dim3(1024), lds, st, q, k, row_ptr, ekey, ecode, L, H, T, bias_f, \
+    hipLaunchKernelGGL((attn_probs_fwd_kernel<DK_, KC_>), grid, dim3(1024), lds, st, q, q_scale, k, row_ptr, ekey, ecode, L, H, T, bias_f, \
                        bias_r, lens, bl_make_drop(drop), P, pd);                                                                  \
     rc = 0;                                                                                                                       \
   }
@@ -914,13 +1022,32 @@ extern "C" int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32
   BL_LAUNCH_CHECK("bl_rel_attn_probs_fwd");
   return BL_OK;
 }
+extern "C" int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode,
+                                     int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, const float* bias_f, const float* bias_r,
+                                     const int32_t* lens, bl_dropout_t drop, float* P, float* Pd, void* stream) {
+  return attn_probs_fwd_impl(hv_contiguous(q, H, L, dk), 1.0f, hv_contiguous(k, H, L, dk), row_ptr, ekey, ecode, B, L, H, dk, T, bias_f, bias_r,
+                             lens, drop, P, Pd, stream);
+}
+static int check_view(const char* who, const bl_head_view_t* v) {
+  BL_CHECK_ARG(v && v->p && bl_aligned16(v->p) && v->sb % 4 == 0 && v->sh % 4 == 0 && v->sl % 4 == 0, "%s: a head view needs a 16-byte aligned base and strides that are multiples of 4", who);
+  return BL_OK;
+}
+extern "C" int bl_rel_attn_probs_fwd_v(const bl_head_view_t* q, float q_scale, const bl_head_view_t* k, const int32_t* row_ptr,
+                                       const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T,
+                                       const float* bias_f, const float* bias_r, const int32_t* lens, bl_dropout_t drop, float* P, float* Pd,
+                                       void* stream) {
+  int rc = check_view("bl_rel_attn_probs_fwd_v", q);
+  if (rc == BL_OK) rc = check_view("bl_rel_attn_probs_fwd_v", k);
+  if (rc != BL_OK) return rc;
+  return attn_probs_fwd_impl(hv_from(q), q_scale, hv_from(k), row_ptr, ekey, ecode, B, L, H, dk, T, bias_f, bias_r, lens, drop, P, Pd, stream);
+}
 
-extern "C" int bl_rel_attn_probs_bwd(const float* g_ctx, const float* v, const float* P, const float* q, const int32_t* row_ptr,
-                                     const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T,
-                                     const float* bias_f, const float* bias_r, bl_dropout_t drop, float* dS, float* gq_edge,
-                                     float* g_bias_f, float* g_bias_r, void* stream) {
+static int attn_probs_bwd_impl(HeadView g_ctx, HeadView v, const float* P, HeadView q, float q_scale, const int32_t* row_ptr,
+                               const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T,
+                               const float* bias_f, const float* bias_r, bl_dropout_t drop, float* dS, float* gq_edge,
+                               float* g_bias_f, float* g_bias_r, void* stream) {
   if (B == 0) return BL_OK;
-  BL_CHECK_ARG(g_ctx && v && P && q && bias_f && bias_r && dS && H > 0, "bl_rel_attn_probs_bwd: null pointer");
+  BL_CHECK_ARG(g_ctx.p && v.p && P && q.p && bias_f && bias_r && dS && H > 0, "bl_rel_attn_probs_bwd: null pointer");
   BL_CHECK_ARG((row_ptr == nullptr) == (ekey == nullptr) && (ekey == nullptr) == (ecode == nullptr), "bl_rel_attn_probs_bwd: partial edge CSR");
   BL_CHECK_ARG(row_ptr == nullptr || (gq_edge && g_bias_f && g_bias_r), "bl_rel_attn_probs_bwd: edge entries need gq_edge, g_bias_f, g_bias_r");
   BL_CHECK_ARG(bl_rel_attn_probs_ok(L, dk, T), "bl_rel_attn_probs_bwd: unsupported shape L=%d dk=%d T=%d", L, dk, T);
@@ -937,7 +1064,7 @@ extern "C" int bl_rel_attn_probs_bwd(const float* g_ctx, const float* v, const f
       bl_set_error("bl_rel_attn_probs_bwd: cannot raise the LDS limit");                                                          \
       return BL_EINVAL;                                                                                                           \
     }                                                                                                                             \
-    hipLaunchKernelGGL((attn_probs_bwd_kernel<DK_, KC_>), grid, dim3(1024), lds, st, g_ctx, v, P, q, row_ptr, ekey, ecode, L, H, T, \
+    hipLaunchKernelGGL((attn_probs_bwd_kernel<DK_, KC_>), grid, dim3(1024), lds, st, g_ctx, v, P, q, q_scale, row_ptr, ekey, ecode, L, H, T, \
                        bias_f, bias_r, bl_make_drop(drop), drop.p > 0.f ? 1 : 0, dS, gq_edge, g_bias_f, g_bias_r);                \
     rc = 0;                                                                                                                       \
   }
@@ -946,6 +1073,24 @@ extern "C" int bl_rel_attn_probs_bwd(const float* g_ctx, const float* v, const f
   BL_CHECK_ARG(rc == 0, "bl_rel_attn_probs_bwd: no kernel for L=%d dk=%d", L, dk);
   BL_LAUNCH_CHECK("bl_rel_attn_probs_bwd");
   return BL_OK;
+}
+extern "C" int bl_rel_attn_probs_bwd(const float* g_ctx, const float* v, const float* P, const float* q, const int32_t* row_ptr,
+                                     const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T,
+                                     const float* bias_f, const float* bias_r, bl_dropout_t drop, float* dS, float* gq_edge,
+                                     float* g_bias_f, float* g_bias_r, void* stream) {
+  return attn_probs_bwd_impl(hv_contiguous(g_ctx, H, L, dk), hv_contiguous(v, H, L, dk), P, hv_contiguous(q, H, L, dk), 1.0f, row_ptr, ekey, ecode,
+                             B, L, H, dk, T, bias_f, bias_r, drop, dS, gq_edge, g_bias_f, g_bias_r, stream);
+}
+extern "C" int bl_rel_attn_probs_bwd_v(const bl_head_view_t* g_ctx, const bl_head_view_t* v, const float* P, const bl_head_view_t* q,
+                                       float q_scale, const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L,
+                                       int32_t H, int32_t dk, int32_t T, const float* bias_f, const float* bias_r, bl_dropout_t drop, float* dS,
+                                       float* gq_edge, float* g_bias_f, float* g_bias_r, void* stream) {
+  int rc = check_view("bl_rel_attn_probs_bwd_v", g_ctx);
+  if (rc == BL_OK) rc = check_view("bl_rel_attn_probs_bwd_v", v);
+  if (rc == BL_OK) rc = check_view("bl_rel_attn_probs_bwd_v", q);
+  if (rc != BL_OK) return rc;
+  return attn_probs_bwd_impl(hv_from(g_ctx), hv_from(v), P, hv_from(q), q_scale, row_ptr, ekey, ecode, B, L, H, dk, T, bias_f, bias_r, drop, dS,
+                             gq_edge, g_bias_f, g_bias_r, stream);
 }
 
 static int att_mm_lds(const void* fn, int L, const char* who) {
@@ -959,29 +1104,51 @@ static int att_mm_lds(const void* fn, int L, const char* who) {
 
 extern "C" int32_t bl_attn_mm32_ok(int32_t L, int32_t dk) { return dk == 32 && L > 0 && L % 4 == 0 && (size_t)L * 33 * 4 <= 152 * 1024; }
 
-extern "C" int bl_attn_rows_times(const float* A, const float* M, int32_t G, int32_t L, int32_t dk, const float* add, float scale,
-                                  float* out, void* stream) {
-  if (G == 0) return BL_OK;
-  BL_CHECK_ARG(A && M && out, "bl_attn_rows_times: null pointer");
+static int attn_rows_times_impl(const float* A, HeadView M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add, float scale,
+                                HeadView out, void* stream) {
+  if (B * H == 0) return BL_OK;
+  BL_CHECK_ARG(A && M.p && out.p, "bl_attn_rows_times: null pointer");
   BL_CHECK_ARG(bl_attn_mm32_ok(L, dk), "bl_attn_rows_times: needs dk == 32, L %% 4 == 0, L <= 1164 (got L=%d dk=%d)", L, dk);
   int rc = att_mm_lds((const void*)attn_nn32_kernel, L, "bl_attn_rows_times");
   if (rc != BL_OK) return rc;
-  dim3 grid(G, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
-  hipLaunchKernelGGL(attn_nn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, M, L, add, scale, out);
+  dim3 grid(B * H, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
+  hipLaunchKernelGGL(attn_nn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, M, H, L, add, scale, out);
   BL_LAUNCH_CHECK("bl_attn_rows_times");
   return BL_OK;
 }
+extern "C" int bl_attn_rows_times(const float* A, const float* M, int32_t G, int32_t L, int32_t dk, const float* add, float scale,
+                                  float* out, void* stream) {
+  return attn_rows_times_impl(A, hv_contiguous(M, 1, L, dk), G, 1, L, dk, add, scale, hv_contiguous(out, 1, L, dk), stream);
+}
+extern "C" int bl_attn_rows_times_v(const float* A, const bl_head_view_t* M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add,
+                                    float scale, const bl_head_view_t* out, void* stream) {
+  int rc = check_view("bl_attn_rows_times_v", M);
+  if (rc == BL_OK) rc = check_view("bl_attn_rows_times_v", out);
+  if (rc != BL_OK) return rc;
+  return attn_rows_times_impl(A, hv_from(M), B, H, L, dk, add, scale, hv_from(out), stream);
+}
 
-extern "C" int bl_attn_transposed_times(const float* A, const float* Bm, int32_t G, int32_t L, int32_t dk, float* out, void* stream) {
-  if (G == 0) return BL_OK;
-  BL_CHECK_ARG(A && Bm && out, "bl_attn_transposed_times: null pointer");
+static int attn_transposed_times_impl(const float* A, HeadView Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk, HeadView out,
+                                      void* stream) {
+  if (B * H == 0) return BL_OK;
+  BL_CHECK_ARG(A && Bm.p && out.p, "bl_attn_transposed_times: null pointer");
   BL_CHECK_ARG(bl_attn_mm32_ok(L, dk), "bl_attn_transposed_times: needs dk == 32, L %% 4 == 0, L <= 1164 (got L=%d dk=%d)", L, dk);
   int rc = att_mm_lds((const void*)attn_tn32_kernel, L, "bl_attn_transposed_times");
   if (rc != BL_OK) return rc;
-  dim3 grid(G, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
-  hipLaunchKernelGGL(attn_tn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, Bm, L, out);
+  dim3 grid(B * H, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
+  hipLaunchKernelGGL(attn_tn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, Bm, bm_scale, H, L, out);
   BL_LAUNCH_CHECK("bl_attn_transposed_times");
   return BL_OK;
+}
+extern "C" int bl_attn_transposed_times(const float* A, const float* Bm, int32_t G, int32_t L, int32_t dk, float* out, void* stream) {
+  return attn_transposed_times_impl(A, hv_contiguous(Bm, 1, L, dk), 1.0f, G, 1, L, dk, hv_contiguous(out, 1, L, dk), stream);
+}
+extern "C" int bl_attn_transposed_times_v(const float* A, const bl_head_view_t* Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk,
+                                          const bl_head_view_t* out, void* stream) {
+  int rc = check_view("bl_attn_transposed_times_v", Bm);
+  if (rc == BL_OK) rc = check_view("bl_attn_transposed_times_v", out);
+  if (rc != BL_OK) return rc;
+  return attn_transposed_times_impl(A, hv_from(Bm), bm_scale, B, H, L, dk, hv_from(out), stream);
 }
 
 extern "C" int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L,

@@ -54,7 +54,15 @@ def make(name, *, use_value_bias, scalar, norm, seed, D=64, H=4, FF=96, T=5, L=2
     print(name, float(y.abs().mean()))
 
 
+CASES = {
+    "great": dict(use_value_bias=False, scalar=False, norm="postnorm", seed=0),   # what the registry's seq-great runs
+    "rat": dict(use_value_bias=True, scalar=False, norm="prenorm", seed=1),       # seq-rat + the prenorm branch
+    "scalar": dict(use_value_bias=False, scalar=True, norm="postnorm", seed=2),   # GREAT as published (scalar key bias)
+    # seq-great's configuration at head dimension 32 (BASELINE configs[4]: 256 / 8 heads): the shape the one-call-per-layer
+    # form (bl_great_layer_fwd / _bwd) takes -- added in round 6; the three cases above were not regenerated
+    "great32": dict(use_value_bias=False, scalar=False, norm="postnorm", seed=3, D=64, H=2, FF=96),
+}
+
 if __name__ == "__main__":
-    make("great", use_value_bias=False, scalar=False, norm="postnorm", seed=0)   # what the registry's seq-great runs
-    make("rat", use_value_bias=True, scalar=False, norm="prenorm", seed=1)       # seq-rat + the prenorm branch
-    make("scalar", use_value_bias=False, scalar=True, norm="postnorm", seed=2)   # GREAT as published (scalar key bias)
+    for name in (sys.argv[1:] or list(CASES)):
+        make(name, **CASES[name])

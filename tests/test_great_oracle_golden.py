@@ -12,7 +12,7 @@ from oracle import great_oracle as G
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name", ["great", "rat", "scalar"])
+@pytest.mark.parametrize("name", ["great", "rat", "scalar", "great32"])
 def test_encoder_stack_matches_reference(name):
     z = np.load(os.path.join(GOLD, f"great_{name}.npz"))
     D, H, layers, FF, T, value_bias, scalar = (int(v) for v in z["cfg"])

@@ -31,12 +31,25 @@ def _gpu():
     hip_ops.load_library()
 
 
-@pytest.mark.parametrize("name", ["great", "rat", "scalar"])
+@pytest.mark.parametrize("name", ["great", "rat", "scalar", "great32", "great32-op-by-op"])
 def test_encoder_stack_matches_reference_golden(name):
+    """great32 (head dimension 32) is the shape the one-call-per-layer form takes (bl_great_layer_fwd / _bwd: head views, packed
+    hand-overs, gradient epilogues); "-op-by-op" runs the same case with that form switched off."""
     from buglab.data.seqcollate import edge_csr
+    from buglab.models import hip_ops
     from buglab.models.hip_ops import RelEdges
     from buglab.models.layers.relational_transformer import RelationalTransformerEncoderLayer
 
+    fused_before = hip_ops.FUSED_GREAT_LAYER
+    if name.endswith("-op-by-op"):
+        name, hip_ops.FUSED_GREAT_LAYER = name[: -len("-op-by-op")], False
+    try:
+        _golden_case(name, edge_csr, hip_ops, RelEdges, RelationalTransformerEncoderLayer)
+    finally:
+        hip_ops.FUSED_GREAT_LAYER = fused_before
+
+
+def _golden_case(name, edge_csr, hip_ops, RelEdges, RelationalTransformerEncoderLayer):
     z = np.load(os.path.join(GOLD, f"great_{name}.npz"))
     D, H, layers, FF, T, value_bias, scalar = (int(v) for v in z["cfg"])
     norm = str(z["norm"])
@@ -63,9 +76,16 @@ def test_encoder_stack_matches_reference_golden(name):
     assert (masked == (np.arange(L)[None, :] >= lens.cpu().numpy()[:, None])).all()
     rp, key, code = edge_csr(z["edges"], z["edge_types"], B, L)
     edges = RelEdges(torch.from_numpy(rp).cuda(), torch.from_numpy(key).cuda(), torch.from_numpy(code).cuda(), int(key.shape[0]))
-    y = x.view(B * L, D)
-    for layer in stack:
-        y = layer(y, lens, edges, B, L)
+    for attempt in range(2):  # (the first pass also packs the weight images; the second is counted)
+        calls0 = hip_ops.CALL_COUNT
+        y, chain = x.view(B * L, D), {}
+        for layer in stack:
+            y = layer(y, lens, edges, B, L, chain=chain)
+    if name == "great32":
+        want_fused = hip_ops.FUSED_GREAT_LAYER
+        assert stack[0].fused_call_ok(B, L) == want_fused
+        if want_fused:  # one C call per layer
+            assert hip_ops.CALL_COUNT - calls0 == len(stack), hip_ops.CALL_COUNT - calls0
     y = y.view(B, L, D)
     valid = torch.from_numpy(~masked).cuda()
     ref_y = torch.zeros(B, L, D)
@@ -89,6 +109,73 @@ def test_encoder_stack_matches_reference_golden(name):
             assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), (i, ours)
     if norm == "postnorm":  # the reference's quirk: norm2 never receives a gradient under postnorm
         assert stack[0].norm2_g.grad is None or float(stack[0].norm2_g.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,L,H,T,FF,p,edges_on", [(2, 64, 2, 3, 96, 0.0, True), (3, 200, 4, 8, 256, 0.2, True), (2, 512, 8, 8, 1024, 0.1, True),
+                                                    (2, 96, 2, 4, 64, 0.3, False)])
+def test_one_call_layer_equals_the_op_by_op_path(B, L, H, T, FF, p, edges_on):
+    """hip_ops.great_layer (csrc/bl_great_layer.hip) against the op-by-op path it replaces, two stacked layers, same parameters and
+    dropout counters: outputs and every gradient.  The two paths differ in the order LayerNorm sums a row (and nothing else:
+    same GEMM kernels, same masks), so the bound is a few fp32 roundings of the largest entry."""
+    from buglab.data.seqcollate import edge_csr
+    from buglab.models import hip_ops
+    from buglab.models.hip_ops import RelEdges
+    from buglab.models.layers.relational_transformer import RelationalTransformerEncoderLayer
+
+    torch.manual_seed(1)
+    dk = 32
+    D = H * dk
+    stack = torch.nn.ModuleList([RelationalTransformerEncoderLayer(D, dk, dk, H, T, dim_feedforward=FF, dropout=p) for _ in range(2)]).cuda().train()
+    with torch.no_grad():
+        for l in stack:
+            l.norm1_g.add_(0.2 * torch.randn_like(l.norm1_g))
+            l.norm1_b.add_(0.2 * torch.randn_like(l.norm1_b))
+    rng = np.random.default_rng(0)
+    lens_np = rng.integers(max(1, L // 2), L + 1, size=B).astype(np.int32)
+    lens_np[0] = L
+    lens = torch.from_numpy(lens_np).cuda()
+    ne = 6 * B * L if edges_on else 0
+    s_ = rng.integers(0, B, size=ne)
+    e = np.stack([s_, (rng.random(ne) * lens_np[s_]).astype(np.int64), (rng.random(ne) * lens_np[s_]).astype(np.int64)], 1)
+    rp, key, code = edge_csr(e, rng.integers(0, T, size=ne), B, L)
+    edges = RelEdges(torch.from_numpy(rp).cuda(), torch.from_numpy(key).cuda(), torch.from_numpy(code).cuda(), int(key.shape[0]))
+    x0 = torch.randn(B * L, D, device="cuda")
+    w = torch.randn(B * L, D, device="cuda")
+
+    def run(fused):
+        before = hip_ops.FUSED_GREAT_LAYER
+        hip_ops.FUSED_GREAT_LAYER = fused
+        try:
+            for q in stack.parameters():
+                q.grad = None
+            x = x0.clone().requires_grad_(True)
+            assert stack[0].fused_call_ok(B, L) == fused
+            y, chain = x, {}
+            for i, l in enumerate(stack):
+                y = l(y, lens, edges, B, L, dropout_seed=11 if p > 0 else None, dropout_stream=8 * (i + 1), chain=chain)
+            (y * w).sum().backward()
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone(), {n: (q.grad.clone() if q.grad is not None else None) for n, q in stack.named_parameters()}
+        finally:
+            hip_ops.FUSED_GREAT_LAYER = before
+
+    y_f, gx_f, gp_f = run(True)
+    y_o, gx_o, gp_o = run(False)
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    assert close(y_f, y_o, 2e-5), float((y_f - y_o).abs().max())
+    assert close(gx_f, gx_o, 5e-5), float((gx_f - gx_o).abs().max())
+    for n in gp_o:
+        if gp_o[n] is None:
+            assert gp_f[n] is None or float(gp_f[n].abs().max()) == 0.0, n
+            continue
+        assert gp_f[n] is not None, n
+        assert close(gp_f[n], gp_o[n], 5e-5), (n, float((gp_f[n] - gp_o[n]).abs().max()), float(gp_o[n].abs().max()))
+    # forward-only form (no_grad: nothing saved) gives the same output
+    with torch.no_grad():
+        y, chain = x0, {}
+        for i, l in enumerate(stack):
+            y = l(y, lens, edges, B, L, dropout_seed=11 if p > 0 else None, dropout_stream=8 * (i + 1), chain=chain)
+    assert torch.equal(y, y_f)
 
 
 def test_attention_dropout_and_padding():
@@ -273,8 +360,9 @@ def _oracle_params(module):
     return out
 
 
-@pytest.mark.parametrize("model_name", ["seq-great", "seq-rat"])
-def test_seq_model_end_to_end_matches_oracle(model_name):
+@pytest.mark.parametrize("model_name,hidden,heads", [("seq-great", 64, 4), ("seq-rat", 64, 4), ("seq-great", 64, 2)])
+def test_seq_model_end_to_end_matches_oracle(model_name, hidden, heads):
+    """(seq-great, 64, 2): head dimension 32 -- the layers run as one C call per direction (bl_great_layer_fwd / _bwd)."""
     import copy
     from pathlib import Path
 
@@ -285,7 +373,7 @@ def test_seq_model_end_to_end_matches_oracle(model_name):
     from oracle import seq_oracle as SO
 
     data = make_buglab_seq_dataset(6, seed=5)
-    model = load_model({"modelName": model_name, "hidden_state_size": 64, "num_layers": 2, "num_heads": 4, "intermediate_dimension_size": 96,
+    model = load_model({"modelName": model_name, "hidden_state_size": hidden, "num_layers": 2, "num_heads": heads, "intermediate_dimension_size": 96,
                         "dropout_rate": 0.0}, Path("/tmp/_bl_seq_e2e.pkl.gz"))[0]
     model.compute_metadata(copy.deepcopy(data))
     torch.manual_seed(0)
@@ -301,7 +389,7 @@ def test_seq_model_end_to_end_matches_oracle(model_name):
     named = dict(nn_.named_parameters())
     table = _oracle_params(nn_)
     p = {k: v[0].clone().requires_grad_(True) for k, v in table.items()}
-    cfg = G.GreatConfig(d_model=64, num_heads=4, num_layers=2, dim_feedforward=96, num_edge_types=max(1, len(model.edge_types)),
+    cfg = G.GreatConfig(d_model=hidden, num_heads=heads, num_layers=2, dim_feedforward=96, num_edge_types=max(1, len(model.edge_types)),
                         use_edge_value_biases=model_name == "seq-rat")
     out = SO.forward_loss(p, mb_np, cfg)
     assert abs(float(loss.detach()) - float(out["loss"])) < 1e-4, (float(loss.detach()), float(out["loss"]))
