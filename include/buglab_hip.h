@@ -654,10 +654,13 @@ int bl_rel_attn_probs_bwd_v(const bl_head_view_t* g_ctx, const bl_head_view_t* v
                             const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk,
                             int32_t T, const float* bias_f, const float* bias_r, bl_dropout_t drop, float* dS, float* gq_edge,
                             float* g_bias_f, float* g_bias_r, void* stream);
+/* a_drop (p > 0): A is read through the counter-hash dropout mask, element index (g L + i) L + k -- A = the probabilities P of
+ * bl_rel_attn_probs_fwd_v called with Pd == NULL: nn.Dropout on the attention probabilities (multihead_attention.py:72) without
+ * a stored copy of the dropped matrix */
 int bl_attn_rows_times_v(const float* A, const bl_head_view_t* M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add, float scale,
-                         const bl_head_view_t* out, void* stream);
+                         const bl_head_view_t* out, bl_dropout_t a_drop, void* stream);
 int bl_attn_transposed_times_v(const float* A, const bl_head_view_t* Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk,
-                               const bl_head_view_t* out, void* stream);
+                               const bl_head_view_t* out, bl_dropout_t a_drop, void* stream);
 /* `rat` edge value biases (relational_multihead_attention.py:155-178): ctx[b, h, i, :] += P[(b, h, i), key] * vb[code][h, :] */
 int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
                           int32_t dk, const float* P, const float* vb_f, const float* vb_r, float* ctx, void* stream);
@@ -713,7 +716,7 @@ typedef struct {
 int32_t bl_great_layer_ok(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, int32_t FF);
 /* `saved` (forward -> backward; own_xp: the call packs x itself because no x_packed is handed in) and workspace bytes
  * (backward: 0 = forward, 1 = backward, 3 = forward-only call with saved == NULL) */
-int64_t bl_great_layer_saved_bytes(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t FF, int32_t attn_dropout, int32_t own_xp);
+int64_t bl_great_layer_saved_bytes(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t FF, int32_t own_xp);
 int64_t bl_great_layer_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t FF, int32_t backward);
 int bl_great_layer_fwd(const bl_great_layer_t* d, const float* x, const uint16_t* x_packed, float* out, uint16_t* out_packed, void* saved,
                        void* ws, void* stream);

@@ -1693,7 +1693,7 @@ class _GreatLayer(torch.autograd.Function):
         packs = [_packed_layer_weights(_f32(W, "W"), need_bwd) for W in (qkv_W, out_W, lin1_W, lin2_W)]
         d = _great_desc(B, L, H, dk, T, FF, lens, edges, bias_f, bias_r, norm_g, norm_b, lin1_b, lin2_b, packs, drops)
         xp = chain.get("packed") if (chain is not None and chain.get("of") == (x.data_ptr(), x._version)) else None
-        saved = (torch.empty((lib.bl_great_layer_saved_bytes(B, L, H, dk, FF, 1 if drops[0].p > 0 else 0, 1 if xp is None else 0),),
+        saved = (torch.empty((lib.bl_great_layer_saved_bytes(B, L, H, dk, FF, 1 if xp is None else 0),),
                              dtype=torch.uint8, device=dev) if need_bwd else None)
         ws = torch.empty((lib.bl_great_layer_workspace_bytes(B, L, H, dk, FF, 0 if need_bwd else 3),), dtype=torch.uint8, device=dev)
         out = torch.empty_like(x)

@@ -162,11 +162,11 @@ _SIGNATURES = {
                                  c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, bl_dropout_t, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p], ctypes.c_int),
     "bl_attn_rows_times_v": ([c_void_p, POINTER(bl_head_view_t), c_int32, c_int32, c_int32, c_int32, c_void_p, c_float, POINTER(bl_head_view_t),
-                              c_void_p], ctypes.c_int),
+                              bl_dropout_t, c_void_p], ctypes.c_int),
     "bl_attn_transposed_times_v": ([c_void_p, POINTER(bl_head_view_t), c_float, c_int32, c_int32, c_int32, c_int32, POINTER(bl_head_view_t),
-                                    c_void_p], ctypes.c_int),
+                                    bl_dropout_t, c_void_p], ctypes.c_int),
     "bl_great_layer_ok": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int32),
-    "bl_great_layer_saved_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
+    "bl_great_layer_saved_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
     "bl_great_layer_workspace_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
     "bl_great_layer_fwd": ([POINTER(bl_great_layer_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_great_layer_bwd": ([POINTER(bl_great_layer_t), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(bl_great_layer_grads_t), c_void_p,

@@ -7,6 +7,7 @@
 //   * no permuted copies of q / k / v / context or their gradients: the attention kernels address the QKV projection's own
 //     [B L, H 3 dk] output (and the [B L, H dk] context) through head views (bl_head_view_t); the query scale dk^-0.5 is applied
 //     where q is loaded;
+//   * the dropped attention probabilities are never stored: P.V and P^T.dO read P through the counter-hash mask;
 //   * no packing pass in front of a Linear whose input a kernel of the layer just produced: LayerNorm writes its result also in
 //     bl_pack_bf16x3's form, linear1's epilogue writes relu + dropout ONLY packed (the fp32 hidden activations never exist);
 //   * no elementwise backward kernels: the gradient through dropout(Linear(.)) of a residual branch leaves the LayerNorm
@@ -37,8 +38,7 @@ inline Shape shape_of(int B, int L, int H, int dk, int FF, int T) {
 struct Saved {  // forward -> backward
   uint16_t* xp;      // [R, 3 D]   the layer input, packed (only when the caller did not hand one in)
   float* qkv;        // [R, 3 D]   per head [q | k | v]
-  float* P;          // [G L, L]   attention probabilities
-  float* Pd;         // [G L, L]   ... after dropout (= P without dropout)
+  float* P;          // [G L, L]   attention probabilities BEFORE dropout (the mask is applied where P is read)
   uint16_t* ctx_p;   // [R, 3 D]   packed attention context
   float* z1;         // [R, D]     x + attention branch
   float *mean1, *rstd1;
@@ -48,7 +48,7 @@ struct Saved {  // forward -> backward
   float *mean2, *rstd2;
   size_t bytes;
 };
-Saved carve_saved(void* base, const Shape& s, bool attn_dropout, bool own_xp) {
+Saved carve_saved(void* base, const Shape& s, bool own_xp) {
   Saved v;
   char* p = static_cast<char*>(base);
   size_t o = 0;
@@ -56,8 +56,6 @@ Saved carve_saved(void* base, const Shape& s, bool attn_dropout, bool own_xp) {
   TAKE(xp, uint16_t, own_xp ? s.R * 3 * s.D : 0)
   TAKE(qkv, float, s.R * 3 * s.D)
   TAKE(P, float, s.G * s.L * s.L)
-  TAKE(Pd, float, attn_dropout ? s.G * s.L * s.L : 0)
-  if (!attn_dropout) v.Pd = v.P;
   TAKE(ctx_p, uint16_t, s.R * 3 * s.D)
   TAKE(z1, float, s.R * s.D)
   TAKE(mean1, float, s.R)
@@ -182,15 +180,15 @@ extern "C" int32_t bl_great_layer_ok(int32_t B, int32_t L, int32_t H, int32_t dk
   return 1;
 }
 
-extern "C" int64_t bl_great_layer_saved_bytes(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t FF, int32_t attn_dropout, int32_t own_xp) {
-  return (int64_t)carve_saved(nullptr, shape_of(B, L, H, dk, FF, 1), attn_dropout != 0, own_xp != 0).bytes;
+extern "C" int64_t bl_great_layer_saved_bytes(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t FF, int32_t own_xp) {
+  return (int64_t)carve_saved(nullptr, shape_of(B, L, H, dk, FF, 1), own_xp != 0).bytes;
 }
 
 extern "C" int64_t bl_great_layer_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t dk, int32_t FF, int32_t backward) {
   const Shape s = shape_of(B, L, H, dk, FF, 1);
   if (backward == 1) return (int64_t)carve_bwd(nullptr, s).bytes;
   const size_t f = carve_fwd(nullptr, s).bytes;
-  return (int64_t)(backward == 3 ? f + carve_saved(nullptr, s, true, true).bytes : f);
+  return (int64_t)(backward == 3 ? f + carve_saved(nullptr, s, true).bytes : f);
 }
 
 extern "C" int bl_great_layer_fwd(const bl_great_layer_t* d, const float* x, const uint16_t* x_packed, float* out, uint16_t* out_packed,
@@ -201,9 +199,7 @@ extern "C" int bl_great_layer_fwd(const bl_great_layer_t* d, const float* x, con
   const int R = (int)s.R, D = (int)s.D, FF = s.FF, dk = s.dk;
   const WsFwd w = carve_fwd(ws, s);
   // forward-only call (saved == NULL): what a backward pass would read lives in the workspace instead
-  const bool attn_drop = has_drop(d->drop_attn);
-  const Saved sv = saved ? carve_saved(saved, s, attn_drop, x_packed == nullptr)
-                         : carve_saved(static_cast<char*>(ws) + w.bytes, s, true, true);
+  const Saved sv = saved ? carve_saved(saved, s, x_packed == nullptr) : carve_saved(static_cast<char*>(ws) + w.bytes, s, true);
   const float scale = 1.0f / sqrtf((float)dk);
 
   const uint16_t* xp = x_packed;
@@ -220,14 +216,14 @@ extern "C" int bl_great_layer_fwd(const bl_great_layer_t* d, const float* x, con
   const bl_head_view_t q = view_of(sv.qkv, 0, s, 3 * D, 3 * dk), k = view_of(sv.qkv, dk, s, 3 * D, 3 * dk),
                        v = view_of(sv.qkv, 2 * dk, s, 3 * D, 3 * dk);
   {  // softmax(q k^T / sqrt(dk) + edge terms), dropout (multihead_attention.py:54-72, relational_multihead_attention.py:135-152)
-    BlProfScope ps(BL_PROF_ATTN_PROBS_FWD, 0.0, stream, 4.0 * s.G * s.L * (s.L * (attn_drop ? 2.0 : 1.0) + 2.0 * dk));
+    BlProfScope ps(BL_PROF_ATTN_PROBS_FWD, 0.0, stream, 4.0 * s.G * s.L * (s.L + 2.0 * dk));
     GL_TRY(bl_rel_attn_probs_fwd_v(&q, scale, &k, d->row_ptr, d->ekey, d->ecode, s.B, s.L, s.H, dk, s.T, d->bias_f, d->bias_r, d->lens,
-                                   d->drop_attn, sv.P, sv.Pd, stream));
+                                   d->drop_attn, sv.P, nullptr, stream));
   }
   {  // context = P . V, written as [B L, H dk]
     BlProfScope ps(BL_PROF_ATTN_ROWS_TIMES, 2.0 * s.G * s.L * s.L * dk, stream, 4.0 * s.G * s.L * (s.L + 2.0 * dk));
     const bl_head_view_t c = view_of(w.ctx, 0, s, D, dk);
-    GL_TRY(bl_attn_rows_times_v(sv.Pd, &v, s.B, s.H, s.L, dk, nullptr, 1.0f, &c, stream));
+    GL_TRY(bl_attn_rows_times_v(sv.P, &v, s.B, s.H, s.L, dk, nullptr, 1.0f, &c, d->drop_attn, stream));
   }
   {
     BlProfScope ps(BL_PROF_PACK_ROWS, 0.0, stream);
@@ -275,8 +271,7 @@ extern "C" int bl_great_layer_bwd(const bl_great_layer_t* d, const uint16_t* x_p
   BL_CHECK_ARG(d->row_ptr == nullptr || (g->bias_f && g->bias_r), "bl_great_layer_bwd: edge entries need the edge-bias gradient buffers");
   const Shape s = shape_of(d->B, d->L, d->H, d->dk, d->FF, d->T);
   const int R = (int)s.R, D = (int)s.D, FF = s.FF, dk = s.dk;
-  const bool attn_drop = has_drop(d->drop_attn);
-  const Saved sv = carve_saved(const_cast<void*>(saved), s, attn_drop, x_packed == nullptr);
+  const Saved sv = carve_saved(const_cast<void*>(saved), s, x_packed == nullptr);
   const WsBwd w = carve_bwd(ws, s);
   const uint16_t* xp = x_packed ? x_packed : sv.xp;
   const float scale = 1.0f / sqrtf((float)dk);
@@ -350,10 +345,11 @@ extern "C" int bl_great_layer_bwd(const bl_great_layer_t* d, const uint16_t* x_p
   const bl_head_view_t gq = view_of(w.g_qkv, 0, s, 3 * D, 3 * dk), gk = view_of(w.g_qkv, dk, s, 3 * D, 3 * dk),
                        gv = view_of(w.g_qkv, 2 * dk, s, 3 * D, 3 * dk);
   const bl_head_view_t gc = view_of(w.g_ctx, 0, s, D, dk);
+  const bl_dropout_t nodrop = {0.f, 0u, 0u};
   const double mm_flop = 2.0 * s.G * s.L * s.L * dk, mm_bytes = 4.0 * s.G * s.L * (s.L + 2.0 * dk);
   {  // g_v = Pd^T . dO
     BlProfScope ps(BL_PROF_ATTN_TRANSPOSED_TIMES, mm_flop, stream, mm_bytes, two);
-    GL_TRY(bl_attn_transposed_times_v(sv.Pd, &gc, 1.0f, s.B, s.H, s.L, dk, &gv, stream));
+    GL_TRY(bl_attn_transposed_times_v(sv.P, &gc, 1.0f, s.B, s.H, s.L, dk, &gv, d->drop_attn, stream));
   }
   const bool edges = d->row_ptr != nullptr;
   if (edges && hipMemsetAsync(w.gq_edge, 0, s.R * s.D * sizeof(float), st) != hipSuccess) {
@@ -367,11 +363,11 @@ extern "C" int bl_great_layer_bwd(const bl_great_layer_t* d, const uint16_t* x_p
   }
   {  // g_q = (dS . K + edge part) / sqrt(dk)
     BlProfScope ps(BL_PROF_ATTN_ROWS_TIMES, mm_flop, stream, mm_bytes, two);
-    GL_TRY(bl_attn_rows_times_v(w.dS, &k, s.B, s.H, s.L, dk, edges ? w.gq_edge : nullptr, scale, &gq, stream));
+    GL_TRY(bl_attn_rows_times_v(w.dS, &k, s.B, s.H, s.L, dk, edges ? w.gq_edge : nullptr, scale, &gq, nodrop, stream));
   }
   {  // g_k = dS^T . (q / sqrt(dk))
     BlProfScope ps(BL_PROF_ATTN_TRANSPOSED_TIMES, mm_flop, stream, mm_bytes, two);
-    GL_TRY(bl_attn_transposed_times_v(w.dS, &q, scale, s.B, s.H, s.L, dk, &gk, stream));
+    GL_TRY(bl_attn_transposed_times_v(w.dS, &q, scale, s.B, s.H, s.L, dk, &gk, nodrop, stream));
   }
   {
     BlProfScope ps(BL_PROF_PACK_ROWS, 0.0, stream, 0.0, two);

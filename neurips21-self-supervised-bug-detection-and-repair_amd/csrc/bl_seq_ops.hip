@@ -362,9 +362,10 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const HeadView q, 
   const float* __restrict__ qg = hv_mat(q, b, h);
   {
     const float* __restrict__ kg = hv_mat(k, b, h);
-    for (int x = tid; x < LP * DK; x += 1024) {
-      const int j = x / DK, d = x - j * DK;
-      Kt[d * LS + j] = j < L ? kg[(size_t)j * k.sl + d] : 0.f;
+    for (int x = tid; x < LP * (DK / 4); x += 1024) {  // 16 bytes per thread: a row of the head is DK / 4 of them
+      const int j = x / (DK / 4), d = 4 * (x - j * (DK / 4));
+      const float4 kv4 = j < L ? *reinterpret_cast<const float4*>(kg + (size_t)j * k.sl + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+      Kt[d * LS + j] = kv4.x; Kt[(d + 1) * LS + j] = kv4.y; Kt[(d + 2) * LS + j] = kv4.z; Kt[(d + 3) * LS + j] = kv4.w;
     }
     for (int x = tid; x < 2 * T * DK; x += 1024) {
       const int c = x / DK, d = x - c * DK;
@@ -511,9 +512,10 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const HeadView g_c
   const float* __restrict__ qg = hv_mat(q, b, h);
   {
     const float* __restrict__ vg = hv_mat(v, b, h);
-    for (int x = tid; x < LP * DK; x += 1024) {
-      const int j = x / DK, d = x - j * DK;
-      Vt[d * LS + j] = j < L ? vg[(size_t)j * v.sl + d] : 0.f;
+    for (int x = tid; x < LP * (DK / 4); x += 1024) {
+      const int j = x / (DK / 4), d = 4 * (x - j * (DK / 4));
+      const float4 vv4 = j < L ? *reinterpret_cast<const float4*>(vg + (size_t)j * v.sl + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+      Vt[d * LS + j] = vv4.x; Vt[(d + 1) * LS + j] = vv4.y; Vt[(d + 2) * LS + j] = vv4.z; Vt[(d + 3) * LS + j] = vv4.w;
     }
     if (row_ptr) {
       for (int x = tid; x < ntab; x += 1024) {
@@ -675,15 +677,21 @@ typedef float att_f32x16 __attribute__((ext_vector_type(16)));
 #define ATT_MM_WAVES 8
 
 // out[(g, i), :] = (sum_k A[(g, i), k] M[g, k, :] (+ add[(g, i), :])) * scale
+// a_drop (thresh != 0): A is read through the counter-hash dropout mask, element index (g L + i) L + k -- the dropped
+// probabilities of multihead_attention.py:72 are never stored (bl_rel_attn_probs_fwd's Pd)
 __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const float* __restrict__ A, const HeadView M, int H, int L,
                                                                       const float* __restrict__ add, float scale,
-                                                                      const HeadView out) {
+                                                                      const HeadView out, const bl_drop_dev a_drop) {
   extern __shared__ __attribute__((aligned(16))) float att_lds[];  // [L][33]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, half = lane >> 5;
   const int g = blockIdx.x, gb = g / H, gh = g - gb * H;
   {
     const float* __restrict__ mg = hv_mat(M, gb, gh);
-    for (int x = tid; x < L * 32; x += 64 * ATT_MM_WAVES) att_lds[(x >> 5) * 33 + (x & 31)] = mg[(size_t)(x >> 5) * M.sl + (x & 31)];
+    for (int x = tid; x < L * 8; x += 64 * ATT_MM_WAVES) {
+      const float4 m4 = *reinterpret_cast<const float4*>(mg + (size_t)(x >> 3) * M.sl + 4 * (x & 7));
+      float* o = att_lds + (x >> 3) * 33 + 4 * (x & 7);
+      o[0] = m4.x; o[1] = m4.y; o[2] = m4.z; o[3] = m4.w;
+    }
   }
   __syncthreads();
   const int r0 = (blockIdx.y * ATT_MM_WAVES + wave) * 32;
@@ -703,7 +711,12 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const f
 #pragma unroll
     for (int qq = 0; qq < 8; ++qq) {
       const int k = min(k0 + 8 * qq + 4 * half, L - 4);
-      const float av[4] = {a[qq].x, a[qq].y, a[qq].z, a[qq].w};
+      float av[4] = {a[qq].x, a[qq].y, a[qq].z, a[qq].w};
+      if (a_drop.thresh) {  // (uniform)
+        const uint32_t e0 = (uint32_t)((size_t)g * L + row) * (uint32_t)L + (uint32_t)k;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) av[s2] = bl_keep(a_drop, e0 + s2) ? av[s2] * a_drop.scale : 0.f;
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(att_lds[(k + s2) * 33 + li], av[s2], acc, 0, 0, 0);
@@ -728,13 +741,17 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const f
 
 // out[g, key, :] = sum_i A[(g, i), key] Bm[g, i, :]
 __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_tn32_kernel(const float* __restrict__ A, const HeadView Bm, float bm_scale,
-                                                                      int H, int L, const HeadView out) {
+                                                                      int H, int L, const HeadView out, const bl_drop_dev a_drop) {
   extern __shared__ __attribute__((aligned(16))) float att_lds[];  // [L][33]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, half = lane >> 5;
   const int g = blockIdx.x, gb = g / H, gh = g - gb * H;
   {
     const float* __restrict__ bg = hv_mat(Bm, gb, gh);
-    for (int x = tid; x < L * 32; x += 64 * ATT_MM_WAVES) att_lds[(x >> 5) * 33 + (x & 31)] = bg[(size_t)(x >> 5) * Bm.sl + (x & 31)] * bm_scale;
+    for (int x = tid; x < L * 8; x += 64 * ATT_MM_WAVES) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bg + (size_t)(x >> 3) * Bm.sl + 4 * (x & 7));
+      float* o = att_lds + (x >> 3) * 33 + 4 * (x & 7);
+      o[0] = b4.x * bm_scale; o[1] = b4.y * bm_scale; o[2] = b4.z * bm_scale; o[3] = b4.w * bm_scale;
+    }
   }
   __syncthreads();
   const int key0 = (blockIdx.y * ATT_MM_WAVES + wave) * 32;
@@ -751,6 +768,13 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_tn32_kernel(const f
     for (int u = 0; u < 32; ++u) {
       const float* __restrict__ rowp = ag + (size_t)(i0 + 2 * u) * L;
       a[u] = i0 + 2 * u < L ? rowp[voff] : 0.f;  // (L is even: row i0 + 2 u + 1 exists whenever row i0 + 2 u does)
+    }
+    if (a_drop.thresh) {  // (uniform)
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const uint32_t e = (uint32_t)((size_t)g * L + i0 + 2 * u + half) * (uint32_t)L + (uint32_t)key;
+        a[u] = bl_keep(a_drop, e) ? a[u] * a_drop.scale : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
@@ -997,8 +1021,9 @@ static int attn_probs_fwd_impl(HeadView q, float q_scale, HeadView k, const int3
   BL_CHECK_ARG(q.p && k.p && bias_f && bias_r && lens && P && H > 0, "bl_rel_attn_probs_fwd: null pointer");
   BL_CHECK_ARG((row_ptr == nullptr) == (ekey == nullptr) && (ekey == nullptr) == (ecode == nullptr), "bl_rel_attn_probs_fwd: partial edge CSR");
   BL_CHECK_ARG(bl_rel_attn_probs_ok(L, dk, T), "bl_rel_attn_probs_fwd: unsupported shape L=%d dk=%d T=%d", L, dk, T);
-  BL_CHECK_ARG(drop.p <= 0.f || (Pd && Pd != P && (long long)B * H * L * L < (1ll << 32)),
-               "bl_rel_attn_probs_fwd: dropout needs a second output and fewer than 2^32 scores");
+  // (Pd == NULL with dropout: only P is written -- the consumer applies the mask where it reads P, bl_attn_*_times_v's a_drop)
+  BL_CHECK_ARG(drop.p <= 0.f || ((Pd == nullptr || Pd != P) && (long long)B * H * L * L < (1ll << 32)),
+               "bl_rel_attn_probs_fwd: dropout needs a second output (or none) and fewer than 2^32 scores");
   const int kc = (L + 255) / 256;
   const size_t lds = att_lds_bytes(L, dk, T);
   float* pd = drop.p > 0.f ? Pd : nullptr;
@@ -1025,6 +1050,7 @@ static int attn_probs_fwd_impl(HeadView q, float q_scale, HeadView k, const int3
 extern "C" int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode,
                                      int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T, const float* bias_f, const float* bias_r,
                                      const int32_t* lens, bl_dropout_t drop, float* P, float* Pd, void* stream) {
+  BL_CHECK_ARG(drop.p <= 0.f || Pd, "bl_rel_attn_probs_fwd: dropout needs a second output");
   return attn_probs_fwd_impl(hv_contiguous(q, H, L, dk), 1.0f, hv_contiguous(k, H, L, dk), row_ptr, ekey, ecode, B, L, H, dk, T, bias_f, bias_r,
                              lens, drop, P, Pd, stream);
 }
@@ -1105,50 +1131,56 @@ static int att_mm_lds(const void* fn, int L, const char* who) {
 extern "C" int32_t bl_attn_mm32_ok(int32_t L, int32_t dk) { return dk == 32 && L > 0 && L % 4 == 0 && (size_t)L * 33 * 4 <= 152 * 1024; }
 
 static int attn_rows_times_impl(const float* A, HeadView M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add, float scale,
-                                HeadView out, void* stream) {
+                                HeadView out, bl_dropout_t a_drop, void* stream) {
   if (B * H == 0) return BL_OK;
   BL_CHECK_ARG(A && M.p && out.p, "bl_attn_rows_times: null pointer");
   BL_CHECK_ARG(bl_attn_mm32_ok(L, dk), "bl_attn_rows_times: needs dk == 32, L %% 4 == 0, L <= 1164 (got L=%d dk=%d)", L, dk);
   int rc = att_mm_lds((const void*)attn_nn32_kernel, L, "bl_attn_rows_times");
   if (rc != BL_OK) return rc;
   dim3 grid(B * H, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
-  hipLaunchKernelGGL(attn_nn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, M, H, L, add, scale, out);
+  BL_CHECK_ARG(a_drop.p <= 0.f || (long long)B * H * L * L < (1ll << 32), "bl_attn_rows_times: more than 2^32 elements under a dropout mask");
+  hipLaunchKernelGGL(attn_nn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, M, H, L, add, scale, out,
+                     bl_make_drop(a_drop));
   BL_LAUNCH_CHECK("bl_attn_rows_times");
   return BL_OK;
 }
 extern "C" int bl_attn_rows_times(const float* A, const float* M, int32_t G, int32_t L, int32_t dk, const float* add, float scale,
                                   float* out, void* stream) {
-  return attn_rows_times_impl(A, hv_contiguous(M, 1, L, dk), G, 1, L, dk, add, scale, hv_contiguous(out, 1, L, dk), stream);
+  const bl_dropout_t none = {0.f, 0u, 0u};
+  return attn_rows_times_impl(A, hv_contiguous(M, 1, L, dk), G, 1, L, dk, add, scale, hv_contiguous(out, 1, L, dk), none, stream);
 }
 extern "C" int bl_attn_rows_times_v(const float* A, const bl_head_view_t* M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add,
-                                    float scale, const bl_head_view_t* out, void* stream) {
+                                    float scale, const bl_head_view_t* out, bl_dropout_t a_drop, void* stream) {
   int rc = check_view("bl_attn_rows_times_v", M);
   if (rc == BL_OK) rc = check_view("bl_attn_rows_times_v", out);
   if (rc != BL_OK) return rc;
-  return attn_rows_times_impl(A, hv_from(M), B, H, L, dk, add, scale, hv_from(out), stream);
+  return attn_rows_times_impl(A, hv_from(M), B, H, L, dk, add, scale, hv_from(out), a_drop, stream);
 }
 
 static int attn_transposed_times_impl(const float* A, HeadView Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk, HeadView out,
-                                      void* stream) {
+                                      bl_dropout_t a_drop, void* stream) {
   if (B * H == 0) return BL_OK;
   BL_CHECK_ARG(A && Bm.p && out.p, "bl_attn_transposed_times: null pointer");
   BL_CHECK_ARG(bl_attn_mm32_ok(L, dk), "bl_attn_transposed_times: needs dk == 32, L %% 4 == 0, L <= 1164 (got L=%d dk=%d)", L, dk);
   int rc = att_mm_lds((const void*)attn_tn32_kernel, L, "bl_attn_transposed_times");
   if (rc != BL_OK) return rc;
   dim3 grid(B * H, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
-  hipLaunchKernelGGL(attn_tn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, Bm, bm_scale, H, L, out);
+  BL_CHECK_ARG(a_drop.p <= 0.f || (long long)B * H * L * L < (1ll << 32), "bl_attn_transposed_times: more than 2^32 elements under a dropout mask");
+  hipLaunchKernelGGL(attn_tn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, Bm, bm_scale, H, L, out,
+                     bl_make_drop(a_drop));
   BL_LAUNCH_CHECK("bl_attn_transposed_times");
   return BL_OK;
 }
 extern "C" int bl_attn_transposed_times(const float* A, const float* Bm, int32_t G, int32_t L, int32_t dk, float* out, void* stream) {
-  return attn_transposed_times_impl(A, hv_contiguous(Bm, 1, L, dk), 1.0f, G, 1, L, dk, hv_contiguous(out, 1, L, dk), stream);
+  const bl_dropout_t none = {0.f, 0u, 0u};
+  return attn_transposed_times_impl(A, hv_contiguous(Bm, 1, L, dk), 1.0f, G, 1, L, dk, hv_contiguous(out, 1, L, dk), none, stream);
 }
 extern "C" int bl_attn_transposed_times_v(const float* A, const bl_head_view_t* Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk,
-                                          const bl_head_view_t* out, void* stream) {
+                                          const bl_head_view_t* out, bl_dropout_t a_drop, void* stream) {
   int rc = check_view("bl_attn_transposed_times_v", Bm);
   if (rc == BL_OK) rc = check_view("bl_attn_transposed_times_v", out);
   if (rc != BL_OK) return rc;
-  return attn_transposed_times_impl(A, hv_from(Bm), bm_scale, B, H, L, dk, hv_from(out), stream);
+  return attn_transposed_times_impl(A, hv_from(Bm), bm_scale, B, H, L, dk, hv_from(out), a_drop, stream);
 }
 
 extern "C" int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L,
