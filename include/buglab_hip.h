@@ -621,7 +621,7 @@ int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32_t* row_ptr
                           const int32_t* lens, bl_dropout_t drop, float* P, float* Pd, void* stream);
 /* ... and their backward: g_ctx [B, H, L, dk] = gradient of the context, v, q [B, H, L, dk], P from the forward call ->
  * dS [B H L, L] = d loss / d scores (the grouped GEMMs dQ = dS.K and dK = dS^T.Q read it);  with an edge CSR also
- * gq_edge [B, H, L, dk] = the edge terms' part of d loss / d q (only rows with entries are written: pass it zeroed) and
+ * gq_edge [B, H, L, dk] = the edge terms' part of d loss / d q (every row is written: zeros where a row has no entries) and
  * g_bias_f / g_bias_r [T, H dk] += (atomics).  Replaces dO.V^T GEMM + bl_softmax_dropout_bwd + bl_rel_attn_bias_bwd. */
 int bl_rel_attn_probs_bwd(const float* g_ctx, const float* v, const float* P, const float* q, const int32_t* row_ptr,
                           const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H, int32_t dk, int32_t T,
@@ -657,10 +657,18 @@ int bl_rel_attn_probs_bwd_v(const bl_head_view_t* g_ctx, const bl_head_view_t* v
 /* a_drop (p > 0): A is read through the counter-hash dropout mask, element index (g L + i) L + k -- A = the probabilities P of
  * bl_rel_attn_probs_fwd_v called with Pd == NULL: nn.Dropout on the attention probabilities (multihead_attention.py:72) without
  * a stored copy of the dropped matrix */
+/* out_packed (optional; out may then be NULL): the result in bl_pack_bf16x3's form as columns of a packed [B L, 3 W] matrix --
+ * element (b, h, l, d), plane pl at p[((b L + l) 3 + pl) W + col0 + h hs + d] (16-byte aligned base, W a multiple of 8, col0 and hs
+ * multiples of 4): the context as the output projection's operand (W = H dk, col0 = 0, hs = dk), the gradients of q / k / v as the
+ * operand of the QKV projection's gradient GEMMs (W = 3 H dk, col0 = which dk, hs = 3 dk) */
+typedef struct {
+  uint16_t* p;
+  int32_t W, col0, hs;
+} bl_packed_head_view_t;
 int bl_attn_rows_times_v(const float* A, const bl_head_view_t* M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add, float scale,
-                         const bl_head_view_t* out, bl_dropout_t a_drop, void* stream);
+                         const bl_head_view_t* out, bl_dropout_t a_drop, const bl_packed_head_view_t* out_packed, void* stream);
 int bl_attn_transposed_times_v(const float* A, const bl_head_view_t* Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk,
-                               const bl_head_view_t* out, bl_dropout_t a_drop, void* stream);
+                               const bl_head_view_t* out, bl_dropout_t a_drop, const bl_packed_head_view_t* out_packed, void* stream);
 /* `rat` edge value biases (relational_multihead_attention.py:155-178): ctx[b, h, i, :] += P[(b, h, i), key] * vb[code][h, :] */
 int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L, int32_t H,
                           int32_t dk, const float* P, const float* vb_f, const float* vb_r, float* ctx, void* stream);

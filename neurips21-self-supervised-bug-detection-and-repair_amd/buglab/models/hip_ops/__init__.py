@@ -1604,7 +1604,7 @@ class _RelAttention(torch.autograd.Function):
             # dO.V^T, dropout mask, softmax backward and the edge terms' gradients in one kernel; dS is written once
             (g_bf, r_bf), (g_br, r_br) = _grad_target(bias_f), _grad_target(bias_r)
             dS = torch.empty((G * L, L), dtype=torch.float32, device=dev)
-            gq_edge = torch.zeros((G * L, dk), dtype=torch.float32, device=dev) if has_e else None
+            gq_edge = torch.empty((G * L, dk), dtype=torch.float32, device=dev) if has_e else None  # (the kernel writes every row)
             with _timed("attn_probs_bwd", 0.0, nbytes=4.0 * G * L * (2 * L + 3 * dk)):  # reads P, dO, v, q; writes dS
                 _check(lib.bl_rel_attn_probs_bwd(g_ct.data_ptr(), vt.data_ptr(), P.data_ptr(), qs.data_ptr(), *(ep or (None, None, None)), B, L, H, dk, T,
                                                  bias_f.data_ptr(), bias_r.data_ptr(), drop.c(), dS.data_ptr(), _p(gq_edge), g_bf.data_ptr(),

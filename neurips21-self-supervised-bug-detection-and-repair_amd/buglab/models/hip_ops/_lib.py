@@ -62,6 +62,10 @@ class bl_head_view_t(Structure):
     _fields_ = [("p", c_void_p), ("sb", c_int64), ("sh", c_int32), ("sl", c_int32)]
 
 
+class bl_packed_head_view_t(Structure):
+    _fields_ = [("p", c_void_p), ("W", c_int32), ("col0", c_int32), ("hs", c_int32)]
+
+
 class bl_great_layer_t(Structure):
     _fields_ = [("B", c_int32), ("L", c_int32), ("H", c_int32), ("dk", c_int32), ("T", c_int32), ("FF", c_int32),
                 ("row_ptr", c_void_p), ("ekey", c_void_p), ("ecode", c_void_p), ("lens", c_void_p),
@@ -162,9 +166,9 @@ _SIGNATURES = {
                                  c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, bl_dropout_t, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p], ctypes.c_int),
     "bl_attn_rows_times_v": ([c_void_p, POINTER(bl_head_view_t), c_int32, c_int32, c_int32, c_int32, c_void_p, c_float, POINTER(bl_head_view_t),
-                              bl_dropout_t, c_void_p], ctypes.c_int),
+                              bl_dropout_t, POINTER(bl_packed_head_view_t), c_void_p], ctypes.c_int),
     "bl_attn_transposed_times_v": ([c_void_p, POINTER(bl_head_view_t), c_float, c_int32, c_int32, c_int32, c_int32, POINTER(bl_head_view_t),
-                                    bl_dropout_t, c_void_p], ctypes.c_int),
+                                    bl_dropout_t, POINTER(bl_packed_head_view_t), c_void_p], ctypes.c_int),
     "bl_great_layer_ok": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int32),
     "bl_great_layer_saved_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),
     "bl_great_layer_workspace_bytes": ([c_int32, c_int32, c_int32, c_int32, c_int32, c_int32], c_int64),

@@ -14,10 +14,12 @@
 //     backward already masked, packed and column-summed (bl_layernorm_bwd_branch); the gradient through dropout(relu(.)) of
 //     linear1 is the epilogue of linear2's input-gradient GEMM (BL_X6_EPI_MASK_PACK); the two residual sums are the epilogues
 //     of linear1's and the QKV projection's input-gradient GEMMs (BL_X6_EPI_RES).
-//   forward   9 launches: QKV GEMM, probabilities, P.V, pack context, output GEMM(+dropout), add+LayerNorm, linear1
+//   * the attention products write what a Linear reads next in packed form themselves: the context (P.V) and the gradients of
+//     q / k / v (dS.K, dS^T.Q, P^T.dO) land as columns of the packed operands (bl_packed_head_view_t);
+//   forward   8 launches: QKV GEMM, probabilities, P.V (-> packed context), output GEMM(+dropout), add+LayerNorm, linear1
 //             (+bias, relu, dropout -> packed), linear2 (+bias, dropout), add+LayerNorm
-//   backward  15 (+1 memset): LN backward, 2 GEMMs each for linear2 / linear1, LN backward, 2 GEMMs for the output projection,
-//             P^T.dO, probabilities' backward, dS.K, dS^T.Q, pack, 2 GEMMs for the QKV projection; the four weight-gradient
+//   backward  14: LN backward, 2 GEMMs each for linear2 / linear1, LN backward, 2 GEMMs for the output projection,
+//             P^T.dO, probabilities' backward, dS.K, dS^T.Q (-> packed), 2 GEMMs for the QKV projection; the four weight-gradient
 //             GEMMs on the side stream when one is given (each is one round of 128 x 128 tiles at these shapes -- a third of
 //             what a CU can hold -- and depends only on its Linear's packed output gradient), joined before the call returns
 // The caller owns every buffer (`saved` lives from forward to backward, `ws` during the call); nothing is allocated here.
@@ -70,14 +72,13 @@ Saved carve_saved(void* base, const Shape& s, bool own_xp) {
 }
 
 struct WsFwd {
-  float *ctx, *att, *x1, *ff;  // [R, D] each
+  float *att, *x1, *ff;  // [R, D] each
   size_t bytes;
 };
 WsFwd carve_fwd(void* base, const Shape& s) {
   WsFwd v;
   char* p = static_cast<char*>(base);
   size_t o = 0;
-  TAKE(ctx, float, s.R * s.D)
   TAKE(att, float, s.R * s.D)
   TAKE(x1, float, s.R * s.D)
   TAKE(ff, float, s.R * s.D)
@@ -95,7 +96,6 @@ struct WsBwd {
   float* g_ctx;       // [R, D]
   float* dS;          // [G L, L]
   float* gq_edge;     // [G L, dk]
-  float* g_qkv;       // [R, 3 D]
   uint16_t* g_qkv_p;  // [R, 9 D]
   size_t bytes;
 };
@@ -112,7 +112,6 @@ WsBwd carve_bwd(void* base, const Shape& s) {
   TAKE(g_ctx, float, s.R * s.D)
   TAKE(dS, float, s.G * s.L * s.L)
   TAKE(gq_edge, float, s.R * s.D)
-  TAKE(g_qkv, float, s.R * 3 * s.D)
   TAKE(g_qkv_p, uint16_t, s.R * 9 * s.D)
   v.bytes = o;
   return v;
@@ -220,14 +219,10 @@ extern "C" int bl_great_layer_fwd(const bl_great_layer_t* d, const float* x, con
     GL_TRY(bl_rel_attn_probs_fwd_v(&q, scale, &k, d->row_ptr, d->ekey, d->ecode, s.B, s.L, s.H, dk, s.T, d->bias_f, d->bias_r, d->lens,
                                    d->drop_attn, sv.P, nullptr, stream));
   }
-  {  // context = P . V, written as [B L, H dk]
+  {  // context = dropout(P) . V, written packed as [B L, 3 H dk]: the output projection's operand
     BlProfScope ps(BL_PROF_ATTN_ROWS_TIMES, 2.0 * s.G * s.L * s.L * dk, stream, 4.0 * s.G * s.L * (s.L + 2.0 * dk));
-    const bl_head_view_t c = view_of(w.ctx, 0, s, D, dk);
-    GL_TRY(bl_attn_rows_times_v(sv.P, &v, s.B, s.H, s.L, dk, nullptr, 1.0f, &c, d->drop_attn, stream));
-  }
-  {
-    BlProfScope ps(BL_PROF_PACK_ROWS, 0.0, stream);
-    GL_TRY(bl_pack_bf16x3(w.ctx, D, R, D, sv.ctx_p, stream));
+    const bl_packed_head_view_t cp = {sv.ctx_p, D, 0, dk};
+    GL_TRY(bl_attn_rows_times_v(sv.P, &v, s.B, s.H, s.L, dk, nullptr, 1.0f, nullptr, d->drop_attn, &cp, stream));
   }
   {  // output projection + dropout1 (multihead_attention.py:35, relational_transformer.py:108-110)
     BlProfScope ps(BL_PROF_LINEAR_FWD, 2.0 * R * D * (double)D, stream);
@@ -342,20 +337,17 @@ extern "C" int bl_great_layer_bwd(const bl_great_layer_t* d, const uint16_t* x_p
   }
   const bl_head_view_t q = view_of(sv.qkv, 0, s, 3 * D, 3 * dk), k = view_of(sv.qkv, dk, s, 3 * D, 3 * dk),
                        v = view_of(sv.qkv, 2 * dk, s, 3 * D, 3 * dk);
-  const bl_head_view_t gq = view_of(w.g_qkv, 0, s, 3 * D, 3 * dk), gk = view_of(w.g_qkv, dk, s, 3 * D, 3 * dk),
-                       gv = view_of(w.g_qkv, 2 * dk, s, 3 * D, 3 * dk);
+  // the gradients of q / k / v leave the attention kernels as columns of the packed [B L, 9 D] operand of the QKV projection's GEMMs
+  const bl_packed_head_view_t gq = {w.g_qkv_p, 3 * D, 0, 3 * dk}, gk = {w.g_qkv_p, 3 * D, dk, 3 * dk}, gv = {w.g_qkv_p, 3 * D, 2 * dk, 3 * dk};
   const bl_head_view_t gc = view_of(w.g_ctx, 0, s, D, dk);
   const bl_dropout_t nodrop = {0.f, 0u, 0u};
   const double mm_flop = 2.0 * s.G * s.L * s.L * dk, mm_bytes = 4.0 * s.G * s.L * (s.L + 2.0 * dk);
-  {  // g_v = Pd^T . dO
+  {  // g_v = dropout(P)^T . dO  (on the side stream next to the probabilities' backward it only took bandwidth from that kernel:
+     // 217 -> 293 us, the step 1.8 % slower -- tools/experiments/README.md)
     BlProfScope ps(BL_PROF_ATTN_TRANSPOSED_TIMES, mm_flop, stream, mm_bytes, two);
-    GL_TRY(bl_attn_transposed_times_v(sv.P, &gc, 1.0f, s.B, s.H, s.L, dk, &gv, d->drop_attn, stream));
+    GL_TRY(bl_attn_transposed_times_v(sv.P, &gc, 1.0f, s.B, s.H, s.L, dk, nullptr, d->drop_attn, &gv, stream));
   }
   const bool edges = d->row_ptr != nullptr;
-  if (edges && hipMemsetAsync(w.gq_edge, 0, s.R * s.D * sizeof(float), st) != hipSuccess) {
-    bl_set_error("bl_great_layer_bwd: hipMemsetAsync failed");
-    return BL_EINVAL;
-  }
   {  // dS from dO . V^T, the dropout mask, the softmax and the edge terms
     BlProfScope ps(BL_PROF_ATTN_PROBS_BWD, 0.0, stream, 4.0 * s.G * s.L * (2.0 * s.L + 3.0 * dk), two);
     GL_TRY(bl_rel_attn_probs_bwd_v(&gc, &v, sv.P, &q, scale, d->row_ptr, d->ekey, d->ecode, s.B, s.L, s.H, dk, s.T, d->bias_f, d->bias_r,
@@ -363,15 +355,11 @@ extern "C" int bl_great_layer_bwd(const bl_great_layer_t* d, const uint16_t* x_p
   }
   {  // g_q = (dS . K + edge part) / sqrt(dk)
     BlProfScope ps(BL_PROF_ATTN_ROWS_TIMES, mm_flop, stream, mm_bytes, two);
-    GL_TRY(bl_attn_rows_times_v(w.dS, &k, s.B, s.H, s.L, dk, edges ? w.gq_edge : nullptr, scale, &gq, nodrop, stream));
+    GL_TRY(bl_attn_rows_times_v(w.dS, &k, s.B, s.H, s.L, dk, edges ? w.gq_edge : nullptr, scale, nullptr, nodrop, &gq, stream));
   }
   {  // g_k = dS^T . (q / sqrt(dk))
     BlProfScope ps(BL_PROF_ATTN_TRANSPOSED_TIMES, mm_flop, stream, mm_bytes, two);
-    GL_TRY(bl_attn_transposed_times_v(w.dS, &q, scale, s.B, s.H, s.L, dk, &gk, nodrop, stream));
-  }
-  {
-    BlProfScope ps(BL_PROF_PACK_ROWS, 0.0, stream, 0.0, two);
-    GL_TRY(bl_pack_bf16x3(w.g_qkv, 3 * D, R, 3 * D, w.g_qkv_p, stream));
+    GL_TRY(bl_attn_transposed_times_v(w.dS, &q, scale, s.B, s.H, s.L, dk, nullptr, nodrop, &gk, stream));
   }
   GL_FORK(3)
   {

@@ -26,6 +26,24 @@ struct HeadView {
   int sh, sl;
 };
 __device__ __forceinline__ float* hv_mat(const HeadView& v, int b, int h) { return v.p + (size_t)b * v.sb + (size_t)h * v.sh; }
+// ... and the same tensor written in bl_pack_bf16x3's form as columns of a [B L, 3 W] packed matrix (bl_packed_head_view_t):
+// element (b, h, l, d), plane pl at p[((b L + l) 3 + pl) W + col0 + h hs + d] -- the attention context as the output projection's
+// operand, the gradients of q / k / v as the operand of the QKV projection's gradient GEMMs
+struct PackedHeadView {
+  uint16_t* p;
+  int W, col0, hs;
+};
+__device__ __forceinline__ void phv_store4(const PackedHeadView& v, size_t grow, int h, int n, float a, float b, float c, float d) {
+  uint16_t hh[4], mm[4], ll[4];
+  split3(a, hh[0], mm[0], ll[0]);
+  split3(b, hh[1], mm[1], ll[1]);
+  split3(c, hh[2], mm[2], ll[2]);
+  split3(d, hh[3], mm[3], ll[3]);
+  uint2* o = reinterpret_cast<uint2*>(v.p + grow * 3 * v.W + v.col0 + h * v.hs + n);
+  o[0] = make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
+  o[v.W >> 2] = make_uint2((uint32_t)mm[0] | ((uint32_t)mm[1] << 16), (uint32_t)mm[2] | ((uint32_t)mm[3] << 16));
+  o[v.W >> 1] = make_uint2((uint32_t)ll[0] | ((uint32_t)ll[1] << 16), (uint32_t)ll[2] | ((uint32_t)ll[3] << 16));
+}
 static inline HeadView hv_contiguous(const float* p, int H, int L, int dk) {
   HeadView v = {const_cast<float*>(p), (long long)H * L * dk, L * dk, dk};
   return v;
@@ -643,6 +661,8 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const HeadView g_c
             if (e < ntab) tabacc[kk] = fmaf(cv, qd, tabacc[kk]);  // (64 % DK == 0: e % DK == lane % DK)
           }
         }
+      } else if (gq_edge && lane < DK) {
+        gq_edge[row * DK + lane] = 0.f;  // (every row is written: the caller need not zero the buffer)
       }
 #pragma unroll
       for (int x = 0; x < NS; ++x) pv[x] = pn[x];
@@ -681,7 +701,8 @@ typedef float att_f32x16 __attribute__((ext_vector_type(16)));
 // probabilities of multihead_attention.py:72 are never stored (bl_rel_attn_probs_fwd's Pd)
 __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const float* __restrict__ A, const HeadView M, int H, int L,
                                                                       const float* __restrict__ add, float scale,
-                                                                      const HeadView out, const bl_drop_dev a_drop) {
+                                                                      const HeadView out, const bl_drop_dev a_drop,
+                                                                      const PackedHeadView outp) {
   extern __shared__ __attribute__((aligned(16))) float att_lds[];  // [L][33]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, half = lane >> 5;
   const int g = blockIdx.x, gb = g / H, gh = g - gb * H;
@@ -724,7 +745,7 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const f
   }
   if (r0 + li < L) {
     const size_t o = ((size_t)g * L + row) * 32;
-    float* __restrict__ orow = hv_mat(out, gb, gh) + (size_t)row * out.sl;
+    float* __restrict__ orow = out.p ? hv_mat(out, gb, gh) + (size_t)row * out.sl : nullptr;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int n = 8 * g4 + 4 * half;
@@ -734,14 +755,16 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_nn32_kernel(const f
         v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
       }
       v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-      *reinterpret_cast<float4*>(orow + n) = v;
+      if (orow) *reinterpret_cast<float4*>(orow + n) = v;
+      if (outp.p) phv_store4(outp, (size_t)gb * L + row, gh, n, v.x, v.y, v.z, v.w);
     }
   }
 }
 
 // out[g, key, :] = sum_i A[(g, i), key] Bm[g, i, :]
 __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_tn32_kernel(const float* __restrict__ A, const HeadView Bm, float bm_scale,
-                                                                      int H, int L, const HeadView out, const bl_drop_dev a_drop) {
+                                                                      int H, int L, const HeadView out, const bl_drop_dev a_drop,
+                                                                      const PackedHeadView outp) {
   extern __shared__ __attribute__((aligned(16))) float att_lds[];  // [L][33]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, half = lane >> 5;
   const int g = blockIdx.x, gb = g / H, gh = g - gb * H;
@@ -783,10 +806,12 @@ __global__ __launch_bounds__(64 * ATT_MM_WAVES, 4) void attn_tn32_kernel(const f
     }
   }
   if (key0 + li < L) {
-    float* __restrict__ orow = hv_mat(out, gb, gh) + (size_t)key * out.sl;
+    float* __restrict__ orow = out.p ? hv_mat(out, gb, gh) + (size_t)key * out.sl : nullptr;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)
-      *reinterpret_cast<float4*>(orow + 8 * g4 + 4 * half) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+    for (int g4 = 0; g4 < 4; ++g4) {
+      if (orow) *reinterpret_cast<float4*>(orow + 8 * g4 + 4 * half) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+      if (outp.p) phv_store4(outp, (size_t)gb * L + key, gh, 8 * g4 + 4 * half, acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+    }
   }
 }
 
@@ -1054,6 +1079,23 @@ extern "C" int bl_rel_attn_probs_fwd(const float* q, const float* k, const int32
   return attn_probs_fwd_impl(hv_contiguous(q, H, L, dk), 1.0f, hv_contiguous(k, H, L, dk), row_ptr, ekey, ecode, B, L, H, dk, T, bias_f, bias_r,
                              lens, drop, P, Pd, stream);
 }
+static inline HeadView hv_null() {
+  HeadView v = {nullptr, 0, 0, 0};
+  return v;
+}
+static inline PackedHeadView phv_none() {
+  PackedHeadView v = {nullptr, 0, 0, 0};
+  return v;
+}
+static inline PackedHeadView phv_from(const bl_packed_head_view_t* a) {
+  PackedHeadView v = {a->p, a->W, a->col0, a->hs};
+  return v;
+}
+static int check_packed_view(const char* who, const bl_packed_head_view_t* v) {
+  BL_CHECK_ARG(v->p && bl_aligned16(v->p) && v->W > 0 && v->W % 8 == 0 && v->col0 % 4 == 0 && v->hs % 4 == 0,
+               "%s: a packed head view needs a 16-byte aligned base, W a multiple of 8, col0 and hs multiples of 4", who);
+  return BL_OK;
+}
 static int check_view(const char* who, const bl_head_view_t* v) {
   BL_CHECK_ARG(v && v->p && bl_aligned16(v->p) && v->sb % 4 == 0 && v->sh % 4 == 0 && v->sl % 4 == 0, "%s: a head view needs a 16-byte aligned base and strides that are multiples of 4", who);
   return BL_OK;
@@ -1131,56 +1173,62 @@ static int att_mm_lds(const void* fn, int L, const char* who) {
 extern "C" int32_t bl_attn_mm32_ok(int32_t L, int32_t dk) { return dk == 32 && L > 0 && L % 4 == 0 && (size_t)L * 33 * 4 <= 152 * 1024; }
 
 static int attn_rows_times_impl(const float* A, HeadView M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add, float scale,
-                                HeadView out, bl_dropout_t a_drop, void* stream) {
+                                HeadView out, bl_dropout_t a_drop, PackedHeadView outp, void* stream) {
   if (B * H == 0) return BL_OK;
-  BL_CHECK_ARG(A && M.p && out.p, "bl_attn_rows_times: null pointer");
+  BL_CHECK_ARG(A && M.p && (out.p || outp.p), "bl_attn_rows_times: null pointer");
   BL_CHECK_ARG(bl_attn_mm32_ok(L, dk), "bl_attn_rows_times: needs dk == 32, L %% 4 == 0, L <= 1164 (got L=%d dk=%d)", L, dk);
   int rc = att_mm_lds((const void*)attn_nn32_kernel, L, "bl_attn_rows_times");
   if (rc != BL_OK) return rc;
   dim3 grid(B * H, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
   BL_CHECK_ARG(a_drop.p <= 0.f || (long long)B * H * L * L < (1ll << 32), "bl_attn_rows_times: more than 2^32 elements under a dropout mask");
   hipLaunchKernelGGL(attn_nn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, M, H, L, add, scale, out,
-                     bl_make_drop(a_drop));
+                     bl_make_drop(a_drop), outp);
   BL_LAUNCH_CHECK("bl_attn_rows_times");
   return BL_OK;
 }
 extern "C" int bl_attn_rows_times(const float* A, const float* M, int32_t G, int32_t L, int32_t dk, const float* add, float scale,
                                   float* out, void* stream) {
   const bl_dropout_t none = {0.f, 0u, 0u};
-  return attn_rows_times_impl(A, hv_contiguous(M, 1, L, dk), G, 1, L, dk, add, scale, hv_contiguous(out, 1, L, dk), none, stream);
+  return attn_rows_times_impl(A, hv_contiguous(M, 1, L, dk), G, 1, L, dk, add, scale, hv_contiguous(out, 1, L, dk), none, phv_none(), stream);
 }
 extern "C" int bl_attn_rows_times_v(const float* A, const bl_head_view_t* M, int32_t B, int32_t H, int32_t L, int32_t dk, const float* add,
-                                    float scale, const bl_head_view_t* out, bl_dropout_t a_drop, void* stream) {
+                                    float scale, const bl_head_view_t* out, bl_dropout_t a_drop, const bl_packed_head_view_t* out_packed,
+                                    void* stream) {
   int rc = check_view("bl_attn_rows_times_v", M);
-  if (rc == BL_OK) rc = check_view("bl_attn_rows_times_v", out);
+  if (rc == BL_OK && out) rc = check_view("bl_attn_rows_times_v", out);
+  if (rc == BL_OK && out_packed) rc = check_packed_view("bl_attn_rows_times_v", out_packed);
   if (rc != BL_OK) return rc;
-  return attn_rows_times_impl(A, hv_from(M), B, H, L, dk, add, scale, hv_from(out), a_drop, stream);
+  return attn_rows_times_impl(A, hv_from(M), B, H, L, dk, add, scale, out ? hv_from(out) : hv_null(), a_drop,
+                              out_packed ? phv_from(out_packed) : phv_none(), stream);
 }
 
 static int attn_transposed_times_impl(const float* A, HeadView Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk, HeadView out,
-                                      bl_dropout_t a_drop, void* stream) {
+                                      bl_dropout_t a_drop, PackedHeadView outp, void* stream) {
   if (B * H == 0) return BL_OK;
-  BL_CHECK_ARG(A && Bm.p && out.p, "bl_attn_transposed_times: null pointer");
+  BL_CHECK_ARG(A && Bm.p && (out.p || outp.p), "bl_attn_transposed_times: null pointer");
   BL_CHECK_ARG(bl_attn_mm32_ok(L, dk), "bl_attn_transposed_times: needs dk == 32, L %% 4 == 0, L <= 1164 (got L=%d dk=%d)", L, dk);
   int rc = att_mm_lds((const void*)attn_tn32_kernel, L, "bl_attn_transposed_times");
   if (rc != BL_OK) return rc;
   dim3 grid(B * H, (L + 32 * ATT_MM_WAVES - 1) / (32 * ATT_MM_WAVES));
   BL_CHECK_ARG(a_drop.p <= 0.f || (long long)B * H * L * L < (1ll << 32), "bl_attn_transposed_times: more than 2^32 elements under a dropout mask");
   hipLaunchKernelGGL(attn_tn32_kernel, grid, dim3(64 * ATT_MM_WAVES), (size_t)L * 33 * sizeof(float), (hipStream_t)stream, A, Bm, bm_scale, H, L, out,
-                     bl_make_drop(a_drop));
+                     bl_make_drop(a_drop), outp);
   BL_LAUNCH_CHECK("bl_attn_transposed_times");
   return BL_OK;
 }
 extern "C" int bl_attn_transposed_times(const float* A, const float* Bm, int32_t G, int32_t L, int32_t dk, float* out, void* stream) {
   const bl_dropout_t none = {0.f, 0u, 0u};
-  return attn_transposed_times_impl(A, hv_contiguous(Bm, 1, L, dk), 1.0f, G, 1, L, dk, hv_contiguous(out, 1, L, dk), none, stream);
+  return attn_transposed_times_impl(A, hv_contiguous(Bm, 1, L, dk), 1.0f, G, 1, L, dk, hv_contiguous(out, 1, L, dk), none, phv_none(), stream);
 }
 extern "C" int bl_attn_transposed_times_v(const float* A, const bl_head_view_t* Bm, float bm_scale, int32_t B, int32_t H, int32_t L, int32_t dk,
-                                          const bl_head_view_t* out, bl_dropout_t a_drop, void* stream) {
+                                          const bl_head_view_t* out, bl_dropout_t a_drop, const bl_packed_head_view_t* out_packed,
+                                          void* stream) {
   int rc = check_view("bl_attn_transposed_times_v", Bm);
-  if (rc == BL_OK) rc = check_view("bl_attn_transposed_times_v", out);
+  if (rc == BL_OK && out) rc = check_view("bl_attn_transposed_times_v", out);
+  if (rc == BL_OK && out_packed) rc = check_packed_view("bl_attn_transposed_times_v", out_packed);
   if (rc != BL_OK) return rc;
-  return attn_transposed_times_impl(A, hv_from(Bm), bm_scale, B, H, L, dk, hv_from(out), a_drop, stream);
+  return attn_transposed_times_impl(A, hv_from(Bm), bm_scale, B, H, L, dk, out ? hv_from(out) : hv_null(), a_drop,
+                                    out_packed ? phv_from(out_packed) : phv_none(), stream);
 }
 
 extern "C" int bl_rel_value_bias_fwd(const int32_t* row_ptr, const int32_t* ekey, const int32_t* ecode, int32_t B, int32_t L,
