@@ -559,6 +559,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_issue_s = time.perf_counter() - t0  # the host has ISSUED every step; the device drains its queue until the synchronize below
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -677,6 +678,8 @@ def main():
                 "parallelism": f"dp{world}",
                 "loss_last_step": round(last_loss, 5),
                 "c_abi_calls_per_step": round(calls_per_step, 1),
+                # host time to issue a step (Python + autograd + C calls + launches); close to ms_per_step = the host, not the device, paces the run
+                "host_issue_ms_per_step": round(1e3 * host_issue_s / args.steps, 3),
             },
             "predict_graphs_per_s": None if predict_elapsed is None else round(args.graphs * world * args.steps / predict_elapsed, 1),  # forward-only, eval mode
             "roofline": roof,
