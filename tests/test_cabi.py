@@ -114,3 +114,34 @@ def _check_bf16x6_image_rule(lib, hip_ops):
     finally:
         lib.bl_set_rows_tile(prev)
     assert hip_ops.rows_x6w_ok(256, 512) and not hip_ops.rows_x6w_ok(256, 128) and not hip_ops.rows_x6w_ok(128, 512)
+
+
+def test_ctypes_structures_match_the_c_layout(tmp_path):
+    """Every structure that crosses the boundary by value or by pointer: size and every field offset as gcc lays the header's
+    declaration out == what the ctypes mirror in hip_ops/_lib.py says (a mismatch would shift every later field silently)."""
+    import ctypes
+    import importlib
+
+    L = importlib.import_module("buglab.models.hip_ops._lib")  # (hip_ops._lib itself resolves to the loaded library)
+
+    names = ["bl_rows_t", "bl_rows_packed_t", "bl_dropout_t", "bl_mp_layer_t", "bl_pack_job_t", "bl_bug_loss_t", "bl_x6_epi_t", "bl_head_view_t",
+             "bl_packed_head_view_t", "bl_great_layer_t", "bl_great_layer_grads_t"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for n in names:
+        cls = getattr(L, n)
+        lines.append(f'  printf("{n} %zu", sizeof({n}));')
+        for f, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({n}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == len(names)
+    for line in out:
+        n, size, *offs = line.split()
+        cls = getattr(L, n)
+        assert ctypes.sizeof(cls) == int(size), (n, ctypes.sizeof(cls), size)
+        assert [getattr(cls, f).offset for f, _ in cls._fields_] == [int(o) for o in offs], n
