@@ -465,9 +465,12 @@ double bl_prof_read_bytes(int32_t kind); /* algorithmic bytes recorded with a me
  *     g_amax_dev: the device amax G was packed with. */
 #define BL_H3_ROW_SCALE 256.0f /* layer inputs: |h| <= 1.25 after tanh x dropout, embedding rows O(1); saturation at 255.9 */
 #define BL_H3_W_SCALE 64.0f    /* weights: saturation at 1023 */
-/* which split the message GEMMs of bl_mp_layer_fwd / _bwd use: 1 = f16x3 (default), 0 = bf16x6; BL_MSG_GEMM=x6 / h3 in the
- * environment sets the initial value.  Returns the previous mode.  bl_mp_layer_weight_image then returns 2 (f16x3 image). */
-int32_t bl_set_msg_gemm_mode(int32_t f16x3);
+/* which split the message GEMMs of bl_mp_layer_fwd / _bwd use: 1 = f16x3 (default), 0 = bf16x6, 2 = f16x1 -- the f16x3 images
+ * and kernels with the high-plane term only (fp16 operands, fp32 accumulation and results, gradient operand scaled by its
+ * device-side amax): the reduced-precision mode behind the reference's `train.py --amp` (/root/reference/buglab/models/train.py:8,106),
+ * never the default and never the benchmarked headline.  BL_MSG_GEMM=x6 / h3 / amp in the environment sets the initial value.
+ * Returns the previous mode.  bl_mp_layer_weight_image returns 2 (f16x3 image) in modes 1 and 2. */
+int32_t bl_set_msg_gemm_mode(int32_t mode);
 int32_t bl_get_msg_gemm_mode(void);
 /* packing threads that had to saturate a finite value at +-65504 since the last reset, on the current device (synchronises; -1 if
  * the counter is unavailable): 0 in a healthy run -- the trainer checks it once per epoch (runtime/trainer.py). */

@@ -34,6 +34,7 @@ from buglab.models.graphmodel import StrElementRepresentationModel
 from buglab.models.hip_ops import Dropout, RelEdges
 from buglab.models.layers.messagepassing import GnnOutput, SubtokenEmbedder
 from buglab.models.layers.relational_transformer import RelationalTransformerEncoderLayer
+from buglab.models.layers.transformer import TransformerEncoderLayer
 from buglab.representations.tokenseq import project_graph_to_tokens
 from buglab.runtime.neuralmodel import AbstractNeuralModel
 
@@ -50,15 +51,21 @@ class SequenceEncoder(nn.Module):
                  intermediate_dimension: int, dropout_rate: float, layer_type: str = "great", rezero_mode: str = "off",
                  normalisation_mode: str = "postnorm"):
         super().__init__()
-        if layer_type not in ("great", "rat"):
-            raise NotImplementedError(f"layer type `{layer_type}`: the HIP path implements the relational transformer variants "
-                                      "`great` and `rat` (reference seqmodel.py:91-107); `transformer` / `gru` wrap torch.nn modules")
+        if layer_type == "gru":
+            raise NotImplementedError("layer type `gru` (reference seqmodel.py:119-126: a bidirectional torch.nn.GRU) is not built on the HIP "
+                                      "path; `great`, `rat` and `transformer` are")
+        if layer_type not in ("great", "rat", "transformer"):
+            raise ValueError(f"Unrecognized layer type `{layer_type}`.")  # reference seqmodel.py:128
         D = embedding_dim
         self.embed = token_embedder
         self.positional_encoding = nn.Parameter(torch.randn(1, MAX_POSITIONS, D))
         self.input_norm_g, self.input_norm_b = nn.Parameter(torch.ones(D)), nn.Parameter(torch.zeros(D))
         self.dropout_rate = dropout_rate
+        self.layer_type = layer_type
+        # `transformer`: torch.nn.TransformerEncoderLayer's arithmetic (reference seqmodel.py:108-118); edges are not looked at
         self.layers = nn.ModuleList([
+            TransformerEncoderLayer(d_model=D, nhead=num_heads, dim_feedforward=intermediate_dimension, dropout=dropout_rate)
+            for _ in range(num_layers)]) if layer_type == "transformer" else nn.ModuleList([
             RelationalTransformerEncoderLayer(d_model=D, key_query_dimension=D // num_heads, value_dimension=D // num_heads,
                                               nhead=num_heads, num_edge_types=max(1, num_edge_types), dim_feedforward=intermediate_dimension,
                                               dropout=dropout_rate, use_edge_value_biases=layer_type == "rat", rezero_mode=rezero_mode,

@@ -4,7 +4,7 @@ Usage:
     train.py [options] MODEL_NAME TRAIN_DATA_PATH VALID_DATA_PATH MODEL_FILENAME
 
 Options:
-    --amp                         Use AMP (not supported on the fp32-parity HIP path; raises)
+    --amp                         Use AMP (message GEMMs with fp16 operands, fp32 accumulation)
     --max-num-epochs=<epochs>     The maximum number of epochs to run training for. [default: 100]
     --max-files-per-fold=<n>      The maximum number of files to include in each fold.
     --minibatch-size=<size>       The minibatch size. [default: 300]

@@ -4,7 +4,7 @@ Usage:
     trainandeval.py [options] MODEL_NAME TRAIN_DATA_PATH VALID_DATA_PATH TEST_DATA_PATH MODEL_FILENAME
 
 Options:
-    --amp                         Use AMP (not supported on the fp32-parity HIP path; raises)
+    --amp                         Use AMP (message GEMMs with fp16 operands, fp32 accumulation)
     --limit-num-elements=<num>    Limit the number of elements to evaluate on.
     --max-num-epochs=<epochs>     The maximum number of epochs to run training for. [default: 100]
     --max-files-per-fold=<n>      The maximum number of files to include in each fold.

@@ -120,8 +120,11 @@ class ModelTrainer:
         self._scheduler_creator = scheduler_creator
         self._target_metric = target_validation_metric
         self._target_higher_better = target_validation_metric_higher_is_better
-        if enable_amp:
-            raise NotImplementedError("AMP is out of scope for the fp32-parity HIP path (SURVEY.md section 5)")
+        # --amp (reference train.py:8,106 -> ptgnn's autocast + GradScaler): on this path the message GEMMs -- half of a step --
+        # run with fp16 operands (one MFMA term instead of f16x3's three, half the operand bytes), fp32 accumulation and fp32
+        # results; the gradient operand is scaled by its device-side amax, so no GradScaler and no skipped steps.  Everything
+        # else stays fp32.  Applied when training starts (`train`), undone when it ends.
+        self._enable_amp = bool(enable_amp)
         self._nn = None
         self._use_multiprocessing = False
         self._train_epoch_end_hooks: List[Callable] = []
@@ -472,6 +475,9 @@ class ModelTrainer:
         rank, _ = self._world()
         best = float("-inf") if (self._target_metric is not None and self._target_higher_better) else float("inf")
         bad_epochs = 0
+        prev_gemm_mode = hip_ops.set_msg_gemm_mode("f16x1") if self._enable_amp else None
+        if self._enable_amp:
+            LOGGER.info("--amp: message GEMMs with fp16 operands (one MFMA term, fp32 accumulation); was %s", prev_gemm_mode)
         try:
             for epoch in range(self._max_num_epochs):
                 metrics = self._run_training(training_data, epoch, device, optimizer, scheduler, parallelize)
@@ -492,4 +498,6 @@ class ModelTrainer:
                         break
         finally:
             self._drop_prestarted_pool()
+            if prev_gemm_mode is not None:
+                hip_ops.set_msg_gemm_mode(prev_gemm_mode)
         return best

@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256) void pack_weights_h_kernel(const float* __rest
 // C[rows of g] = out_scale * rows(a) . B_g, rows gathered from <= 3 packed sources; MASKED: the routed left operand (one source,
 // winner bitmask) of the input-gradient GEMM.  out_scale = 1 / (s_a s_b) (host part) x *out_scale_dev (when the left operand's
 // scale lives in device memory: the reciprocal of h3_scale_from_amax(*amax)).
-template <bool MASKED>
+// ONE: the reduced-precision form behind `train.py --amp` (bl_set_msg_gemm_mode(2)): the high planes only -- one fp16 MFMA term with
+// fp32 accumulation, what torch.cuda.amp.autocast makes of a Linear -- from the same packed images (the low planes are not read).
+template <bool MASKED, bool ONE>
 __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_h3_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
@@ -136,11 +138,11 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_h3_kernel(
       const int gr_ = j_ == 0 ? gr0[i] : (j_ == 1 ? gr1[i] : gr2[i]);                                         \
       const uint4* src_ = base_ + (size_t)gr_ * 2 * (wj_ >> 3) + (kl_ >> 3);                                  \
       ra[i][0] = src_[0];                                                                                     \
-      ra[i][1] = src_[wj_ >> 3];                                                                              \
+      if (!ONE) ra[i][1] = src_[wj_ >> 3];                                                                    \
       if (MASKED) ma[i] = win_bits[(size_t)(row0 + min(row_, nrows - 1)) * ld_bits + (kc_ >> 5)];              \
       const uint4* bsrc_ = Bt + (size_t)((k0_) >> 5) * 1024 + i * 512;                                        \
       rb[i][0] = bsrc_[0];                                                                                    \
-      rb[i][1] = bsrc_[256];                                                                                  \
+      if (!ONE) rb[i][1] = bsrc_[256];                                                                        \
     }                                                                                                         \
   }
 #define H3_STORE_STAGE(k0_)                                                                                   \
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_h3_kernel(
       if (MASKED) keep_ = keep_from_bits(ma[i] >> (8 * p_kg)); /* k0 is a multiple of 32 */                  \
       if (!kok_) keep_ = make_uint4(0u, 0u, 0u, 0u);                                                          \
       const bool nok_ = kok_ && (n0 + row_ < N);                                                              \
-      _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                         \
+      _Pragma("unroll") for (int p = 0; p < (ONE ? 1 : 2); ++p) {                                             \
         uint4 a_ = ra[i][p];                                                                                  \
         a_.x &= keep_.x; a_.y &= keep_.y; a_.z &= keep_.z; a_.w &= keep_.w;                                   \
         As[row_ * HROW + p * 4 + p_kg] = a_;                                                                  \
@@ -184,13 +186,13 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_h3_kernel(
       for (int ti = 0; ti < 2; ++ti) {
         const uint4* p = &As[(wm * 64 + ti * 32 + li) * HROW + kg];
         ah[ti] = __builtin_bit_cast(f16x8, p[0]);
-        al[ti] = __builtin_bit_cast(f16x8, p[4]);
+        if (!ONE) al[ti] = __builtin_bit_cast(f16x8, p[4]);
       }
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
         const uint4* p = &Bs[(wn * 64 + tj * 32 + li) * HROW + kg];
         bh[tj] = __builtin_bit_cast(f16x8, p[0]);
-        bl[tj] = __builtin_bit_cast(f16x8, p[4]);
+        if (!ONE) bl[tj] = __builtin_bit_cast(f16x8, p[4]);
       }
       // swapped operands (B fragment in the A slot): the accumulator holds the transposed tile; small terms first
 #pragma unroll
@@ -198,8 +200,10 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_h3_kernel(
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
           f32x16 a = acc[ti][tj];
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[tj], ah[ti], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tj], al[ti], a, 0, 0, 0);
+          if (!ONE) {
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[tj], ah[ti], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tj], al[ti], a, 0, 0, 0);
+          }
           a = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[tj], ah[ti], a, 0, 0, 0);
           acc[ti][tj] = a;
         }
@@ -250,7 +254,7 @@ __device__ __forceinline__ f16x8 h3_tr_frag(const short* p) {
   return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool ROUTED>
+template <bool ROUTED, bool ONE>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_h3_kernel(
     const uint4* __restrict__ xp0, const uint4* __restrict__ xp1, const uint4* __restrict__ xp2,
     const int* __restrict__ idx0, const int* __restrict__ idx1, const int* __restrict__ idx2, int w0, int w1, int w2,
@@ -303,10 +307,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_h3_kernel(
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
       const uint4* a_ = abase + (size_t)arow[i] * 2 * awg;                                       \
       ra[i][0] = a_[0];                                                                          \
-      ra[i][1] = a_[awg];                                                                        \
+      if (!ONE) ra[i][1] = a_[awg];                                                              \
       const uint4* g_ = gbase + (size_t)grow[i] * 2 * gwg;                                       \
       rb[i][0] = g_[0];                                                                          \
-      rb[i][1] = g_[gwg];                                                                        \
+      if (!ONE) rb[i][1] = g_[gwg];                                                              \
       mk[i] = ROUTED ? mbase[(size_t)mrow[i] * ld_bits] : 0u;                                    \
     }                                                                                            \
   }
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_h3_kernel(
       uint4 keep_ = ROUTED ? keep_from_bits(mk[i] >> mshift) : make_uint4(~0u, ~0u, ~0u, ~0u);   \
       if (!(eok_ && b_ok)) keep_ = make_uint4(0u, 0u, 0u, 0u);                                   \
       const int slot_ = (msg0 + 16 * i) * HWRS + 8 * fg;                                         \
-      _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                            \
+      _Pragma("unroll") for (int p = 0; p < (ONE ? 1 : 2); ++p) {                                \
         *reinterpret_cast<uint4*>(&As[p * HWPLANE + slot_]) = (eok_ && a_ok) ? ra[i][p] : make_uint4(0u, 0u, 0u, 0u); \
         uint4 b_ = rb[i][p];                                                                     \
         b_.x &= keep_.x; b_.y &= keep_.y; b_.z &= keep_.z; b_.w &= keep_.w;                      \
@@ -358,14 +362,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_h3_kernel(
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < (ONE ? 1 : 2); ++p) {
           af[t][p] = h3_tr_frag(a_tr + p * HWPLANE + s * 16 * HWRS + t * 32);
           bf[t][p] = h3_tr_frag(b_tr + p * HWPLANE + s * 16 * HWRS + t * 32);
         }
 #define HW_TERM(pa_, pb_)                                                                             \
   _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)   \
       acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ti][pa_], bf[tj][pb_], acc[ti][tj], 0, 0, 0);
-      HW_TERM(1, 0) HW_TERM(0, 1) HW_TERM(0, 0)
+      if (!ONE) { HW_TERM(1, 0) HW_TERM(0, 1) }
+      HW_TERM(0, 0)
     }
     __syncthreads();
     if (kt + 1 < nk) {
@@ -477,6 +482,9 @@ extern "C" int bl_pack_weights_h3(const float* w, int32_t G, int32_t K, int32_t 
   return BL_OK;
 }
 
+// 1: the f16x3 GEMMs of this file evaluate the high-plane term only (bl_set_msg_gemm_mode(2), `train.py --amp`); see the ONE forms
+bool g_h3_one_term = false;
+
 extern "C" int bl_gemm_rows_h3(const bl_rows_packed_t* a, const uint32_t* win_bits, int32_t ld_bits, const uint16_t* bp,
                                int64_t b_group_stride, const int32_t* group_ptr, const int32_t* group_w, int32_t G, int32_t M, int32_t N,
                                int32_t K, float out_scale, const float* a_amax_dev, float* c, int32_t ldc, void* stream) {
@@ -506,10 +514,15 @@ extern "C" int bl_gemm_rows_h3(const bl_rows_packed_t* a, const uint32_t* win_bi
   x0, x1, x2, a->idx[0], a->nsrc > 1 ? a->idx[1] : nullptr, a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0],              \
       a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1], koff[2], a->nsrc, win_bits, ld_bits,        \
       reinterpret_cast<const uint4*>(bp), (long long)(b_group_stride / 8), group_ptr, group_w, G, M, N, K, c, ldc, 1, out_scale, a_amax_dev
-  if (win_bits)
-    hipLaunchKernelGGL((gemm_rows_h3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, H3_ARGS);
+  if (g_h3_one_term) {
+    if (win_bits)
+      hipLaunchKernelGGL((gemm_rows_h3_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, H3_ARGS);
+    else
+      hipLaunchKernelGGL((gemm_rows_h3_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, H3_ARGS);
+  } else if (win_bits)
+    hipLaunchKernelGGL((gemm_rows_h3_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, H3_ARGS);
   else
-    hipLaunchKernelGGL((gemm_rows_h3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, H3_ARGS);
+    hipLaunchKernelGGL((gemm_rows_h3_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, H3_ARGS);
   BL_LAUNCH_CHECK(who);
   return BL_OK;
 }
@@ -521,7 +534,7 @@ int wgrad_h3_resident() {
   static int resident = 0;
   if (resident == 0) {
     int per_cu = 0;
-    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_h3_kernel<ROUTED>, 256, 0);
+    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wgrad_h3_kernel<ROUTED, false>, 256, 0);
     if (oe != hipSuccess || per_cu <= 0) per_cu = 2;
     resident = per_cu * bl_num_cus();
   }
@@ -572,10 +585,15 @@ extern "C" int bl_gemm_wgrad_h3(const bl_rows_packed_t* a, const uint16_t* g_pac
       a->nsrc > 2 ? a->idx[2] : nullptr, a->width[0], a->nsrc > 1 ? a->width[1] : 0, a->nsrc > 2 ? a->width[2] : 0, koff[1],   \
       koff[2], a->nsrc, reinterpret_cast<const uint4*>(g_packed), g_idx, win_bits, ld_bits, group_ptr, group_w, G, M, N, K,     \
       kchunk, gw, (long long)gw_group_stride, ld_gw, ntiles_n, xcd, order_ctr, out_scale, g_amax_dev
-  if (routed)
-    hipLaunchKernelGGL((gemm_wgrad_h3_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, HW_ARGS);
+  if (g_h3_one_term) {
+    if (routed)
+      hipLaunchKernelGGL((gemm_wgrad_h3_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, HW_ARGS);
+    else
+      hipLaunchKernelGGL((gemm_wgrad_h3_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, HW_ARGS);
+  } else if (routed)
+    hipLaunchKernelGGL((gemm_wgrad_h3_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, HW_ARGS);
   else
-    hipLaunchKernelGGL((gemm_wgrad_h3_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, HW_ARGS);
+    hipLaunchKernelGGL((gemm_wgrad_h3_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, HW_ARGS);
   BL_LAUNCH_CHECK(who);
   return BL_OK;
 }

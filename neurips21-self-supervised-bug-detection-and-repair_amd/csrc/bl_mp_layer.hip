@@ -122,6 +122,7 @@ extern "C" double bl_prof_read_bytes(int32_t kind) {
 }
 
 // ---- buffer carving ---------------------------------------------------------------------------------
+extern bool g_h3_one_term;  // csrc/bl_gemm_h3.hip: the f16x3 GEMMs evaluate the high-plane term only (mode 2)
 namespace {
 inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 inline size_t packed_w_elems(int G, int K, int N) { return (size_t)G * ((N + 127) / 128) * (K / 32) * 12288; }
@@ -195,13 +196,16 @@ WsBwd carve_bwd(void* base, int N, int E, int Din, int Dm, int Dout, bool full_g
 // and weights -- bounded tensors, fixed power-of-two scales BL_H3_ROW_SCALE / BL_H3_W_SCALE; the routed gradient operand gq has
 // no bound known in advance: its amax is taken on the device and the scale derived from it there (no host round trip).  The
 // dense node update stays on bf16x6 (its operands g_z / LayerNorm outputs are produced packed by fused kernels).
+// Mode 2 ("f16x1", `train.py --amp`): the same packed images and kernels, high-plane term only (g_h3_one_term in bl_gemm_h3.hip) --
+// fp16 operands, fp32 accumulation and fp32 results, the gradient operand scaled by its device-side amax (what a GradScaler is for).
 int g_msg_h3 = -1;
 bool msg_h3() {
   if (g_msg_h3 < 0) {
     const char* e = getenv("BL_MSG_GEMM");
-    g_msg_h3 = (e && (e[0] == 'x' || e[0] == 'b')) ? 0 : 1;  // "x6" / "bf16x6" -> 0; default f16x3
+    g_msg_h3 = (e && (e[0] == 'x' || e[0] == 'b')) ? 0 : ((e && (e[0] == 'a' || (e[0] == 'f' && e[4] == '1'))) ? 2 : 1);  // "x6" / "bf16x6" -> 0; "amp" / "f16x1" -> 2; default f16x3
+    g_h3_one_term = g_msg_h3 == 2;
   }
-  return g_msg_h3 == 1;
+  return g_msg_h3 >= 1;
 }
 
 bool g_fused_node_bwd = true;  // bl_set_fused_node_bwd: act backward -> dense input gradient -> LayerNorm backward in one kernel
@@ -259,12 +263,17 @@ extern "C" int32_t bl_mp_layer_weight_image(int32_t Din, int32_t Dm, int32_t for
   if (msg_h3()) return 2;  // bl_pack_weights_h3 (kinds 5 / 6 of bl_pack_weights_multi)
   return for_backward ? bl_gemm_rows_x6w_ok(2 * Din, Dm) : bl_gemm_rows_x6w_ok(Dm, 2 * Din);
 }
-extern "C" int32_t bl_set_msg_gemm_mode(int32_t f16x3) {
-  const int32_t prev = msg_h3() ? 1 : 0;
-  g_msg_h3 = f16x3 ? 1 : 0;
+extern "C" int32_t bl_set_msg_gemm_mode(int32_t mode) {
+  (void)msg_h3();
+  const int32_t prev = g_msg_h3;
+  g_msg_h3 = mode == 2 ? 2 : (mode ? 1 : 0);
+  g_h3_one_term = g_msg_h3 == 2;
   return prev;
 }
-extern "C" int32_t bl_get_msg_gemm_mode(void) { return msg_h3() ? 1 : 0; }
+extern "C" int32_t bl_get_msg_gemm_mode(void) {
+  (void)msg_h3();
+  return g_msg_h3;
+}
 
 extern "C" int64_t bl_mp_layer_packed_weight_elems(int32_t T, int32_t Din, int32_t Dm, int32_t for_backward) {
   if (msg_h3()) return for_backward ? bl_packed_weight_elems_h3(T, Dm, 2 * Din) : bl_packed_weight_elems_h3(T, 2 * Din, Dm);

@@ -1,0 +1,48 @@
+"""CPU: `seq-transformer` host side -- the registry builds it (reference modelregistry.py:135), the encoder stacks the plain
+transformer layer, and the layer's parameter layout maps to torch.nn.TransformerEncoderLayer's and back without loss."""
+import copy
+from pathlib import Path
+
+import pytest
+import torch
+
+
+def test_layout_maps_are_inverse():
+    from buglab.models.layers.transformer import TransformerEncoderLayer
+
+    torch.manual_seed(1)
+    ref = torch.nn.TransformerEncoderLayer(d_model=64, nhead=4, dim_feedforward=96, dropout=0.0)
+    with torch.no_grad():
+        ref.self_attn.in_proj_bias.uniform_(-1, 1)
+    mine = TransformerEncoderLayer(64, 4, 96, dropout=0.0).load_torch_layer(ref)
+    back = mine.torch_layout()
+    for name, p in ref.named_parameters():
+        assert torch.equal(back[name], p.detach()), name
+    # head h's query / key / value columns are contiguous blocks of the packed projection: x @ in_proj_W == torch's in_proj, permuted
+    x = torch.randn(5, 64)
+    qkv = x @ mine.in_proj_W + mine.in_proj_b
+    q, k, v = torch.nn.functional.linear(x, ref.self_attn.in_proj_weight, ref.self_attn.in_proj_bias).chunk(3, dim=-1)
+    for h in range(4):
+        blk = qkv[:, h * 48:(h + 1) * 48]
+        assert torch.allclose(blk[:, :16], q[:, h * 16:(h + 1) * 16], atol=1e-6)
+        assert torch.allclose(blk[:, 16:32], k[:, h * 16:(h + 1) * 16], atol=1e-6)
+        assert torch.allclose(blk[:, 32:], v[:, h * 16:(h + 1) * 16], atol=1e-6)
+
+
+def test_registry_builds_seq_transformer_and_refuses_seq_gru(tmp_path):
+    from buglab.data.synthetic import make_buglab_seq_dataset
+    from buglab.models.layers.transformer import TransformerEncoderLayer
+    from buglab.models.modelregistry import load_model
+
+    data = make_buglab_seq_dataset(4, seed=2)
+    model = load_model({"modelName": "seq-transformer", "hidden_state_size": 64, "num_layers": 3, "num_heads": 4,
+                        "intermediate_dimension_size": 96}, Path(tmp_path / "m.pkl.gz"))[0]
+    model.compute_metadata(copy.deepcopy(data))
+    nn_ = model.build_neural_module()
+    layers = [m for m in nn_.modules() if isinstance(m, TransformerEncoderLayer)]
+    assert len(layers) == 3 and all(l.head_dim == 16 for l in layers)
+    assert model.tensorize(copy.deepcopy(data[0])) is not None
+    with pytest.raises(NotImplementedError):
+        load_model({"modelName": "seq-gru"}, Path(tmp_path / "g.pkl.gz"))
+    with pytest.raises(AssertionError):
+        TransformerEncoderLayer(65, 4)

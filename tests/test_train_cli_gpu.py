@@ -55,6 +55,32 @@ def test_train_then_evaluate_roundtrip(tmp_path):
     assert n == 16
 
 
+def test_train_cli_with_amp(tmp_path):
+    """`train.py ... --amp` (reference train.py:8,106): trains with the message GEMMs on fp16 operands, saves a checkpoint that
+    evaluates like any other, and leaves the process on the default split afterwards."""
+    from buglab.data.synthetic import make_buglab_dataset
+    from buglab.models import evaluate, hip_ops, train
+    from buglab.utils.msgpackutils import save_msgpack_l_gz
+
+    data = make_buglab_dataset(64, seed=5)
+    (tmp_path / "train").mkdir()
+    (tmp_path / "valid").mkdir()
+    save_msgpack_l_gz(data[:48], tmp_path / "train" / "a.msgpack.l.gz")
+    save_msgpack_l_gz(data[48:], tmp_path / "valid" / "v.msgpack.l.gz")
+    model_path = tmp_path / "model.pkl.gz"
+    before = hip_ops.msg_gemm_mode()
+    args = train.parse_args(["gnn-mlp", str(tmp_path / "train"), str(tmp_path / "valid"), str(model_path), "--max-num-epochs", "2",
+                             "--minibatch-size", "16", "--quiet", "--sequential", "--amp",
+                             "--model-spec", '{"hidden_state_size": 64, "num_layers": 4}'])
+    assert args["--amp"]
+    train.run(args)
+    assert hip_ops.msg_gemm_mode() == before
+    assert model_path.exists()
+    metrics = evaluate.run({"MODEL_FILENAME": str(model_path), "TEST_DATA_PATH": str(tmp_path / "valid"), "--assume-buggy": False,
+                            "--eval-only-no-bug": False, "--limit-num-elements": None, "--sequential": True})
+    assert metrics["num_samples"] == 16
+
+
 def test_trainandeval_entry_point(tmp_path, capsys):
     """reference buglab/models/trainandeval.py:1-29: train.run(args) then evaluate.run(args) from ONE argument dictionary."""
     from buglab.data.synthetic import make_buglab_dataset
