@@ -347,6 +347,24 @@ int bl_gru_cell_fwd(const float* gi, const float* gh, const float* h, int32_t ld
 int bl_gru_cell_bwd(const float* g_out, const float* gi, const float* gh, const float* h, int32_t ld_h, int32_t N,
                     int32_t D, bl_dropout_t drop, float* g_gi, float* g_gh, float* g_h, void* stream);
 
+/* Time recurrence of one BIDIRECTIONAL GRU layer over a padded [B, L] minibatch (`seq-gru`): replaces torch.nn.GRU(bidirectional,
+ * batch_first) applied to a PackedSequence (reference buglab/models/seqmodel.py:119-126, called at :385-392 between
+ * pack_padded_sequence(lengths, enforce_sorted=False) and pad_packed_sequence): every sequence runs over its own length, the
+ * reverse direction starts at its last real token, positions >= lens[b] come back as zeros.  Row b * L + t everywhere.
+ *   gi   [B L, >= 6 Hh]  x W_ih + b_ih of both directions, columns [direction][r | z | n][Hh]  (one row GEMM outside)
+ *   w_hh [2][Hh][3 Hh]   gh = h . w_hh[direction] + b_hh[direction]   (torch's weight_hh_l{k}{_reverse}, transposed); b_hh [2][3 Hh]
+ *   out  [B L, >= 2 Hh]  forward direction in columns 0 .. Hh - 1, reverse in Hh .. 2 Hh - 1
+ *   saved  bl_gru_scan_saved_elems floats kept for bl_gru_scan_bwd (NULL: forward only), gates [2][B L][r | z | n | gh_n] then h_prev [2][B L][Hh]
+ * Hh in {32, 64, 128}.  One workgroup per (sequence, direction); exact fp32 arithmetic.
+ * bwd: g_out [B L, >= 2 Hh] -> g_gi [B L, >= 6 Hh] (gradient of gi; zeros at padded rows) and g_gh [2][B L][3 Hh] (gradient of
+ * the recurrent pre-activations: the caller forms g_w_hh[d] = h_prev[d]^T g_gh[d] (bl_gemm_wgrad on saved's h_prev block) and
+ * g_b_hh[d] = column sums of g_gh[d]). */
+int64_t bl_gru_scan_saved_elems(int32_t B, int32_t L, int32_t Hh);
+int bl_gru_scan_fwd(const float* gi, int32_t ld_gi, const float* w_hh, const float* b_hh, const int32_t* lens, int32_t B, int32_t L,
+                    int32_t Hh, float* out, int32_t ld_out, float* saved, void* stream);
+int bl_gru_scan_bwd(const float* g_out, int32_t ld_g, const float* w_hh, const float* saved, const int32_t* lens, int32_t B, int32_t L,
+                    int32_t Hh, float* g_gi, int32_t ld_ggi, float* g_gh, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ONE MlpMessagePassingLayer per call (SURVEY.md section 8b's minimum set).  Replaces ptgnn's
  * MlpMessagePassingLayer.forward and its autograd; kwargs of the reference call site

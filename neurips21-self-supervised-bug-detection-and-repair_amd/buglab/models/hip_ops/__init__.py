@@ -1656,6 +1656,49 @@ def rel_attention(qkv, lens, edges: RelEdges, bias_f, bias_r, vb_f, vb_r, B, L, 
                                bool(scalar_bias), drop)
 
 
+# ---- `seq-gru`: the time recurrence of one bidirectional GRU layer (csrc/bl_gru_scan.hip) -------------------------------------
+class _GruScan(torch.autograd.Function):
+    """gi [B L, 6 Hh] (x W_ih + b_ih of both directions, columns [direction][r | z | n]) -> h_t of both directions [B L, 2 Hh] with
+    torch.nn.GRU's PackedSequence semantics (reference seqmodel.py:385-392).  Backward: one reverse scan (bl_gru_scan_bwd) gives the
+    gradient of gi and of the recurrent pre-activations; the recurrent weight gradient h_prev^T d_gh is a weight-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, gi, W_hh, b_hh, lens, B, L):
+        lib = load_library()
+        _f32(gi, "gi")
+        Hh = W_hh.shape[1]
+        R = B * L
+        assert gi.shape == (R, 6 * Hh) and W_hh.shape == (2, Hh, 3 * Hh) and b_hh.shape == (2, 3 * Hh)
+        need_bwd = any(ctx.needs_input_grad)
+        out = torch.empty((R, 2 * Hh), dtype=torch.float32, device=gi.device)
+        saved = torch.empty((lib.bl_gru_scan_saved_elems(B, L, Hh),), dtype=torch.float32, device=gi.device) if need_bwd else None
+        _check(lib.bl_gru_scan_fwd(gi.data_ptr(), gi.stride(0), _f32(W_hh.contiguous()).data_ptr(), _f32(b_hh.contiguous()).data_ptr(),
+                                   _i32(lens).data_ptr(), B, L, Hh, out.data_ptr(), out.stride(0), _p(saved), _stream()), "bl_gru_scan_fwd")
+        ctx.saved = (W_hh, lens, B, L, Hh, saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        W_hh, lens, B, L, Hh, saved = _take_saved(ctx)
+        lib = load_library()
+        R = B * L
+        dev = g_out.device
+        g_out = g_out.contiguous()
+        g_gi = torch.empty((R, 6 * Hh), dtype=torch.float32, device=dev)
+        g_gh = torch.empty((2, R, 3 * Hh), dtype=torch.float32, device=dev)
+        _check(lib.bl_gru_scan_bwd(g_out.data_ptr(), g_out.stride(0), _f32(W_hh.contiguous()).data_ptr(), saved.data_ptr(), _i32(lens).data_ptr(),
+                                   B, L, Hh, g_gi.data_ptr(), g_gi.stride(0), g_gh.data_ptr(), _stream()), "bl_gru_scan_bwd")
+        g_W = torch.zeros_like(W_hh)
+        h_prev = saved[2 * R * 4 * Hh:].view(2, R, Hh)
+        for d in range(2):
+            gemm_wgrad([(h_prev[d], None)], g_gh[d], R, 3 * Hh, g_W[d])  # h_prev^T . d_gh
+        return g_gi, g_W, g_gh.sum(1), None, None, None
+
+
+def gru_scan(gi, W_hh, b_hh, lens, B: int, L: int):
+    return _GruScan.apply(gi.contiguous(), W_hh, b_hh, lens, int(B), int(L))
+
+
 # ---- one relational transformer encoder layer per C call (csrc/bl_great_layer.hip) ----------------------------------------
 FUSED_GREAT_LAYER = os.environ.get("BL_FUSED_GREAT_LAYER", "1") != "0"  # A/B switch: 0 = the op-by-op path above
 

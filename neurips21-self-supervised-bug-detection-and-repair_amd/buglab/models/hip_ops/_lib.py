@@ -219,6 +219,9 @@ _SIGNATURES = {
     "bl_act_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_act_bwd_packed": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_mp_scatter_grad": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gru_scan_saved_elems": ([c_int32, c_int32, c_int32], c_int64),
+    "bl_gru_scan_fwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_gru_scan_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_gru_cell_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p], ctypes.c_int),
     "bl_gru_cell_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_segment_log_softmax_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p], ctypes.c_int),

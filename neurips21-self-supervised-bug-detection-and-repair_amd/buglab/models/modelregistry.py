@@ -1,7 +1,7 @@
 """Model registry -- the plugin API of the path (reference buglab/models/modelregistry.py):
 `load_model`, `construct_model_dict`, `gnn`, buggy-sample weight schedules.  Same names, kwargs,
-defaults and error behaviour; `gnn-mlp`, `ggnn`, `seq-great`, `seq-rat` and `seq-transformer` are built on
-the HIP path; `seq-gru` (a torch.nn.GRU wrapper in the reference) raises NotImplementedError."""
+defaults and error behaviour; all six names -- `gnn-mlp`, `ggnn`, `seq-great`, `seq-rat`,
+`seq-transformer`, `seq-gru` -- are built on the HIP path."""
 import logging
 import re
 from functools import partial
@@ -92,11 +92,9 @@ def seq_transformer(*, layer_type, hidden_state_size: int = 256, dropout_rate: f
                     selector_loss_type: str = "classify-max-loss", num_layers: int = 5, num_heads: int = 8, max_seq_size: int = 400,
                     intermediate_dimension_size: int = 1024, buggy_samples_weight_spec: Union[str, int, float] = 1.0,
                     rezero_mode: str = "off", normalisation_mode: str = "postnorm", **__):
-    """reference :97-126 (same kwargs and defaults).  `great` / `rat` / `transformer` run on the HIP path (the last one with
-    torch.nn.TransformerEncoderLayer's arithmetic, layers/transformer.py); `gru` wraps torch.nn.GRU in the reference and is not built here."""
-    if layer_type == "gru":
-        raise NotImplementedError("`seq-gru` wraps a bidirectional torch.nn.GRU in the reference (seqmodel.py:119-126); the HIP path implements "
-                                  "`seq-great`, `seq-rat` and `seq-transformer`")
+    """reference :97-126 (same kwargs and defaults).  All four layer types run on the HIP path: `great` / `rat` (relational
+    transformer), `transformer` (torch.nn.TransformerEncoderLayer's arithmetic, layers/transformer.py) and `gru` (torch.nn.GRU's,
+    bidirectional over packed sequences: layers/gru.py, csrc/bl_gru_scan.hip)."""
     from buglab.models.seqmodel import SeqBugLabModel
 
     return SeqBugLabModel(hidden_state_size, max_subtoken_vocab_size=vocab_size, dropout_rate=dropout_rate, layer_type=layer_type,

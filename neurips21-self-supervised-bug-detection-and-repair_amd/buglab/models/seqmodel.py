@@ -34,6 +34,7 @@ from buglab.models.graphmodel import StrElementRepresentationModel
 from buglab.models.hip_ops import Dropout, RelEdges
 from buglab.models.layers.messagepassing import GnnOutput, SubtokenEmbedder
 from buglab.models.layers.relational_transformer import RelationalTransformerEncoderLayer
+from buglab.models.layers.gru import BiGRULayer
 from buglab.models.layers.transformer import TransformerEncoderLayer
 from buglab.representations.tokenseq import project_graph_to_tokens
 from buglab.runtime.neuralmodel import AbstractNeuralModel
@@ -51,10 +52,7 @@ class SequenceEncoder(nn.Module):
                  intermediate_dimension: int, dropout_rate: float, layer_type: str = "great", rezero_mode: str = "off",
                  normalisation_mode: str = "postnorm"):
         super().__init__()
-        if layer_type == "gru":
-            raise NotImplementedError("layer type `gru` (reference seqmodel.py:119-126: a bidirectional torch.nn.GRU) is not built on the HIP "
-                                      "path; `great`, `rat` and `transformer` are")
-        if layer_type not in ("great", "rat", "transformer"):
+        if layer_type not in ("great", "rat", "transformer", "gru"):
             raise ValueError(f"Unrecognized layer type `{layer_type}`.")  # reference seqmodel.py:128
         D = embedding_dim
         self.embed = token_embedder
@@ -63,7 +61,8 @@ class SequenceEncoder(nn.Module):
         self.dropout_rate = dropout_rate
         self.layer_type = layer_type
         # `transformer`: torch.nn.TransformerEncoderLayer's arithmetic (reference seqmodel.py:108-118); edges are not looked at
-        self.layers = nn.ModuleList([
+        # `gru`: torch.nn.GRU(D, D // 2, num_layers, bidirectional) as a stack of bidirectional layers (reference seqmodel.py:119-126)
+        self.layers = nn.ModuleList([BiGRULayer(D, D // 2) for _ in range(num_layers)]) if layer_type == "gru" else nn.ModuleList([
             TransformerEncoderLayer(d_model=D, nhead=num_heads, dim_feedforward=intermediate_dimension, dropout=dropout_rate)
             for _ in range(num_layers)]) if layer_type == "transformer" else nn.ModuleList([
             RelationalTransformerEncoderLayer(d_model=D, key_query_dimension=D // num_heads, value_dimension=D // num_heads,
@@ -89,9 +88,12 @@ class SequenceEncoder(nn.Module):
         mk = lambda stream: Dropout(self.dropout_rate if training else 0.0, seed, stream)
         tok_csr = (tok_occ, tok_chunk_ptr, tok_chunk_id) if tok_occ is not None else None
         emb = self.embed(token_ids, token_lens, mk(0), tok_csr)  # [B * L, D]
-        pos = self.positional_encoding[0, :L].unsqueeze(0).expand(B, L, -1).reshape(B * L, -1)
-        x = hip_ops.add_layernorm(emb, pos, self.input_norm_g, self.input_norm_b)  # LayerNorm(embedding + position)
-        x = hip_ops.dropout_rows(x, mk(1))
+        if getattr(self, "layer_type", "great") == "gru":
+            x = emb  # reference seqmodel.py:363: positions, input LayerNorm and dropout are for the transformer variants only
+        else:
+            pos = self.positional_encoding[0, :L].unsqueeze(0).expand(B, L, -1).reshape(B * L, -1)
+            x = hip_ops.add_layernorm(emb, pos, self.input_norm_g, self.input_norm_b)  # LayerNorm(embedding + position)
+            x = hip_ops.dropout_rows(x, mk(1))
         valid = (torch.arange(L, device=x.device, dtype=torch.int32)[None, :] < seq_lens[:, None]).reshape(B * L, 1)
         x = x * valid  # `output_representation *= token_mask` (:372)
         h0 = x

@@ -1,4 +1,4 @@
-"""CPU: `seq-transformer` host side -- the registry builds it (reference modelregistry.py:135), the encoder stacks the plain
+"""CPU: `seq-transformer` / `seq-gru` host side -- the registry builds it (reference modelregistry.py:135), the encoder stacks the plain
 transformer layer, and the layer's parameter layout maps to torch.nn.TransformerEncoderLayer's and back without loss."""
 import copy
 from pathlib import Path
@@ -29,7 +29,23 @@ def test_layout_maps_are_inverse():
         assert torch.allclose(blk[:, 32:], v[:, h * 16:(h + 1) * 16], atol=1e-6)
 
 
-def test_registry_builds_seq_transformer_and_refuses_seq_gru(tmp_path):
+def test_gru_layout_maps_are_inverse():
+    from buglab.models.layers.gru import BiGRULayer
+
+    torch.manual_seed(2)
+    gru = torch.nn.GRU(input_size=64, hidden_size=32, num_layers=2, bidirectional=True, batch_first=True)
+    for k in range(2):
+        mine = BiGRULayer(64, 32).load_torch_gru(gru, k)
+        back = mine.torch_layout(k)
+        want = {n: p for n, p in gru.named_parameters() if f"_l{k}" in n}
+        assert set(back) == set(want)
+        for n, p in want.items():
+            assert torch.equal(back[n], p.detach()), n
+    with pytest.raises(NotImplementedError):
+        BiGRULayer(100, 50)
+
+
+def test_registry_builds_seq_transformer_and_seq_gru(tmp_path):
     from buglab.data.synthetic import make_buglab_seq_dataset
     from buglab.models.layers.transformer import TransformerEncoderLayer
     from buglab.models.modelregistry import load_model
@@ -42,7 +58,11 @@ def test_registry_builds_seq_transformer_and_refuses_seq_gru(tmp_path):
     layers = [m for m in nn_.modules() if isinstance(m, TransformerEncoderLayer)]
     assert len(layers) == 3 and all(l.head_dim == 16 for l in layers)
     assert model.tensorize(copy.deepcopy(data[0])) is not None
-    with pytest.raises(NotImplementedError):
-        load_model({"modelName": "seq-gru"}, Path(tmp_path / "g.pkl.gz"))
+    from buglab.models.layers.gru import BiGRULayer
+
+    g = load_model({"modelName": "seq-gru", "hidden_state_size": 64, "num_layers": 2}, Path(tmp_path / "g.pkl.gz"))[0]
+    g.compute_metadata(copy.deepcopy(data))
+    gl = [m for m in g.build_neural_module().modules() if isinstance(m, BiGRULayer)]
+    assert len(gl) == 2 and all(l.hidden_size == 32 and l.input_size == 64 for l in gl)
     with pytest.raises(AssertionError):
         TransformerEncoderLayer(65, 4)
