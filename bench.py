@@ -359,7 +359,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="gnn-mlp", choices=["gnn-mlp", "seq-great"],
+    ap.add_argument("--model", default="gnn-mlp", choices=["gnn-mlp", "seq-great", "seq-transformer", "seq-gru"],
                     help="gnn-mlp: BASELINE configs[1] (default).  seq-great: BASELINE configs[4], relational transformer, "
                          "hidden 256, 5 layers, 8 heads, FF 1024, sequences of --seq-len tokens")
     ap.add_argument("--seq-len", type=int, default=512)
@@ -399,7 +399,7 @@ def main():
         sys.exit(self_launch(args.gpus))
     if args.dry_launch:
         sys.exit(dry_launch(args.gpus))
-    seq = args.model == "seq-great"
+    seq = args.model.startswith("seq-")  # seq-great = BASELINE configs[4]; seq-transformer / seq-gru: the registry's other sequence encoders, same workload
     if args.hidden is None:
         args.hidden = 256 if seq else 128
     if args.graphs is None:
@@ -432,7 +432,7 @@ def main():
     def build_workload(a):
         """(module, minibatch, optimiser) of one configuration: resident synthetic minibatch, random-init weights."""
         torch.manual_seed(0)  # identical initial weights on every rank
-        if a.model == "seq-great":
+        if a.model.startswith("seq-"):
             # BASELINE configs[4]: every sequence has --seq-len tokens (1-6 subtokens each), 2 relations per token over 8 edge
             # kinds, 40 candidate locations and the usual rewrite candidates; laid out by the product's own padded collator
             from buglab.models.layers.messagepassing import SubtokenEmbedder
@@ -441,7 +441,7 @@ def main():
             samples = make_samples(a.graphs, seed=1000 + rank, num_nodes=a.seq_len, num_messages=2 * a.seq_len, num_edge_types=a.types)
             mb_ = to_device(collate_sequences([SeqTensorizedSample(s, {}, ()) for s in samples], a.types), device)
             enc = SequenceEncoder(SubtokenEmbedder(15000, a.hidden, 6, a.dropout), a.hidden, a.types, a.layers, 8,
-                                  4 * a.hidden, a.dropout, layer_type="great")
+                                  4 * a.hidden, a.dropout, layer_type=a.model[4:])
             module_ = SeqBugLabModule(enc, 48).to(device).train()
             module_._dropout_base_seed = rank
         else:
@@ -508,7 +508,11 @@ def main():
 
     def fwd_work(a):
         """(forward FLOPs, compulsory forward bytes) per graph / sequence of configuration `a` (SURVEY 8d / 8f formulas)."""
-        if a.model == "seq-great":
+        if a.model == "seq-gru":
+            # per sequence and layer: input projections of both directions 2 L D (6 Hh) + recurrent products 2 L 2 Hh (3 Hh), Hh = D / 2
+            Ls, Dh = a.seq_len, a.hidden
+            return a.layers * (2.0 * Ls * Dh * 3 * Dh + 2.0 * Ls * Dh * 3 * (Dh // 2)), a.layers * (3 * 4.0 * Ls * Dh) + 4.0 * a.layers * 4.5 * Dh * Dh / a.graphs
+        if a.model.startswith("seq-"):
             # per sequence and layer: QKV + output projections 8 L D^2, feed-forward 4 L D FF, Q.K^T + P.V 4 L^2 D (SURVEY 8f: ~5.4 GFLOP)
             Ls, Dh, FFd = a.seq_len, a.hidden, 4 * a.hidden
             n_par = a.layers * (4 * Dh * Dh + 2 * Dh * FFd)
@@ -538,7 +542,7 @@ def main():
         del m_, mb2_, o_, st_
         gc.collect()
         torch.cuda.empty_cache()
-        unit = "sequences/s" if a.model == "seq-great" else "graphs/s"
+        unit = "sequences/s" if a.model.startswith("seq-") else "graphs/s"
         rate_ = a.graphs * world * args.steps / el_
         return {"value": round(rate_, 2), "unit": unit, "ms_per_step": round(1e3 * el_ / args.steps, 3),
                 "per_gpu": a.graphs, "n_gpus": world,
@@ -647,6 +651,10 @@ def main():
         if world == 1:
             also["configs[4] seq-great hidden=256 layers=5 heads=8 ff=1024 batch=32 sequences x 512 tokens"] = side_config(
                 model="seq-great", hidden=256, graphs=32, layers=5, types=8, dropout=0.1)
+            # the registry's two other sequence encoders on the same workload (reference modelregistry.py:135-136; torch.nn layers there)
+            for other in ("seq-transformer", "seq-gru"):
+                also[f"{other} hidden=256 layers=5 batch=32 sequences x 512 tokens (registry model outside BASELINE's configs)"] = side_config(
+                    model=other, hidden=256, graphs=32, layers=5, types=8, dropout=0.1)
 
     if rank == 0:
         total_graphs = args.graphs * world * args.steps
@@ -674,7 +682,7 @@ def main():
                       else "f32 (bf16x6 split products)"),
             "data": "synthetic",
             "config": {
-                "workload": (f"seq-great relational transformer hidden={args.hidden} layers={args.layers} heads=8 ff={4 * args.hidden} "
+                "workload": (f"{args.model} {'relational transformer' if args.model == 'seq-great' else 'encoder (torch.nn arithmetic on the HIP path)'} hidden={args.hidden} layers={args.layers} heads=8 ff={4 * args.hidden} "
                              f"edge_kinds={args.types} batch={args.graphs} sequences/GPU x {args.seq_len} tokens dropout={args.dropout}") if seq else
                             (f"gnn-mlp hidden={args.hidden} layers={args.layers} edge_types={args.types} "
                              f"batch={args.graphs} graphs/GPU x ({args.nodes} nodes, {args.messages} msgs) dropout={args.dropout}"
@@ -691,7 +699,7 @@ def main():
             "roofline": roof,
             "box": box,
             "also": also or None,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else (cpu_baseline_seq(args) if seq else cpu_baseline(args)),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else (cpu_baseline_seq(args) if args.model == "seq-great" else None if seq else cpu_baseline(args)),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

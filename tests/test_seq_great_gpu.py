@@ -430,7 +430,7 @@ def test_seq_model_end_to_end_matches_oracle(model_name, hidden, heads):
 
 
 @pytest.mark.parametrize("with_backward", [True, False])
-@pytest.mark.parametrize("family", ["seq-great", "seq-rat", "gnn-mlp", "gnn-mlp-all-outputs", "gnn-mlp-edge-features", "ggnn"])
+@pytest.mark.parametrize("family", ["seq-great", "seq-rat", "seq-transformer", "seq-gru", "gnn-mlp", "gnn-mlp-all-outputs", "gnn-mlp-edge-features", "ggnn"])
 def test_training_steps_do_not_accumulate_device_memory(family, with_backward):
     """A custom autograd Function that keeps its own OUTPUT as a plain ctx attribute forms a cycle (output -> grad_fn -> ctx ->
     output) that crosses into C++ and is never collected: every step's activations stay allocated.  `_GatherLinear` did that
