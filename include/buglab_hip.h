@@ -88,6 +88,26 @@ int bl_embed_subtoken_max_bwd_sorted(const float* g_out, int32_t ld_g, const int
                                      const int32_t* chunk_tok, int32_t nchunks, const int8_t* argsub, int32_t S,
                                      int32_t H, bl_dropout_t drop, int32_t drop_before_pool, float* g_table, void* stream);
 
+/* The embedder with the node model's other `subtoken_combination` values (reference buglab/models/modelregistry.py:65-66 sets "max"
+ * unless the caller's node_representations says otherwise; ptgnn's StrElementRepresentationModel also takes "sum" and "mean"):
+ * combination BL_POOL_MAX = the three entry points above; BL_POOL_SUM: out[n] = drop(sum_{s < lens[n]} emb[n, s]);
+ * BL_POOL_MEAN: the sum / lens[n].  argsub is used by BL_POOL_MAX only (NULL otherwise); bwd needs lens for sum / mean (every
+ * slot s < lens[n] receives g_out[n] (/ lens[n]), under its own mask bit with drop_before_pool); the sorted form needs lens for
+ * BL_POOL_MEAN. */
+#define BL_POOL_MAX 0
+#define BL_POOL_SUM 1
+#define BL_POOL_MEAN 2
+int bl_embed_subtoken_pool_fwd(const float* table, int32_t V, int32_t H, const int32_t* ids, const int32_t* lens, int32_t N, int32_t S,
+                               int32_t combination, bl_dropout_t drop, int32_t drop_before_pool, float* out, int32_t ld_out,
+                               int8_t* argsub, void* stream);
+int bl_embed_subtoken_pool_bwd(const float* g_out, int32_t ld_g, const int32_t* ids, const int32_t* lens, const int8_t* argsub, int32_t N,
+                               int32_t S, int32_t H, int32_t V, int32_t combination, bl_dropout_t drop, int32_t drop_before_pool,
+                               float* g_table, void* stream);
+int bl_embed_subtoken_pool_bwd_sorted(const float* g_out, int32_t ld_g, const int32_t* occ, const int32_t* chunk_ptr,
+                                      const int32_t* chunk_tok, int32_t nchunks, const int32_t* lens, const int8_t* argsub, int32_t S,
+                                      int32_t H, int32_t combination, bl_dropout_t drop, int32_t drop_before_pool, float* g_table,
+                                      void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Grouped, gathered fp32 GEMM on MFMA (v_mfma_f32_32x32x2_f32, exact fp32).
  *   for group g (rows group_ptr[g] .. group_ptr[g+1]):  C[r, 0:N] = drop(act(rows(a)[r, 0:K] . B_g + bias))

@@ -24,9 +24,11 @@ class StrElementRepresentationModel:
     def __init__(self, *, token_splitting: str = "subtoken", embedding_size: int = 128, vocabulary_size: int = 15000,
                  max_num_subtokens: int = 6, subtoken_combination: str = "max", dropout_rate: float = 0.0,
                  min_freq_threshold: int = 5, dropout_placement: str = "after_pooling"):
-        if token_splitting not in ("subtoken", "token") or (token_splitting == "subtoken" and subtoken_combination != "max"):
-            raise NotImplementedError("the HIP embedders implement subtoken / max (the node model, modelregistry.py:61-67) and "
-                                      "token (the edge-feature model, modelregistry.py:70-74)")
+        if token_splitting not in ("subtoken", "token"):
+            raise NotImplementedError("the HIP embedders implement subtoken (the node model, modelregistry.py:61-67) and "
+                                      "token (the edge-feature model, modelregistry.py:70-74) splitting")
+        if subtoken_combination not in ("max", "sum", "mean"):
+            raise ValueError(f"subtoken_combination must be 'max', 'sum' or 'mean' (got {subtoken_combination!r})")
         self.token_splitting, self.subtoken_combination = token_splitting, subtoken_combination
         self.embedding_size, self.vocabulary_size = embedding_size, vocabulary_size
         self.max_num_subtokens, self.dropout_rate = max_num_subtokens, dropout_rate
@@ -56,7 +58,7 @@ class StrElementRepresentationModel:
         if self.token_splitting == "token":
             return TokenEmbedder(len(self.vocabulary), self.embedding_size)
         return SubtokenEmbedder(len(self.vocabulary), self.embedding_size, self.max_num_subtokens, self.dropout_rate,
-                                getattr(self, "dropout_placement", "after_pooling"))
+                                getattr(self, "dropout_placement", "after_pooling"), getattr(self, "subtoken_combination", "max"))
 
     def tensorize_tokens(self, strs) -> np.ndarray:
         """token mode: one vocabulary id per string (the pad token is a vocabulary entry; unseen strings -> unk)."""

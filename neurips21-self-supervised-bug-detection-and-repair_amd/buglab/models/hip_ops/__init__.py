@@ -408,24 +408,27 @@ class GraphIndex(NamedTuple):
     num_hubs: int = -1  # leading entries of node_order that are hubs (-1: unknown, the kernels look at the first 4096)
 
 
+POOLINGS = ("max", "sum", "mean")  # BL_POOL_MAX / _SUM / _MEAN
+
+
 class _EmbedSubtokenMax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, ids, lens, drop: Dropout, tok_csr, before_pool: bool):
+    def forward(ctx, table, ids, lens, drop: Dropout, tok_csr, before_pool: bool, comb: int):
         _f32(table, "embedding table")
         N, S = ids.shape
         V, H = table.shape
         out = torch.empty((N, H), dtype=torch.float32, device=table.device)
-        argsub = torch.empty((N, H), dtype=torch.int8, device=table.device)
+        argsub = torch.empty((N, H), dtype=torch.int8, device=table.device) if comb == 0 else None
         _check(
-            load_library().bl_embed_subtoken_max_fwd(table.data_ptr(), V, H, _i32(ids).data_ptr(), _i32(lens).data_ptr(), N, S,
-                                                     drop.c(), int(bool(before_pool)), out.data_ptr(), out.stride(0), argsub.data_ptr(), _stream()),
-            "bl_embed_subtoken_max_fwd")
-        ctx.saved = (table, ids, argsub, drop, V, H, tok_csr, int(bool(before_pool)))
+            load_library().bl_embed_subtoken_pool_fwd(table.data_ptr(), V, H, _i32(ids).data_ptr(), _i32(lens).data_ptr(), N, S, comb,
+                                                      drop.c(), int(bool(before_pool)), out.data_ptr(), out.stride(0), _p(argsub), _stream()),
+            "bl_embed_subtoken_pool_fwd")
+        ctx.saved = (table, ids, lens, argsub, drop, V, H, tok_csr, int(bool(before_pool)), comb)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        table, ids, argsub, drop, V, H, tok_csr, before_pool = _take_saved(ctx)
+        table, ids, lens, argsub, drop, V, H, tok_csr, before_pool, comb = _take_saved(ctx)
         g_out = g_out.contiguous()
         N, S = ids.shape
         direct = _direct_small(table)
@@ -433,24 +436,26 @@ class _EmbedSubtokenMax(torch.autograd.Function):
         if tok_csr is not None:
             occ, chunk_ptr, chunk_tok = tok_csr
             _check(
-                load_library().bl_embed_subtoken_max_bwd_sorted(g_out.data_ptr(), g_out.stride(0), _i32(occ).data_ptr(),
-                                                                _i32(chunk_ptr).data_ptr(), _i32(chunk_tok).data_ptr(),
-                                                                int(chunk_tok.shape[0]), argsub.data_ptr(), S, H, drop.c(), before_pool,
-                                                                g_table.data_ptr(), _stream()),
-                "bl_embed_subtoken_max_bwd_sorted")
+                load_library().bl_embed_subtoken_pool_bwd_sorted(g_out.data_ptr(), g_out.stride(0), _i32(occ).data_ptr(),
+                                                                 _i32(chunk_ptr).data_ptr(), _i32(chunk_tok).data_ptr(),
+                                                                 int(chunk_tok.shape[0]), _i32(lens).data_ptr(), _p(argsub), S, H, comb, drop.c(),
+                                                                 before_pool, g_table.data_ptr(), _stream()),
+                "bl_embed_subtoken_pool_bwd_sorted")
         else:
             _check(
-                load_library().bl_embed_subtoken_max_bwd(g_out.data_ptr(), g_out.stride(0), ids.data_ptr(), argsub.data_ptr(), N, S, H,
-                                                         V, drop.c(), before_pool, g_table.data_ptr(), _stream()),
-                "bl_embed_subtoken_max_bwd")
-        return (None if direct is not None else g_table), None, None, None, None, None
+                load_library().bl_embed_subtoken_pool_bwd(g_out.data_ptr(), g_out.stride(0), ids.data_ptr(), _i32(lens).data_ptr(), _p(argsub),
+                                                          N, S, H, V, comb, drop.c(), before_pool, g_table.data_ptr(), _stream()),
+                "bl_embed_subtoken_pool_bwd")
+        return (None if direct is not None else g_table), None, None, None, None, None, None
 
 
-def embed_subtoken_max(table, ids, lens, drop: Dropout = NO_DROPOUT, tok_csr=None, dropout_before_pooling: bool = False):
+def embed_subtoken_max(table, ids, lens, drop: Dropout = NO_DROPOUT, tok_csr=None, dropout_before_pooling: bool = False,
+                       combination: str = "max"):
     """tok_csr = (occ, chunk_ptr, chunk_tok) from the collator (token-sorted subtoken occurrences): backward
     then sums per token in registers instead of issuing one atomic per (node, channel).
-    dropout_before_pooling: dropout on the embedded subtokens (then max) instead of on the pooled rows."""
-    return _EmbedSubtokenMax.apply(table, ids, lens, drop, tok_csr, bool(dropout_before_pooling))
+    dropout_before_pooling: dropout on the embedded subtokens (then max) instead of on the pooled rows.
+    combination: "max" (the registry's default, modelregistry.py:65-66), "sum" or "mean" over the subtokens."""
+    return _EmbedSubtokenMax.apply(table, ids, lens, drop, tok_csr, bool(dropout_before_pooling), POOLINGS.index(combination))
 
 
 class _MpLayer(torch.autograd.Function):

@@ -105,6 +105,9 @@ _SIGNATURES = {
                             c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "bl_set_fused_node_bwd": ([c_int32], c_int32),
     "bl_last_error": ([], ctypes.c_char_p),
+    "bl_embed_subtoken_pool_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_embed_subtoken_pool_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "bl_embed_subtoken_pool_bwd_sorted": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_bwd": ([c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "bl_embed_subtoken_max_bwd_sorted": ([c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, bl_dropout_t, c_int32, c_void_p, c_void_p], ctypes.c_int),

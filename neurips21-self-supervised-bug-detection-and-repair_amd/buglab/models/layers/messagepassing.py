@@ -57,13 +57,17 @@ def _uniform_(t: torch.Tensor, bound: float) -> torch.Tensor:
 
 
 class SubtokenEmbedder(nn.Module):
-    """StrElementRepresentationModel in "subtoken"/"max" mode (modelregistry.py:59-82)."""
+    """StrElementRepresentationModel in "subtoken" mode (modelregistry.py:59-82); subtoken_combination "max" (the registry's default),
+    "sum" or "mean"."""
 
     def __init__(self, vocabulary_size: int, embedding_size: int, max_num_subtokens: int = 6, dropout_rate: float = 0.0,
-                 dropout_placement: str = "after_pooling"):
+                 dropout_placement: str = "after_pooling", subtoken_combination: str = "max"):
         super().__init__()
         if dropout_placement not in ("after_pooling", "before_pooling"):
             raise ValueError(f"dropout_placement must be 'after_pooling' or 'before_pooling' (got {dropout_placement!r})")
+        if subtoken_combination not in hip_ops.POOLINGS:
+            raise ValueError(f"subtoken_combination must be one of {hip_ops.POOLINGS} (got {subtoken_combination!r})")
+        self.subtoken_combination = subtoken_combination
         self.embedding_size = embedding_size
         self.max_num_subtokens = max_num_subtokens
         self.dropout_rate = dropout_rate
@@ -74,7 +78,8 @@ class SubtokenEmbedder(nn.Module):
 
     def forward(self, token_ids, token_lens, drop: Dropout, tok_csr=None):
         before = getattr(self, "dropout_placement", "after_pooling") == "before_pooling"  # (older pickles: after)
-        return hip_ops.embed_subtoken_max(self.table, token_ids, token_lens, drop, tok_csr, dropout_before_pooling=before)
+        return hip_ops.embed_subtoken_max(self.table, token_ids, token_lens, drop, tok_csr, dropout_before_pooling=before,
+                                          combination=getattr(self, "subtoken_combination", "max"))  # (older pickles: max)
 
 
 class TokenEmbedder(nn.Module):

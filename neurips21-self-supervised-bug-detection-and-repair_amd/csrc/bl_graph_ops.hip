@@ -19,7 +19,7 @@
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, int H,
                                                         const int* __restrict__ ids, const int* __restrict__ lens,
                                                         int N, int S, bl_drop_dev drop, float* __restrict__ out,
-                                                        int ld_out, int8_t* __restrict__ argsub, int drop_before_pool) {
+                                                        int ld_out, int8_t* __restrict__ argsub, int drop_before_pool, int comb) {
   const int h4n = H >> 2;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)N * h4n) return;
@@ -47,10 +47,18 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
       v.z = bl_keep(drop, i + 2) ? v.z * drop.scale : 0.f;
       v.w = bl_keep(drop, i + 3) ? v.w * drop.scale : 0.f;
     }
+    if (comb != 0) {  // sum / mean over the subtokens (subtoken_combination of the node model, modelregistry.py:65-66)
+      best.x += v.x; best.y += v.y; best.z += v.z; best.w += v.w;
+      continue;
+    }
     if (v.x > best.x) { best.x = v.x; a0 = s; }
     if (v.y > best.y) { best.y = v.y; a1 = s; }
     if (v.z > best.z) { best.z = v.z; a2 = s; }
     if (v.w > best.w) { best.w = v.w; a3 = s; }
+  }
+  if (comb == 2) {
+    const float inv = 1.0f / (float)len;
+    best.x *= inv; best.y *= inv; best.z *= inv; best.w *= inv;
   }
   if (drop.thresh && !pre) {
     const uint32_t i = (uint32_t)n * (uint32_t)H + (uint32_t)h;
@@ -60,6 +68,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     best.w = bl_keep(drop, i + 3) ? best.w * drop.scale : 0.f;
   }
   *reinterpret_cast<float4*>(out + (size_t)n * ld_out + h) = best;
+  if (argsub == nullptr) return;  // (sum / mean: there is no winner)
   char4 a;
   a.x = (char)a0; a.y = (char)a1; a.z = (char)a2; a.w = (char)a3;
   *reinterpret_cast<char4*>(argsub + (size_t)n * H + h) = a;
@@ -73,11 +82,22 @@ __device__ __forceinline__ uint32_t embed_mask_index(int n, int s, int h, int S,
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g_out, int ld_g,
                                                         const int* __restrict__ ids,
                                                         const int8_t* __restrict__ argsub, int N, int S, int H,
-                                                        bl_drop_dev drop, float* __restrict__ g_table, int drop_before_pool) {
+                                                        bl_drop_dev drop, float* __restrict__ g_table, int drop_before_pool,
+                                                        int comb, const int* __restrict__ lens) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)N * H) return;
   const int n = (int)(t / H), h = (int)(t % H);
   float g = g_out[(size_t)n * ld_g + h];
+  if (comb != 0) {  // sum / mean: every slot s < len receives the (scaled) gradient
+    int len = lens[n];
+    len = len < 1 ? 1 : (len > S ? S : len);
+    if (comb == 2) g *= 1.0f / (float)len;
+    for (int s = 0; s < len; ++s) {
+      const float gs = drop.thresh ? (bl_keep(drop, embed_mask_index(n, s, h, S, H, drop_before_pool)) ? g * drop.scale : 0.f) : g;
+      if (gs != 0.f) unsafeAtomicAdd(&g_table[(size_t)ids[(size_t)n * S + s] * H + h], gs);
+    }
+    return;
+  }
   const int s = argsub[(size_t)n * H + h];
   if (drop.thresh) g = bl_keep(drop, embed_mask_index(n, s, h, S, H, drop_before_pool)) ? g * drop.scale : 0.f;
   if (g != 0.f) {
@@ -88,11 +108,22 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 // deterministic mode: thread h owns column h and walks the nodes in order (slow; the token-sorted kernel is the fast path)
 __global__ __launch_bounds__(256) void embed_bwd_serial_kernel(const float* __restrict__ g_out, int ld_g, const int* __restrict__ ids,
                                                                const int8_t* __restrict__ argsub, int N, int S, int H, bl_drop_dev drop,
-                                                               float* __restrict__ g_table, int drop_before_pool) {
+                                                               float* __restrict__ g_table, int drop_before_pool, int comb,
+                                                               const int* __restrict__ lens) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   for (int n = 0; n < N; ++n) {
     float g = g_out[(size_t)n * ld_g + h];
+    if (comb != 0) {
+      int len = lens[n];
+      len = len < 1 ? 1 : (len > S ? S : len);
+      if (comb == 2) g *= 1.0f / (float)len;
+      for (int s = 0; s < len; ++s) {
+        const float gs = drop.thresh ? (bl_keep(drop, embed_mask_index(n, s, h, S, H, drop_before_pool)) ? g * drop.scale : 0.f) : g;
+        if (gs != 0.f) g_table[(size_t)ids[(size_t)n * S + s] * H + h] += gs;
+      }
+      continue;
+    }
     const int s = argsub[(size_t)n * H + h];
     if (drop.thresh) g = bl_keep(drop, embed_mask_index(n, s, h, S, H, drop_before_pool)) ? g * drop.scale : 0.f;
     if (g != 0.f) g_table[(size_t)ids[(size_t)n * S + s] * H + h] += g;
@@ -110,7 +141,8 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
                                                                const int* __restrict__ chunk_ptr,
                                                                const int* __restrict__ chunk_tok, int nchunks,
                                                                const int8_t* __restrict__ argsub, int S, int H,
-                                                               bl_drop_dev drop, float* __restrict__ g_table, int drop_before_pool) {
+                                                               bl_drop_dev drop, float* __restrict__ g_table, int drop_before_pool,
+                                                               int comb, const int* __restrict__ lens) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= nchunks) return;
@@ -122,18 +154,24 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
     const int cnt = min(64, end - base);
     const int mine = lane < cnt ? occ[base + lane] : 0;
     for (int i0 = 0; i0 < cnt; i0 += 4) {
-      float g[4][NV];
+      float g[4][NV], inv[4];
       int a[4][NV], n[4], sl[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pos = __shfl(mine, min(i0 + u, cnt - 1), 64);
         n[u] = pos / S;
         sl[u] = i0 + u < cnt ? pos - n[u] * S : -2;  // -2 never equals an argsub value
+        inv[u] = 1.f;
+        if (comb == 2) {  // mean: the occurrence's share of its node's gradient
+          int len = lens[n[u]];
+          len = len < 1 ? 1 : (len > S ? S : len);
+          inv[u] = 1.0f / (float)len;
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           const int h = lane + 64 * j;
           g[u][j] = h < H ? g_out[(size_t)n[u] * ld_g + h] : 0.f;
-          a[u][j] = h < H ? (int)argsub[(size_t)n[u] * H + h] : -1;
+          a[u][j] = comb != 0 ? (h < H ? sl[u] : -1) : (h < H ? (int)argsub[(size_t)n[u] * H + h] : -1);  // (sum / mean: every listed slot counts)
         }
       }
 #pragma unroll
@@ -143,7 +181,7 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const float* __re
           float v = g[u][j];
           // (only the slot that won contributes, so the mask bit of (n, sl, h) is the winner's when it matters)
           if (drop.thresh) v = bl_keep(drop, embed_mask_index(n[u], sl[u] < 0 ? 0 : sl[u], lane + 64 * j, S, H, drop_before_pool)) ? v * drop.scale : 0.f;
-          if (a[u][j] == sl[u]) acc[j] += v;
+          if (a[u][j] == sl[u] && sl[u] >= 0) acc[j] += v * inv[u];
         }
     }
   }
@@ -813,49 +851,80 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restri
   else if ((D) <= 256) { constexpr int NV = 4; __VA_ARGS__; }      \
   else { constexpr int NV = 8; __VA_ARGS__; }
 
+// subtoken_combination of the node model (reference modelregistry.py:65-66: "max" unless node_representations says otherwise):
+// BL_POOL_MAX 0, BL_POOL_SUM 1, BL_POOL_MEAN 2 (sum / len).  argsub: the winners' slots, max only (NULL otherwise).
+extern "C" int bl_embed_subtoken_pool_fwd(const float* table, int32_t V, int32_t H, const int32_t* ids, const int32_t* lens, int32_t N,
+                                          int32_t S, int32_t combination, bl_dropout_t drop, int32_t drop_before_pool, float* out,
+                                          int32_t ld_out, int8_t* argsub, void* stream) {
+  const char* who = "bl_embed_subtoken_pool_fwd";
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(combination >= 0 && combination <= 2, "%s: combination must be 0 (max), 1 (sum) or 2 (mean)", who);
+  BL_CHECK_ARG(table && ids && lens && out && (argsub || combination != 0), "%s: null pointer", who);
+  BL_CHECK_ARG(H > 0 && H % 4 == 0 && ld_out % 4 == 0 && S >= 1 && S <= 127 && V > 0, "%s: H %% 4, 1 <= S <= 127", who);
+  BL_CHECK_ARG(bl_aligned16(table) && bl_aligned16(out), "%s: misaligned", who);
+  BL_CHECK_ARG(!drop_before_pool || (uint64_t)N * (uint64_t)S * (uint64_t)H < (1ull << 32), "%s: dropout index space is 32 bit", who);
+  const long long total = (long long)N * (H / 4);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, H,
+                     ids, lens, N, S, bl_make_drop(drop), out, ld_out, combination == 0 ? argsub : nullptr, drop_before_pool, combination);
+  BL_LAUNCH_CHECK(who);
+  return BL_OK;
+}
+
+extern "C" int bl_embed_subtoken_pool_bwd(const float* g_out, int32_t ld_g, const int32_t* ids, const int32_t* lens, const int8_t* argsub,
+                                          int32_t N, int32_t S, int32_t H, int32_t V, int32_t combination, bl_dropout_t drop,
+                                          int32_t drop_before_pool, float* g_table, void* stream) {
+  const char* who = "bl_embed_subtoken_pool_bwd";
+  if (N == 0) return BL_OK;
+  BL_CHECK_ARG(combination >= 0 && combination <= 2, "%s: combination must be 0 (max), 1 (sum) or 2 (mean)", who);
+  BL_CHECK_ARG(g_out && ids && g_table && V > 0 && (combination == 0 ? argsub != nullptr : lens != nullptr), "%s: null pointer", who);
+  const long long total = (long long)N * H;
+  if (bl_get_deterministic())
+    hipLaunchKernelGGL(embed_bwd_serial_kernel, dim3((H + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_out, ld_g, ids, argsub, N,
+                       S, H, bl_make_drop(drop), g_table, drop_before_pool, combination, lens);
+  else
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out,
+                       ld_g, ids, argsub, N, S, H, bl_make_drop(drop), g_table, drop_before_pool, combination, lens);
+  BL_LAUNCH_CHECK(who);
+  return BL_OK;
+}
+
+extern "C" int bl_embed_subtoken_pool_bwd_sorted(const float* g_out, int32_t ld_g, const int32_t* occ, const int32_t* chunk_ptr,
+                                                 const int32_t* chunk_tok, int32_t nchunks, const int32_t* lens, const int8_t* argsub,
+                                                 int32_t S, int32_t H, int32_t combination, bl_dropout_t drop, int32_t drop_before_pool,
+                                                 float* g_table, void* stream) {
+  const char* who = "bl_embed_subtoken_pool_bwd_sorted";
+  if (nchunks == 0) return BL_OK;
+  BL_CHECK_ARG(combination >= 0 && combination <= 2, "%s: combination must be 0 (max), 1 (sum) or 2 (mean)", who);
+  BL_CHECK_ARG(g_out && occ && chunk_ptr && chunk_tok && g_table && (combination == 0 ? argsub != nullptr : true) &&
+                   (combination == 2 ? lens != nullptr : true), "%s: null pointer", who);
+  BL_CHECK_ARG(H > 0 && H <= 512 && S >= 1 && S <= 127, "%s: H in 1..512, 1 <= S <= 127", who);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NV(H, hipLaunchKernelGGL((embed_bwd_sorted_kernel<NV>), dim3((nchunks + 3) / 4), dim3(256), 0, st, g_out, ld_g, occ,
+                                     chunk_ptr, chunk_tok, nchunks, argsub, S, H, bl_make_drop(drop), g_table, drop_before_pool,
+                                     combination, lens))
+  BL_LAUNCH_CHECK(who);
+  return BL_OK;
+}
+
+// the "max" forms SURVEY section 8b names (= combination 0)
 extern "C" int bl_embed_subtoken_max_fwd(const float* table, int32_t V, int32_t H, const int32_t* ids,
                                          const int32_t* lens, int32_t N, int32_t S, bl_dropout_t drop, int32_t drop_before_pool,
                                          float* out, int32_t ld_out, int8_t* argsub, void* stream) {
-  if (N == 0) return BL_OK;
-  BL_CHECK_ARG(table && ids && lens && out && argsub, "bl_embed_subtoken_max_fwd: null pointer");
-  BL_CHECK_ARG(H > 0 && H % 4 == 0 && ld_out % 4 == 0 && S >= 1 && S <= 127 && V > 0, "bl_embed_subtoken_max_fwd: H %% 4, 1 <= S <= 127");
-  BL_CHECK_ARG(bl_aligned16(table) && bl_aligned16(out), "bl_embed_subtoken_max_fwd: misaligned");
-  BL_CHECK_ARG(!drop_before_pool || (uint64_t)N * (uint64_t)S * (uint64_t)H < (1ull << 32), "bl_embed_subtoken_max_fwd: dropout index space is 32 bit");
-  const long long total = (long long)N * (H / 4);
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, H,
-                     ids, lens, N, S, bl_make_drop(drop), out, ld_out, argsub, drop_before_pool);
-  BL_LAUNCH_CHECK("bl_embed_subtoken_max_fwd");
-  return BL_OK;
+  return bl_embed_subtoken_pool_fwd(table, V, H, ids, lens, N, S, 0, drop, drop_before_pool, out, ld_out, argsub, stream);
 }
 
 extern "C" int bl_embed_subtoken_max_bwd(const float* g_out, int32_t ld_g, const int32_t* ids, const int8_t* argsub,
                                          int32_t N, int32_t S, int32_t H, int32_t V, bl_dropout_t drop, int32_t drop_before_pool,
                                          float* g_table, void* stream) {
-  if (N == 0) return BL_OK;
-  BL_CHECK_ARG(g_out && ids && argsub && g_table && V > 0, "bl_embed_subtoken_max_bwd: null pointer");
-  const long long total = (long long)N * H;
-  if (bl_get_deterministic())
-    hipLaunchKernelGGL(embed_bwd_serial_kernel, dim3((H + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_out, ld_g, ids, argsub, N,
-                       S, H, bl_make_drop(drop), g_table, drop_before_pool);
-  else
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out,
-                       ld_g, ids, argsub, N, S, H, bl_make_drop(drop), g_table, drop_before_pool);
-  BL_LAUNCH_CHECK("bl_embed_subtoken_max_bwd");
-  return BL_OK;
+  return bl_embed_subtoken_pool_bwd(g_out, ld_g, ids, nullptr, argsub, N, S, H, V, 0, drop, drop_before_pool, g_table, stream);
 }
 
 extern "C" int bl_embed_subtoken_max_bwd_sorted(const float* g_out, int32_t ld_g, const int32_t* occ,
                                                const int32_t* chunk_ptr, const int32_t* chunk_tok, int32_t nchunks,
                                                const int8_t* argsub, int32_t S, int32_t H, bl_dropout_t drop,
                                                int32_t drop_before_pool, float* g_table, void* stream) {
-  if (nchunks == 0) return BL_OK;
-  BL_CHECK_ARG(g_out && occ && chunk_ptr && chunk_tok && argsub && g_table, "bl_embed_subtoken_max_bwd_sorted: null pointer");
-  BL_CHECK_ARG(H > 0 && H <= 512 && S >= 1 && S <= 127, "bl_embed_subtoken_max_bwd_sorted: H in 1..512, 1 <= S <= 127");
-  hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NV(H, hipLaunchKernelGGL((embed_bwd_sorted_kernel<NV>), dim3((nchunks + 3) / 4), dim3(256), 0, st, g_out, ld_g, occ,
-                                     chunk_ptr, chunk_tok, nchunks, argsub, S, H, bl_make_drop(drop), g_table, drop_before_pool))
-  BL_LAUNCH_CHECK("bl_embed_subtoken_max_bwd_sorted");
-  return BL_OK;
+  return bl_embed_subtoken_pool_bwd_sorted(g_out, ld_g, occ, chunk_ptr, chunk_tok, nchunks, nullptr, argsub, S, H, 0, drop, drop_before_pool,
+                                           g_table, stream);
 }
 
 extern "C" int bl_segment_max_fwd(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items,

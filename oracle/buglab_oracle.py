@@ -245,7 +245,7 @@ def scatter_log_softmax(src: torch.Tensor, index: torch.Tensor, eps: float = 1e-
 # M0  node embedder  (ptgnn StrElementRepresentationModel, configured at
 #     reference modelregistry.py:59-82: subtoken splitting, <=6 subtokens, "max")
 # ----------------------------------------------------------------------------
-def embed_nodes(table, token_ids, token_lens, p_drop, seed, dropout_placement="after_pooling"):
+def embed_nodes(table, token_ids, token_lens, p_drop, seed, dropout_placement="after_pooling", subtoken_combination="max"):
     """dropout_placement "after_pooling" (default): drop(max_s emb) -- the last statement of ptgnn's SubtokenUnitEmbedder.forward as
     recollected (`return self.__dropout_layer(embedded)` after the combination); "before_pooling": max_s drop(emb) with the mask
     over the [N, S, H] embedded subtokens (a dropped element is a 0 that can win the max).  Eval-mode outputs do not depend on it."""
@@ -257,8 +257,14 @@ def embed_nodes(table, token_ids, token_lens, p_drop, seed, dropout_placement="a
         emb = apply_dropout(emb, p_drop, seed, stream=0)
     S = ids.shape[1]
     pad = torch.arange(S).view(1, S) >= lens.view(-1, 1)
-    emb = emb.masked_fill(pad.unsqueeze(-1), -math.inf)
-    h = emb.max(dim=1).values
+    assert subtoken_combination in ("max", "sum", "mean")
+    if subtoken_combination == "max":
+        emb = emb.masked_fill(pad.unsqueeze(-1), -math.inf)
+        h = emb.max(dim=1).values
+    else:  # ptgnn's other combinations as recollected: the sum over the real subtokens, / their number for "mean"
+        h = emb.masked_fill(pad.unsqueeze(-1), 0.0).sum(dim=1)
+        if subtoken_combination == "mean":
+            h = h / lens.view(-1, 1).to(h.dtype)
     return h if dropout_placement == "before_pooling" else apply_dropout(h, p_drop, seed, stream=0)
 
 

@@ -274,9 +274,11 @@ def test_rowdot_and_scatter_add(ops):
     assert (out.cpu().double() - ref).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("combination", ["max", "sum", "mean"])
 @pytest.mark.parametrize("placement", ["after_pooling", "before_pooling"])
-def test_embed_fwd_bwd(ops, placement):
-    """subtoken embedder, dropout on the pooled rows (default) or on the embedded subtokens before the max"""
+def test_embed_fwd_bwd(ops, placement, combination):
+    """subtoken embedder, dropout on the pooled rows (default) or on the embedded subtokens before the pooling (DESIGN.md section 2);
+    max (the registry's default), sum or mean over the subtokens (node_representations["subtoken_combination"])"""
     before = placement == "before_pooling"
     rng = np.random.default_rng(6)
     V, H, N, S = 97, 64, 200, 6
@@ -284,26 +286,35 @@ def test_embed_fwd_bwd(ops, placement):
     ids = rng.integers(0, V, (N, S)).astype(np.int32)
     lens = rng.integers(1, S + 1, N).astype(np.int32)
     tr = table.clone().requires_grad_(True)
-    ref = O.embed_nodes(tr, ids, lens, 0.25, 42, placement)
+    ref = O.embed_nodes(tr, ids, lens, 0.25, 42, placement, combination)
     go = torch.randn(N, H)
     ref.backward(go)
     td = _dev(table).requires_grad_(True)
-    out = ops.embed_subtoken_max(td, _dev(ids), _dev(lens), ops.Dropout(0.25, 42, 0), dropout_before_pooling=before)
+    out = ops.embed_subtoken_max(td, _dev(ids), _dev(lens), ops.Dropout(0.25, 42, 0), dropout_before_pooling=before, combination=combination)
     out.backward(_dev(go))
-    assert (out.detach().cpu() - ref.detach()).abs().max() < 1e-6
+    assert (out.detach().cpu() - ref.detach()).abs().max() < (1e-6 if combination == "max" else 1e-5)
     assert (td.grad.cpu() - tr.grad).abs().max() < 1e-4
     # token-sorted form of the gradient (collator-built occurrence chunks; a hot token spans several chunks)
     from buglab.data.collate import token_occurrence_chunks
 
     ids[: N // 2, 0] = 7
     tr2 = table.clone().requires_grad_(True)
-    O.embed_nodes(tr2, ids, lens, 0.25, 42, placement).backward(go)
+    O.embed_nodes(tr2, ids, lens, 0.25, 42, placement, combination).backward(go)
     occ, cptr, ctok = token_occurrence_chunks(ids, lens, chunk=16)
     assert (np.diff(cptr) <= 16).all() and cptr[-1] == occ.size == int(lens.sum())
     td2 = _dev(table).requires_grad_(True)
     ops.embed_subtoken_max(td2, _dev(ids), _dev(lens), ops.Dropout(0.25, 42, 0), (_dev(occ), _dev(cptr), _dev(ctok)),
-                           dropout_before_pooling=before).backward(_dev(go))
+                           dropout_before_pooling=before, combination=combination).backward(_dev(go))
     assert (td2.grad.cpu() - tr2.grad).abs().max() < 1e-4
+    # deterministic mode: the serial column walk gives the same gradient
+    ops.set_deterministic(True)
+    try:
+        td3 = _dev(table).requires_grad_(True)
+        ops.embed_subtoken_max(td3, _dev(ids), _dev(lens), ops.Dropout(0.25, 42, 0), dropout_before_pooling=before,
+                               combination=combination).backward(_dev(go))
+        assert (td3.grad.cpu() - tr2.grad).abs().max() < 1e-4
+    finally:
+        ops.set_deterministic(False)
 
 
 def test_flat_adam_matches_oracle(ops):

@@ -129,6 +129,11 @@ def test_embedder_dropout_placement_hand_checked():
     emb[1, 1:] = -np.inf  # padding slots of the one-subtoken node
     np.testing.assert_allclose(O.embed_nodes(table, ids, lens, p, seed, "before_pooling").numpy(), emb.max(axis=1))
     assert O.OracleConfig().embed_dropout_placement == "after_pooling"
+    # the other subtoken combinations (node_representations["subtoken_combination"]): sums over the REAL subtokens only
+    np.testing.assert_array_equal(O.embed_nodes(table, ids, lens, 0.5, None, "after_pooling", "sum").numpy(), [[-2.0, 0.0], [-5.0, 4.0]])
+    np.testing.assert_allclose(O.embed_nodes(table, ids, lens, 0.5, None, "after_pooling", "mean").numpy(), [[-2.0 / 3, 0.0], [-5.0, 4.0]])
+    np.testing.assert_allclose(O.embed_nodes(table, ids, lens, p, seed, "before_pooling", "sum").numpy(),
+                               np.where(np.arange(3)[None, :, None] < lens[:, None, None], table.numpy()[ids] * keep_subs / (1 - p), 0.0).sum(axis=1))
 
 
 def test_config_c1_plumbing_on_cpu_oracle():

@@ -66,3 +66,21 @@ def test_registry_builds_seq_transformer_and_seq_gru(tmp_path):
     assert len(gl) == 2 and all(l.hidden_size == 32 and l.input_size == 64 for l in gl)
     with pytest.raises(AssertionError):
         TransformerEncoderLayer(65, 4)
+
+
+def test_registry_passes_subtoken_combination_to_the_embedder(tmp_path):
+    """node_representations["subtoken_combination"] (reference modelregistry.py:65-66: "max" unless given): max / sum / mean build,
+    anything else is refused at construction."""
+    from buglab.data.synthetic import make_buglab_dataset
+    from buglab.models.layers.messagepassing import SubtokenEmbedder
+    from buglab.models.modelregistry import load_model
+
+    data = make_buglab_dataset(4, seed=2)
+    for comb in ("max", "sum", "mean"):
+        spec = {"modelName": "gnn-mlp", "hidden_state_size": 64, "node_representations": {"subtoken_combination": comb}}
+        model = load_model(spec, Path(tmp_path / f"{comb}.pkl.gz"))[0]
+        model.compute_metadata(copy.deepcopy(data))
+        emb = [m for m in model.build_neural_module().modules() if isinstance(m, SubtokenEmbedder)]
+        assert len(emb) == 1 and emb[0].subtoken_combination == comb
+    with pytest.raises(ValueError):
+        load_model({"modelName": "gnn-mlp", "node_representations": {"subtoken_combination": "median"}}, Path(tmp_path / "x.pkl.gz"))

@@ -81,6 +81,35 @@ def test_train_cli_with_amp(tmp_path):
     assert metrics["num_samples"] == 16
 
 
+@pytest.mark.parametrize("combination", ["sum", "mean"])
+def test_training_with_other_subtoken_combinations(combination):
+    """node_representations={"subtoken_combination": "sum" | "mean"} through the registry: a few optimiser steps bring the loss down"""
+    from pathlib import Path
+
+    from buglab.data.collate import to_device
+    from buglab.data.synthetic import make_buglab_dataset
+    from buglab.models.modelregistry import load_model
+    from buglab.runtime.optim import FlatAdam
+
+    data = make_buglab_dataset(8, seed=4)
+    model = load_model({"modelName": "gnn-mlp", "hidden_state_size": 64, "node_representations": {"subtoken_combination": combination}},
+                       Path(f"/tmp/_bl_comb_{combination}.pkl.gz"))[0]
+    model.compute_metadata(copy.deepcopy(data))
+    torch.manual_seed(0)
+    nn_ = model.build_neural_module().cuda().train()
+    samples = [s for s in (model.tensorize(copy.deepcopy(d)) for d in data) if s is not None]
+    mb = to_device(model.collate_minibatch({"samples": samples}), "cuda")
+    opt = FlatAdam(nn_.parameters(), lr=1e-3, num_warmup_steps=0)
+    losses = []
+    for step in range(6):
+        opt.zero_grad()
+        l = nn_(**mb, dropout_seed=step)
+        l.backward()
+        opt.step()
+        losses.append(float(l.detach()))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
 def test_trainandeval_entry_point(tmp_path, capsys):
     """reference buglab/models/trainandeval.py:1-29: train.run(args) then evaluate.run(args) from ONE argument dictionary."""
     from buglab.data.synthetic import make_buglab_dataset
