@@ -374,6 +374,8 @@ def main():
     ap.add_argument("--placement", default="aggregated", choices=["aggregated", "message"],
                     help="where the message activation (GELU) sits relative to the max aggregation: on the aggregated [N, Dm] tensor "
                          "(default: ptgnn's order as recollected, DESIGN.md section 2) or on every message before the max (rounds 1-5)")
+    ap.add_argument("--aggregation", default="max", choices=["max", "sum", "mean"],
+                    help="message aggregation: max (the reference's recipe, gnnlayerdefs.py:11,21 -- the headline) or ptgnn's sum / mean")
     ap.add_argument("--msg-gemm", default="f16x3", choices=["f16x3", "bf16x6", "f16x1"],
                     help="operand split of the message GEMMs (forward, weight gradient, routed input gradient): two fp16 planes / three MFMA "
                          "terms with power-of-two tensor scales (default, csrc/bl_gemm_h3.hip) or three bf16 planes / six terms (rounds 2-5)")
@@ -450,7 +452,8 @@ def main():
             mb_ = to_device(collate_samples(samples, a.types), device)
             # what the registry's gnn() builds: layer dropout a.dropout, node-embedder dropout 0 (reference modelregistry.py:79-82)
             module_ = build_gnn_mlp_module(a.hidden, a.layers, a.types, dropout_rate=a.dropout, dropout_base_seed=rank,
-                                           embedder_dropout_rate=0.0, message_activation_placement=a.placement).to(device).train()
+                                           embedder_dropout_rate=0.0, message_activation_placement=a.placement,
+                                           message_aggregation_function=a.aggregation).to(device).train()
         opt_ = FlatAdam(module_.parameters())
         if world > 1:
             opt_.broadcast_parameters(0)  # what the trainer does before its first step
@@ -643,6 +646,10 @@ def main():
         also["reference minibatch regime: configs[1] model, batch=15 graphs/GPU (30000 nodes: modelregistry.py:53)"] = side_config(graphs=15)
         other = "message" if args.placement == "aggregated" else "aggregated"
         also[f"configs[1] with message_activation_placement={other} (the non-default placement of the one unpinned spec point)"] = side_config(placement=other)
+        if args.aggregation == "max":
+            # BASELINE.json's north_star words the layers as "gather -> MLP -> scatter-sum"; the reference's recipe aggregates by max
+            # (gnnlayerdefs.py:11,21: the headline).  The sum form of the same model, for that wording:
+            also["configs[1] with message_aggregation_function=sum (ptgnn's other aggregation; the reference's recipe passes max)"] = side_config(aggregation="sum")
         if args.msg_gemm == "f16x3":
             also["configs[1] with the message GEMMs as bf16x6 (three bf16 planes, six MFMA terms: rounds 2-5)"] = side_config(msg_gemm="bf16x6")
             # `train.py --amp` (reference train.py:8,106): fp16 operands, one MFMA term -- REDUCED PRECISION, outside the 1e-4 parity bound, reported
@@ -687,7 +694,8 @@ def main():
                             (f"gnn-mlp hidden={args.hidden} layers={args.layers} edge_types={args.types} "
                              f"batch={args.graphs} graphs/GPU x ({args.nodes} nodes, {args.messages} msgs) dropout={args.dropout}"
                              + (" power-law in-degree (max 512)" if args.degree == "powerlaw" else "")),
-                **({} if seq else {"message_activation_placement": args.placement, "message_gemm_split": args.msg_gemm}),
+                **({} if seq else {"message_activation_placement": args.placement, "message_gemm_split": args.msg_gemm,
+                                   "message_aggregation_function": args.aggregation}),
                 "global_batch": args.graphs * world,
                 "parallelism": f"dp{world}",
                 "loss_last_step": round(last_loss, 5),

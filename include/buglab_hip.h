@@ -420,7 +420,14 @@ typedef struct {
                                    * a whole workgroup in the segmented max); < 0: unknown -- the first 4096 are looked at;
                                    * 0: no hubs -- node_order is then not read at all (the collators list the hubs first and every
                                    * other node in natural order, i.e. the identity; any order gives the same results) */
+  int32_t aggregation;            /* BL_AGG_MAX (0: the reference's recipe, gnnlayerdefs.py:11,21), BL_AGG_SUM or BL_AGG_MEAN -- ptgnn's other
+                                   * message_aggregation_function values: a_v = act(sum_{e -> v} m_e (/ in-degree)), 0 for a node without
+                                   * messages; msg_act must then be BL_ACT_GELU_AGG or BL_ACT_NONE; no winner table (winner_out untouched), every
+                                   * message receives its target's gradient in backward (unrouted GEMMs on the matrix cores) */
 } bl_mp_layer_t;
+#define BL_AGG_MAX 0
+#define BL_AGG_SUM 1
+#define BL_AGG_MEAN 2
 
 /* buffer sizes (bytes): `saved` is written by forward and read by backward; the workspace is scratch of one call.
  * backward: 0 = forward call, 1 = backward call, 2 = backward call that will take the bl_routed_dgrad_nodes_rows path (Wt

@@ -308,7 +308,8 @@ def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_
                          edge_feature_size: int = 0, edge_vocabulary_size: int = 0,
                          embedder_dropout_rate: Optional[float] = None,
                          message_activation_placement: str = "aggregated",
-                         embedder_dropout_placement: str = "after_pooling") -> GnnBugLabModule:
+                         embedder_dropout_placement: str = "after_pooling",
+                         message_aggregation_function: str = "max") -> GnnBugLabModule:
     """Device module for given hyper-parameters without a metadata pass (bench / tests / synthetic
     runs).  `GnnBugLabModel.build_neural_module()` goes through the same constructors.
     `embedder_dropout_rate`: dropout of the node embedder; None = `dropout_rate` (the oracle's single-rate
@@ -330,7 +331,8 @@ def build_gnn_mlp_module(hidden_state_size: int = 128, num_layers: int = 8, num_
     else:
         recipe = create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edge_types, features_dimension=edge_feature_size,
                                       num_layers=num_layers, message_activation=message_activation,
-                                      message_activation_placement=message_activation_placement)
+                                      message_activation_placement=message_activation_placement,
+                                      message_aggregation_function=message_aggregation_function)
     return GnnBugLabModule(GraphNeuralNetwork(embed, recipe, edge_embedder=edge_embed), rewrite_vocabulary_size,
                            buggy_samples_weight_schedule=partial(const_weight_schedule, weight=buggy_samples_weight),
                            dropout_base_seed=dropout_base_seed)

@@ -4,17 +4,18 @@ from buglab.models.layers.messagepassing import ConcatResidualLayer, GatedMessag
 
 def create_mlp_mp_layers(hidden_state_size, dropout_rate, num_edges: int, features_dimension: int = 0,
                          num_layers: int = 8, message_activation: str = "gelu",
-                         message_activation_placement: str = "aggregated"):
+                         message_activation_placement: str = "aggregated", message_aggregation_function: str = "max"):
     """Reference gnnlayerdefs.py:5-39: per block [stash, 3 x MP(H,H,H), concat, MP(2H,2H,H)]; the
     reference hard-wires two blocks (8 MP layers); `num_layers` (multiple of 4) is the knob
     BASELINE.json's 4-layer plumbing config needs and defaults to the reference's 8.  The reference passes no
     activation kwarg (gnnlayerdefs.py:6-23), so ptgnn's defaults govern: `message_activation` GELU, applied -- as public
     ptgnn is recollected, DESIGN.md section 2 -- to the AGGREGATED messages (`message_activation_placement="aggregated"`);
-    "message" applies it to every message before the max (rounds 1-5 of this repository)."""
+    "message" applies it to every message before the max (rounds 1-5 of this repository).  `message_aggregation_function`: "max" is
+    what the reference passes (:11,21); "sum" / "mean" are ptgnn's other values."""
     assert num_layers % 4 == 0 and num_layers >= 4, "num_layers must be a positive multiple of 4"
     mk = lambda din, dm: MlpMessagePassingLayer(
         input_state_dimension=din, message_dimension=dm, output_state_dimension=hidden_state_size,
-        num_edge_types=num_edges, message_aggregation_function="max", dropout_rate=dropout_rate,
+        num_edge_types=num_edges, message_aggregation_function=message_aggregation_function, dropout_rate=dropout_rate,
         features_dimension=features_dimension, message_activation=message_activation,
         message_activation_placement=message_activation_placement)
     layers = []

@@ -788,8 +788,12 @@ def _transposed_layer_weights(W: torch.Tensor) -> torch.Tensor:
     return _weight_copies.get(W, ("t",))[0]
 
 
-def _layer_desc(g: "GraphIndex", W, ln_g, ln_b, Wd, bd, Din, msg_act, drop: Dropout) -> bl_mp_layer_t:
+AGGREGATIONS = ("max", "sum", "mean")  # BL_AGG_MAX / _SUM / _MEAN (ptgnn's message_aggregation_function values)
+
+
+def _layer_desc(g: "GraphIndex", W, ln_g, ln_b, Wd, bd, Din, msg_act, drop: Dropout, agg: int = 0) -> bl_mp_layer_t:
     L = bl_mp_layer_t()
+    L.aggregation = int(agg)
     L.N, L.E, L.T, L.Din, L.Dm, L.Dout = g.num_nodes, g.num_messages, W.shape[0], Din, W.shape[2], Wd.shape[1]
     L.msg_src, L.msg_tgt, L.type_ptr = g.msg_src.data_ptr(), g.msg_tgt.data_ptr(), g.type_ptr.data_ptr()
     L.tgt_ptr, L.tgt_msgs, L.src_ptr, L.src_msgs = g.tgt_ptr.data_ptr(), g.tgt_msgs.data_ptr(), g.src_ptr.data_ptr(), g.src_msgs.data_ptr()
@@ -809,7 +813,7 @@ class _MpLayerFused(torch.autograd.Function):
     backward is one opaque byte blob (packed input, routing bitmask, LayerNorm state; layout in csrc/bl_mp_layer.hip)."""
 
     @staticmethod
-    def forward(ctx, h_lo, h_hi, W, ln_g, ln_b, Wd, bd, g: GraphIndex, msg_act: int, drop: Dropout):
+    def forward(ctx, h_lo, h_hi, W, ln_g, ln_b, Wd, bd, g: GraphIndex, msg_act: int, drop: Dropout, agg: int = 0):
         _f32(h_lo, "node states")
         lib = load_library()
         N = h_lo.shape[0]
@@ -823,11 +827,11 @@ class _MpLayerFused(torch.autograd.Function):
         # (grad mode is always off inside Function.forward: whether a backward pass will follow is in needs_input_grad)
         need_bwd = any(ctx.needs_input_grad[:7])
         # which form of W the input gradient will read: its fp32 transpose (vector-unit path) or the packed C = G . W^T form
-        use_vec = _use_vector_dgrad(lib, E, Dm, K2)
+        use_vec = agg == 0 and _use_vector_dgrad(lib, E, Dm, K2)  # (sum / mean: no routing bits -> matrix-core input gradient)
         wkn, wnk = _packed_message_weights(W, Din, need_bwd and not use_vec)
         wt = _transposed_layer_weights(W) if (need_bwd and use_vec) else None
         dev = h_lo.device
-        L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
+        L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop, agg)
         dense_x6 = DENSE_X6 and Dm % 32 == 0 and Dout % 32 == 0
         wd_kn = wd_nk = None
         if dense_x6:
@@ -836,10 +840,12 @@ class _MpLayerFused(torch.autograd.Function):
         # no backward pass will follow (predict / evaluate under no_grad): nothing is saved, the call skips every store that
         # only a backward pass reads (routing bitmask, activation derivative, aggregate, LayerNorm statistics)
         infer = not need_bwd and INFERENCE_MODE
-        saved = None if infer else torch.empty((lib.bl_mp_layer_saved_bytes(N, E, Din, Dm, msg_act),), dtype=torch.uint8, device=dev)
+        # ("mean" without an activation keeps the derivative array all the same: it carries the 1 / in-degree)
+        saved_act = ACT_GELU_AGG if (agg == 2 and msg_act == ACT_NONE) else msg_act
+        saved = None if infer else torch.empty((lib.bl_mp_layer_saved_bytes(N, E, Din, Dm, saved_act),), dtype=torch.uint8, device=dev)
         ws = torch.empty((lib.bl_mp_layer_workspace_bytes(N, E, Din, Dm, Dout, 3 if infer else 0),), dtype=torch.uint8, device=dev)
         out = torch.empty((N, Dout), dtype=torch.float32, device=dev)
-        winner = torch.empty((N, Dm), dtype=torch.int32, device=dev) if WINNER_SINK is not None else None
+        winner = torch.empty((N, Dm), dtype=torch.int32, device=dev) if (WINNER_SINK is not None and agg == 0) else None
         _check(lib.bl_mp_layer_fwd(ctypes.byref(L), h_lo.data_ptr(), h_lo.stride(0), h_lo.shape[1], _p(h_hi),
                                    h_hi.stride(0) if h_hi is not None else 0, wkn.data_ptr(), out.data_ptr(), _p(winner),
                                    _p(saved), ws.data_ptr() if (E > 0 or infer) else None, _stream()), "bl_mp_layer_fwd")
@@ -849,12 +855,12 @@ class _MpLayerFused(torch.autograd.Function):
             _note_use((W, ln_g, ln_b, Wd, bd))
         ctx.save_for_backward(out)  # (an output: never as a plain ctx attribute, see _MpLayer)
         ctx.saved = (h_lo.shape[1], h_hi.shape[1] if h_hi is not None else 0, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, wnk,
-                     dense_x6, wd_kn, wd_nk, wt)
+                     dense_x6, wd_kn, wd_nk, wt, agg)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, wnk, dense_x6, wd_kn, wd_nk, wt = _take_saved(ctx)
+        w_lo, w_hi, W, ln_g, ln_b, Wd, bd, g, msg_act, drop, saved, wnk, dense_x6, wd_kn, wd_nk, wt, agg = _take_saved(ctx)
         (out,) = ctx.saved_tensors
         lib = load_library()
         N, E = g.num_nodes, g.num_messages
@@ -862,7 +868,7 @@ class _MpLayerFused(torch.autograd.Function):
         Din, Dout = w_lo + w_hi, Wd.shape[1]
         dev = out.device
         g_out = g_out.contiguous()
-        use_vec = _use_vector_dgrad(lib, E, Dm, 2 * Din)
+        use_vec = agg == 0 and _use_vector_dgrad(lib, E, Dm, 2 * Din)
         if use_vec and wt is None:
             wt = _transposed_layer_weights(W)
         if wnk is None and not use_vec:  # forward ran without grad mode knowing a backward would follow
@@ -870,7 +876,7 @@ class _MpLayerFused(torch.autograd.Function):
         direct = [_direct_small(bd), _direct_small(ln_g), _direct_small(ln_b), _direct_grad_target(Wd), _direct_grad_target(W)]
         tgt = [d if d is not None else torch.zeros_like(p) for d, p in zip(direct, (bd, ln_g, ln_b, Wd, W))]
         g_bd, g_lng, g_lnb, g_Wd, g_W = tgt
-        L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop)
+        L = _layer_desc(g, W, ln_g, ln_b, Wd, bd, Din, msg_act, drop, agg)
         if dense_x6:  # (forward kept the LayerNorm output in packed form: backward must take the same path)
             if wd_nk is None:
                 wd_nk = pack_weights_x6(_as_groups(Wd.detach()), False)
@@ -896,7 +902,7 @@ class _MpLayerFused(torch.autograd.Function):
         ret = [None if d is not None else t for d, t in zip(direct, tgt)]
         if all(d is not None for d in direct):  # (gradients returned through autograd are not in place yet)
             _notify_backward_launched((W, ln_g, ln_b, Wd, bd))
-        return g_lo, g_hi, ret[4], ret[1], ret[2], ret[3], ret[0], None, None, None
+        return g_lo, g_hi, ret[4], ret[1], ret[2], ret[3], ret[0], None, None, None, None
 
 
 # ---- "the backward of this layer has been launched" notifications (data-parallel gradient buckets, runtime/optim.py) ----
@@ -1081,13 +1087,19 @@ def mp_layer_with_edge_features(h, W, ln_g, ln_b, Wd, bd, table, msg_feat, graph
     return _MpLayerFeat.apply(h.contiguous(), W, ln_g, ln_b, Wd, bd, table, msg_feat, graph, _ACTS[msg_act], drop)
 
 
-def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu_aggregated", drop: Dropout = NO_DROPOUT):
-    """h: the node states [N, Din], or a pair (stash, current) standing for their concatenation (ConcatResidual)."""
+def mp_layer(h, W, ln_g, ln_b, Wd, bd, graph: GraphIndex, msg_act: str = "gelu_aggregated", drop: Dropout = NO_DROPOUT,
+             aggregation: str = "max"):
+    """h: the node states [N, Din], or a pair (stash, current) standing for their concatenation (ConcatResidual).
+    aggregation: "max" (the reference's recipe, gnnlayerdefs.py:11,21) or ptgnn's "sum" / "mean" (one-call layer form only)."""
     pair = isinstance(h, (tuple, list))
     Din = sum(t.shape[1] for t in h) if pair else h.shape[1]
+    agg = AGGREGATIONS.index(aggregation)
     if fused_layer_ok(Din, W.shape[2]) and (not pair or h[0].shape[1] % 32 == 0):
         lo, hi = (h[0].contiguous(), h[1].contiguous()) if pair else (h.contiguous(), None)
-        return _MpLayerFused.apply(lo, hi, W, ln_g, ln_b, Wd, bd, graph, _ACTS[msg_act], drop)
+        return _MpLayerFused.apply(lo, hi, W, ln_g, ln_b, Wd, bd, graph, _ACTS[msg_act], drop, agg)
+    if agg != 0:
+        raise NotImplementedError("sum / mean message aggregation runs in the one-call layer form only (state and message widths multiples of "
+                                  "32, message width <= 512, FUSED_LAYER on)")
     if pair:
         h = torch.cat(list(h), dim=-1)
     return _MpLayer.apply(h.contiguous(), W, ln_g, ln_b, Wd, bd, graph, _ACTS[msg_act], drop)

@@ -50,7 +50,7 @@ class bl_mp_layer_t(Structure):
                 ("src_ptr", c_void_p), ("src_msgs", c_void_p), ("node_order", c_void_p),
                 ("W", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p), ("Wd", c_void_p), ("bd", c_void_p),
                 ("msg_act", c_int32), ("ln_eps", c_float), ("drop", bl_dropout_t), ("Wt", c_void_p),
-                ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p), ("num_hub_slots", c_int32)]
+                ("Wd_packed", c_void_p), ("Wd_packed_bwd", c_void_p), ("num_hub_slots", c_int32), ("aggregation", c_int32)]
 
 
 class bl_x6_epi_t(Structure):

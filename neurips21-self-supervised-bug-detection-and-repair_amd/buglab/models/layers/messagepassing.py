@@ -103,8 +103,14 @@ class MlpMessagePassingLayer(nn.Module):
                  message_activation_placement: str = "aggregated"):
         super().__init__()
         hip_ops.message_activation_code(message_activation, message_activation_placement)  # validates both
-        if message_aggregation_function != "max":
-            raise NotImplementedError("the HIP path implements the reference's `max` aggregation (gnnlayerdefs.py:11,21)")
+        # "max" is what the reference's recipe passes (gnnlayerdefs.py:11,21); ptgnn's "sum" / "mean" run in the one-call layer form
+        # with the activation on the aggregate (or none) and without edge features
+        if message_aggregation_function not in hip_ops.AGGREGATIONS:
+            raise ValueError(f"message_aggregation_function must be one of {hip_ops.AGGREGATIONS} (got {message_aggregation_function!r})")
+        if message_aggregation_function != "max" and (features_dimension > 0 or (message_activation == "gelu" and message_activation_placement == "message")):
+            raise NotImplementedError("sum / mean aggregation: without edge features, message activation on the aggregate or none "
+                                      "(a per-message activation would need the [E, Dm] messages again in backward)")
+        self.message_aggregation_function = message_aggregation_function
         din, dm, dout, T = input_state_dimension, message_dimension, output_state_dimension, num_edge_types
         _check_message_width(dm, "MlpMessagePassingLayer")
         self.input_state_dimension, self.message_dimension, self.output_state_dimension = din, dm, dout
@@ -129,7 +135,8 @@ class MlpMessagePassingLayer(nn.Module):
             table, msg_feat = edge_features
             return hip_ops.mp_layer_with_edge_features(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, table, msg_feat,
                                                        graph, self._msg_act(), drop)
-        return hip_ops.mp_layer(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, graph, self._msg_act(), drop)
+        return hip_ops.mp_layer(node_states, self.W, self.ln_g, self.ln_b, self.Wd, self.bd, graph, self._msg_act(), drop,
+                                aggregation=getattr(self, "message_aggregation_function", "max"))  # (older pickles: max)
 
 
 class GatedMessagePassingLayer(nn.Module):

@@ -48,10 +48,13 @@ def gnn(*, mp_layer, add_self_edge: bool, use_all_gnn_layer_outputs: bool = Fals
         selector_loss_type="classify-max-loss", stop_extending_minibatch_after_num_nodes: int = 30000,
         max_nodes_per_graph: int = 35000, buggy_samples_weight_spec: Union[str, int, float] = 1.0,
         edge_feature_size: int = 0, num_layers: Optional[int] = None, message_activation: Optional[str] = None,
-        message_activation_placement: Optional[str] = None, add_backwards_edges: bool = True, **kwargs):
+        message_activation_placement: Optional[str] = None, add_backwards_edges: bool = True,
+        message_aggregation_function: Optional[str] = None, **kwargs):
     """reference :44-94.  Extra knobs entering through the same kwargs dict:
     `num_layers` (multiple of 4, default the reference's 8), `message_activation`, `message_activation_placement`
-    ("aggregated" -- default, ptgnn's order as recollected -- or "message"), `add_backwards_edges`."""
+    ("aggregated" -- default, ptgnn's order as recollected -- or "message"), `add_backwards_edges`,
+    `message_aggregation_function` ("max" -- what the reference's recipe passes, gnnlayerdefs.py:11,21 -- or ptgnn's "sum" / "mean";
+    gnn-mlp only)."""
     node_representations = dict(node_representations or {})
     node_representations.setdefault("token_splitting", "subtoken")
     node_representations.setdefault("max_num_subtokens", 6)
@@ -69,6 +72,10 @@ def gnn(*, mp_layer, add_self_edge: bool, use_all_gnn_layer_outputs: bool = Fals
         extra["message_activation"] = message_activation
     if message_activation_placement is not None:
         extra["message_activation_placement"] = message_activation_placement
+    if message_aggregation_function is not None and message_aggregation_function != "max":
+        if mp_layer is not create_mlp_mp_layers:
+            raise NotImplementedError("sum / mean aggregation is implemented for the gnn-mlp layers (MlpMessagePassingLayer)")
+        extra["message_aggregation_function"] = message_aggregation_function
     return GnnBugLabModel(
         GraphNeuralNetworkModel(
             # reference :79-82: the node embedder gets NO dropout_rate from gnn() -- only what `node_representations` carries,

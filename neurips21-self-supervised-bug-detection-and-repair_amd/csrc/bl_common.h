@@ -24,6 +24,9 @@ int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr,
                             int32_t act, float* out, int32_t* arg, const float* ln_g, const float* ln_b, float eps, float* ln_out,
                             float* mean, float* rstd, float* dact, uint32_t* winbits, const int32_t* seg_order,
                             uint16_t* ln_out_packed, int32_t num_hub_slots, void* stream);
+int bl_segment_sum_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg, int32_t D,
+                            int32_t act, int32_t mean_agg, float* out, const float* ln_g, const float* ln_b, float eps, float* ln_out,
+                            float* mean, float* rstd, float* dact, const int32_t* seg_order, uint16_t* ln_out_packed, void* stream);
 int bl_act_bwd_impl(const float* g_y, const float* y, int32_t nrows, int32_t N, int32_t ld, int32_t act, bl_dropout_t drop,
                     float* g_z, float* g_bias, uint16_t* g_z_packed, void* stream);
 int bl_mp_scatter_src_accum_impl(const float* g_src, int32_t ld_src, const int32_t* src_ptr, const int32_t* src_msgs, int32_t N,

@@ -302,7 +302,8 @@ __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int l
                                               int* __restrict__ arg, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                               float eps, float* __restrict__ ln_out, float* __restrict__ mean_out,
                                               float* __restrict__ rstd_out, float* __restrict__ dact,
-                                              uint32_t* __restrict__ ln_out_packed) {
+                                              uint32_t* __restrict__ ln_out_packed, float dscale = 1.f) {
+  // dscale: d aggregate / d (item sum) of the "mean" aggregation (1 / items; segment_sum_kernel), folded into dact
   const int lane = threadIdx.x & 63;
   float s = 0.f;
 #pragma unroll
@@ -333,7 +334,7 @@ __device__ __forceinline__ void segmax_finish(const float* __restrict__ x, int l
           else
             dv = barg[j] >= 0 ? bl_gelu_grad(x[(size_t)barg[j] * ldx + d]) : 0.f;
         }
-        dact[(size_t)seg * D + d] = dv;
+        dact[(size_t)seg * D + d] = dv * dscale;
       }
     }
   }
@@ -466,6 +467,63 @@ __global__ __launch_bounds__(256) void segment_max_kernel(SEGMAX_PARAMS) {
   }
   segmax_finish<NV, HAS_LN, GELU2>(x, ldx, seg, D, act, best, barg, raw, werf, out, arg, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
                                    ln_out_packed);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "sum" / "mean" aggregation (ptgnn's other message_aggregation_function values; the reference's recipe passes "max",
+// gnnlayerdefs.py:11,21): a_v = sum_{e -> v} m_e (/ number of items for "mean"; 0 for an empty segment, like torch_scatter),
+// then the same epilogue as the max: activation ON THE AGGREGATE (BL_ACT_GELU_AGG) or none, its derivative, LayerNorm (+ packed
+// copy).  One wave per segment, items summed in CSR order (a fixed order: bit-reproducible).  No winner table and no routing
+// bits: every message receives its target's gradient (x dact, which carries the 1 / items of "mean").
+template <int NV, bool HAS_LN>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ seg_ptr,
+                                                          const int* __restrict__ seg_items, int nseg, int D, int act, int mean_agg,
+                                                          float* __restrict__ out, const float* __restrict__ ln_g,
+                                                          const float* __restrict__ ln_b, float eps, float* __restrict__ ln_out,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          float* __restrict__ dact, const int* __restrict__ seg_order,
+                                                          uint32_t* __restrict__ ln_out_packed) {
+  constexpr int U = NV <= 4 ? 8 : 4;
+  const int lane = threadIdx.x & 63;
+  const int slot = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= nseg) return;
+  const int seg = seg_order ? seg_order[slot] : slot;
+  const int beg = seg_ptr[seg], end = seg_ptr[seg + 1];
+  float best[NV], raw[NV], werf[NV];
+  int barg[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { best[j] = 0.f; raw[j] = 0.f; werf[j] = 0.f; barg[j] = (end > beg && lane + 64 * j < D) ? 0 : -1; }
+  for (int base = beg; base < end; base += 64) {
+    const int cnt = min(64, end - base);
+    const int mine = lane < cnt ? (seg_items ? seg_items[base + lane] : base + lane) : 0;
+    for (int i = 0; i < cnt; i += U) {
+      float v[U][NV];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = __shfl(mine, min(i + u, cnt - 1), 64);
+        const float* __restrict__ row = x + (size_t)e * ldx;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int d = lane + 64 * j;
+          v[u][j] = d < D ? row[d] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (i + u >= cnt) break;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NV; ++j) best[j] += v[u][j];
+      }
+    }
+  }
+  float dscale = 1.f;
+  if (mean_agg && end > beg) {
+    dscale = 1.0f / (float)(end - beg);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) best[j] *= dscale;
+  }
+  segmax_finish<NV, HAS_LN, false>(x, ldx, seg, D, act, best, barg, raw, werf, out, nullptr, ln_g, ln_b, eps, ln_out, mean_out, rstd_out, dact,
+                                   ln_out_packed, dscale);
 }
 
 // backward of the segmented max in gather form: each item row looks up its segment's argmax
@@ -969,6 +1027,32 @@ int bl_segment_max_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr,
     if (act == BL_ACT_GELU) SEGMAX_GO(false, true) else SEGMAX_GO(false, false)
   }
   BL_LAUNCH_CHECK("bl_segment_max_fwd");
+  return BL_OK;
+}
+
+// segmented sum / mean + activation on the aggregate + LayerNorm (the fused layer's "sum" / "mean" aggregation): segment_sum_kernel
+int bl_segment_sum_fwd_impl(const float* x, int32_t ldx, const int32_t* seg_ptr, const int32_t* seg_items, int32_t nseg, int32_t D,
+                            int32_t act, int32_t mean_agg, float* out, const float* ln_g, const float* ln_b, float eps, float* ln_out,
+                            float* mean, float* rstd, float* dact, const int32_t* seg_order, uint16_t* ln_out_packed, void* stream) {
+  if (nseg == 0) return BL_OK;
+  BL_CHECK_ARG(seg_ptr && (out || ln_g), "bl_segment_sum_fwd: null pointer");
+  BL_CHECK_ARG(D > 0 && D <= 512, "bl_segment_sum_fwd: D must be in 1..512 (got %d)", D);
+  BL_CHECK_ARG(act == BL_ACT_NONE || act == BL_ACT_GELU_AGG, "bl_segment_sum_fwd: the activation sits on the aggregate (GELU_AGG) or is absent");
+  const bool has_ln = ln_g != nullptr;
+  BL_CHECK_ARG(!has_ln || (ln_b && (ln_out || ln_out_packed) && (mean == nullptr) == (rstd == nullptr)), "bl_segment_sum_fwd: LayerNorm outputs missing");
+  BL_CHECK_ARG(ln_out_packed == nullptr || (has_ln && D % 8 == 0), "bl_segment_sum_fwd: the packed LayerNorm output needs D %% 8 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* lnp = reinterpret_cast<uint32_t*>(ln_out_packed);
+  dim3 grid((nseg + 3) / 4), block(256);
+  DISPATCH_NV(D, {
+    if (has_ln)
+      hipLaunchKernelGGL((segment_sum_kernel<NV, true>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, act, mean_agg, out, ln_g, ln_b,
+                         eps, ln_out, mean, rstd, dact, seg_order, lnp);
+    else
+      hipLaunchKernelGGL((segment_sum_kernel<NV, false>), grid, block, 0, st, x, ldx, seg_ptr, seg_items, nseg, D, act, mean_agg, out, ln_g, ln_b,
+                         eps, ln_out, mean, rstd, dact, seg_order, lnp);
+  })
+  BL_LAUNCH_CHECK("bl_segment_sum_fwd");
   return BL_OK;
 }
 

@@ -226,6 +226,10 @@ SideEvents* ensure_events() {
   return &e;
 }
 
+inline int saved_act_code(const bl_mp_layer_t* L) {
+  return (L->aggregation == BL_AGG_MEAN && L->msg_act == BL_ACT_NONE) ? BL_ACT_GELU_AGG : L->msg_act;
+}
+
 int check_layer(const bl_mp_layer_t* L, const char* who) {
   BL_CHECK_ARG(L && L->N > 0 && L->E >= 0 && L->T > 0, "%s: bad sizes", who);
   BL_CHECK_ARG(L->Din % 32 == 0 && L->Dm % 32 == 0 && L->Dout % 4 == 0 && L->Din > 0 && L->Dm > 0 && L->Dm <= 512 && L->Dout > 0,
@@ -236,6 +240,10 @@ int check_layer(const bl_mp_layer_t* L, const char* who) {
   BL_CHECK_ARG(L->W && L->ln_g && L->ln_b && L->Wd && L->bd, "%s: null parameter", who);
   BL_CHECK_ARG(L->msg_act == BL_ACT_NONE || L->msg_act == BL_ACT_GELU || L->msg_act == BL_ACT_GELU_AGG,
                "%s: message activation must be none, gelu (per message) or gelu_agg (on the aggregate)", who);
+  BL_CHECK_ARG(L->aggregation >= BL_AGG_MAX && L->aggregation <= BL_AGG_MEAN, "%s: aggregation must be BL_AGG_MAX, BL_AGG_SUM or BL_AGG_MEAN", who);
+  BL_CHECK_ARG(L->aggregation == BL_AGG_MAX || L->msg_act != BL_ACT_GELU,
+               "%s: sum / mean aggregation takes the activation on the aggregate (BL_ACT_GELU_AGG) or none: a per-message activation would need "
+               "the [E, Dm] messages again in backward", who);
   return BL_OK;
 }
 }  // namespace
@@ -303,7 +311,8 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
   // node_order lists the hubs first and the other nodes in natural order: without hubs it is the identity, and the per-node
   // kernels skip the load (one dependent round trip less per wave)
   const int32_t* node_order = L->num_hub_slots == 0 ? nullptr : L->node_order;
-  Saved S = carve_saved(saved, N, E, Din, Dm, L->msg_act);
+  // ("mean" without an activation still needs the [N, Dm] derivative array: it carries the 1 / in-degree)
+  Saved S = carve_saved(saved, N, E, Din, Dm, saved_act_code(L));
   float* pre = (float*)ws;
   if (infer) {
     const WsInfer I = carve_infer(ws, N, E, Din, Dm);
@@ -350,6 +359,11 @@ extern "C" int bl_mp_layer_fwd(const bl_mp_layer_t* L, const float* h_lo, int32_
   {
     ProfScope ps(2, 0.0, st, false);
     // (E == 0: every segment is empty and the kernel never dereferences `pre`)
+    if (L->aggregation != BL_AGG_MAX)  // ptgnn's "sum" / "mean" (no winners: winner_out is left untouched)
+      BL_TRY(bl_segment_sum_fwd_impl(pre, Dm, L->tgt_ptr, L->tgt_msgs, N, Dm, L->msg_act, L->aggregation == BL_AGG_MEAN, S.agg, L->ln_g, L->ln_b,
+                                     L->ln_eps, dense_x6 ? nullptr : S.ln_out, S.mean, S.rstd, S.dact, node_order,
+                                     dense_x6 ? (uint16_t*)S.ln_out : nullptr, st));
+    else
     BL_TRY(bl_segment_max_fwd_impl(pre, Dm, L->tgt_ptr, L->tgt_msgs, N, Dm, L->msg_act, S.agg, winner_out, L->ln_g, L->ln_b,
                                    L->ln_eps, dense_x6 ? nullptr : S.ln_out, S.mean, S.rstd, S.dact, S.bits, node_order,
                                    dense_x6 ? (uint16_t*)S.ln_out : nullptr, L->num_hub_slots, st));
@@ -387,10 +401,11 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
   const bool two = side != st;
   SideEvents* ev = two ? ensure_events() : nullptr;
   if (two) BL_CHECK_ARG(ev != nullptr, "bl_mp_layer_bwd: cannot create HIP events");
-  Saved S = carve_saved(const_cast<void*>(saved), N, E, Din, Dm, L->msg_act);
+  Saved S = carve_saved(const_cast<void*>(saved), N, E, Din, Dm, saved_act_code(L));
+  const uint32_t* bits = L->aggregation == BL_AGG_MAX ? S.bits : nullptr;  // sum / mean: every message receives its target's gradient
   // the input gradient from the non-zeros of the routed message gradient (vector units) when the caller supplied W^T and
   // W[t]^T fits one LDS block; node sums fused in (atomics) unless the deterministic mode asks for a fixed summation order
-  const bool vec_dgrad = L->Wt != nullptr && E > 0 && bl_routed_dgrad_vec_ok(Dm, 2 * Din);
+  const bool vec_dgrad = L->Wt != nullptr && E > 0 && bl_routed_dgrad_vec_ok(Dm, 2 * Din) && L->aggregation == BL_AGG_MAX;
   const bool fused_sums = vec_dgrad && !bl_get_deterministic();
   WsBwd B = carve_bwd(ws, N, E, Din, Dm, Dout, !fused_sums);
 
@@ -467,12 +482,15 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
     }
     if (h3) {
       ProfScope ps(14, 2.0 * E * (2.0 * Din) * Dm, side, two);
-      BL_TRY(bl_gemm_wgrad_h3(&a, B.gqp, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, nullptr, T, E, Dm, 2 * Din, 1.0f / BL_H3_ROW_SCALE, B.amax,
+      BL_TRY(bl_gemm_wgrad_h3(&a, B.gqp, L->msg_tgt, bits, Dm / 32, L->type_ptr, nullptr, T, E, Dm, 2 * Din, 1.0f / BL_H3_ROW_SCALE, B.amax,
                               g_W, (int64_t)2 * Din * Dm, Dm, side));
     } else {
       ProfScope ps(8, 2.0 * E * (2.0 * Din) * Dm, side, two);
-      BL_TRY(bl_gemm_wgrad_routed_x6(&a, B.gqp, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, nullptr, T, E, Dm, 2 * Din, g_W,
-                                     (int64_t)2 * Din * Dm, Dm, side));
+      if (bits)
+        BL_TRY(bl_gemm_wgrad_routed_x6(&a, B.gqp, L->msg_tgt, bits, Dm / 32, L->type_ptr, nullptr, T, E, Dm, 2 * Din, g_W,
+                                       (int64_t)2 * Din * Dm, Dm, side));
+      else
+        BL_TRY(bl_gemm_wgrad_x6(&a, B.gqp, L->msg_tgt, L->type_ptr, nullptr, T, E, Dm, 2 * Din, g_W, (int64_t)2 * Din * Dm, Dm, side));
     }
     bl_rows_packed_t g;
     g.xp[0] = B.gqp; g.xp[1] = g.xp[2] = nullptr; g.idx[0] = L->msg_tgt; g.idx[1] = g.idx[2] = nullptr;
@@ -500,15 +518,15 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
       BL_TRY(bl_routed_dgrad_vec(B.g_ln, Dm, L->msg_tgt, S.bits, Dm / 32, L->type_ptr, T, L->Wt, E, Dm, 2 * Din, B.g_a, 2 * Din, st));
     } else if (h3) {
       ProfScope ps(15, 2.0 * E * (2.0 * Din) * Dm, st, two);
-      BL_TRY(bl_gemm_rows_h3(&g, S.bits, Dm / 32, w_packed_bwd, bl_packed_weight_elems_h3(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E, 2 * Din,
+      BL_TRY(bl_gemm_rows_h3(&g, bits, Dm / 32, w_packed_bwd, bl_packed_weight_elems_h3(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E, 2 * Din,
                              Dm, 1.0f / BL_H3_W_SCALE, B.amax, B.g_a, 2 * Din, st));
     } else {
       ProfScope ps(9, 2.0 * E * (2.0 * Din) * Dm, st, two);
       if (bl_mp_layer_weight_image(Din, Dm, 1))
-        BL_TRY(bl_gemm_rows_x6w(&g, S.bits, Dm / 32, w_packed_bwd, bl_packed_weight_elems_x6w(1, Dm, 2 * Din), L->type_ptr, nullptr, T,
+        BL_TRY(bl_gemm_rows_x6w(&g, bits, Dm / 32, w_packed_bwd, bl_packed_weight_elems_x6w(1, Dm, 2 * Din), L->type_ptr, nullptr, T,
                                 E, 2 * Din, Dm, B.g_a, 2 * Din, st));
       else
-        BL_TRY(bl_gemm_rows_x6(&g, S.bits, Dm / 32, w_packed_bwd, (int64_t)packed_w_elems(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E,
+        BL_TRY(bl_gemm_rows_x6(&g, bits, Dm / 32, w_packed_bwd, (int64_t)packed_w_elems(1, Dm, 2 * Din), L->type_ptr, nullptr, T, E,
                                2 * Din, Dm, B.g_a, 2 * Din, st));
     }
   }

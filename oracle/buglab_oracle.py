@@ -132,6 +132,7 @@ class OracleConfig:
     dropout: float = 0.0
     msg_act: str = "gelu"
     msg_act_placement: str = "aggregated"  # see MpSpec
+    msg_aggregation: str = "max"  # "max" (the reference's recipe, gnnlayerdefs.py:11,21) or ptgnn's "sum" / "mean" (activation on the aggregate)
     embed_dropout_placement: str = "after_pooling"  # or "before_pooling": see embed_nodes
     buggy_samples_weight: float = 1.0
     abstain_weight: float = 0.0  # LocalizationModule(abstain_weight=...), localizationmodule.py:15,95-100
@@ -276,7 +277,7 @@ def _gelu(x):
 # M1-M3  one MlpMessagePassingLayer (spec: MpSpec)
 # ----------------------------------------------------------------------------
 def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_drop, seed, stream, trace=None, force_arg=None,
-             feat=None, msg_act_placement="aggregated"):
+             feat=None, msg_act_placement="aggregated", aggregation="max"):
     """feat: [E, F] per-message edge-feature embeddings (message order), or None.
     msg_act_placement: where the message activation sits relative to the max (MpSpec)."""
     assert msg_act in ("gelu", "none") and msg_act_placement in ("aggregated", "message")
@@ -293,7 +294,17 @@ def mp_layer(h, W, ln_g, ln_b, Wd, bd, msg_src, msg_tgt, type_ptr, msg_act, p_dr
         msgs.append(a @ W[t])
     pre = torch.cat(msgs, dim=0) if msgs else h.new_zeros((0, W.shape[2]))
     m = _gelu(pre) if act_before else pre  # the values the max compares
-    agg, arg = scatter_max_with_arg(m, tgt, N)
+    assert aggregation in ("max", "sum", "mean")
+    if aggregation != "max":
+        # ptgnn's other aggregations (torch_scatter sum / mean: 0 for a node without messages); the activation on the aggregate or none
+        assert not act_before and force_arg is None
+        agg = torch.zeros((N, m.shape[1]), dtype=m.dtype).index_add_(0, tgt, m)
+        if aggregation == "mean":
+            deg = torch.zeros(N, dtype=m.dtype).index_add_(0, tgt, torch.ones(tgt.shape[0], dtype=m.dtype))
+            agg = agg / deg.clamp(min=1.0).unsqueeze(1)
+        arg = None
+    else:
+        agg, arg = scatter_max_with_arg(m, tgt, N)
     if force_arg is not None:
         # routing injected by a test: take the given message per (node, channel) instead of this layer's own
         # arg-max (value and gradient follow that message; E marks an empty segment -> 0)
@@ -374,6 +385,7 @@ def gnn_forward(params, gd, cfg: OracleConfig, seed=None, trace=None, force_arg=
                 force_arg=None if force_arg is None else force_arg[li],
                 feat=feat,
                 msg_act_placement=cfg.msg_act_placement,
+                aggregation=cfg.msg_aggregation,
             )
         if op[0] in ("gg", "mp"):
             all_states.append(h)

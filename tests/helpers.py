@@ -57,7 +57,8 @@ def build_module_like(cfg, params=None, device="cuda"):
                              cfg.rewrite_vocab_size, cfg.dropout, cfg.msg_act, cfg.buggy_samples_weight, model=cfg.model,
                              edge_feature_size=cfg.edge_feature_size, edge_vocabulary_size=cfg.edge_vocab_size,
                              message_activation_placement=cfg.msg_act_placement,
-                             embedder_dropout_placement=cfg.embed_dropout_placement).to(device)
+                             embedder_dropout_placement=cfg.embed_dropout_placement,
+                             message_aggregation_function=getattr(cfg, "msg_aggregation", "max")).to(device)
     if params is not None:
         load_oracle_params(m, params)
     return m

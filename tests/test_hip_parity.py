@@ -298,6 +298,26 @@ def test_training_trajectories_of_the_two_message_gemm_splits_agree():
     assert hip_ops.h3_saturation_events(reset=True) == 0
 
 
+@pytest.mark.parametrize("split", ["f16x3", "bf16x6"])
+@pytest.mark.parametrize("msg_act", ["gelu", "none"])
+@pytest.mark.parametrize("aggregation", ["sum", "mean"])
+def test_sum_and_mean_aggregation_match_the_oracle(aggregation, msg_act, split):
+    """ptgnn's other message_aggregation_function values (the reference's recipe passes "max", gnnlayerdefs.py:11,21): segmented sum /
+    mean with the activation on the aggregate, unrouted gradient GEMMs on the matrix cores -- loss, states and every gradient against
+    the oracle at the usual 1e-4, in both operand splits, with empty segments (nodes without messages) and a power-law hub."""
+    from buglab.models import hip_ops
+
+    prev = hip_ops.set_msg_gemm_mode(split)
+    try:
+        cfg, _, mb = Hh.make_case(B=3, n=150, E=800, T=16, H=128, layers=8, C=10, seed=3, msg_act=msg_act, msg_aggregation=aggregation)
+        _check_against_oracle(cfg, mb)
+        cfg, _, mb = Hh.make_case(B=2, n=120, E=900, T=5, H=64, layers=4, seed=9, degree="powerlaw", max_degree=200, msg_act=msg_act,
+                                  msg_aggregation=aggregation, dropout=0.2)
+        _check_against_oracle(cfg, mb, seed=77)
+    finally:
+        hip_ops.set_msg_gemm_mode(prev)
+
+
 def test_amp_mode_is_fp16_accurate_and_trains():
     """`train.py --amp` (reference train.py:8,106) = message GEMMs with fp16 operands, one MFMA term, fp32 accumulation
     (hip_ops.set_msg_gemm_mode('f16x1')).  Against the fp32 oracle: the loss within 2e-2 (fp16's 2^-11 operand rounding through

@@ -112,6 +112,25 @@ def test_message_activation_placement_hand_checked():
     assert O.OracleConfig().msg_act_placement == "aggregated" and O.MpSpec(1, 1, 1).msg_act_placement == "aggregated"
 
 
+def test_sum_and_mean_aggregation_hand_checked():
+    """ptgnn's other message_aggregation_function values in the oracle: with identity-like weights the aggregate of a node is the plain
+    sum (mean) of its incoming messages, a node without messages gets 0, and "max" is untouched by the new argument."""
+    h = torch.tensor([[1.0, 2.0], [3.0, -4.0], [5.0, 6.0]])
+    W = torch.zeros(1, 4, 2)
+    W[0, 0, 0] = W[0, 1, 1] = 1.0  # message = h[src]
+    src, tgt, tp = np.array([0, 1, 2]), np.array([2, 2, 0]), np.array([0, 3])
+    ln_g, ln_b, Wd, bd = torch.ones(2), torch.zeros(2), torch.eye(2), torch.zeros(2)
+    out = {}
+    for agg in ("max", "sum", "mean"):
+        tr = []
+        O.mp_layer(h, W, ln_g, ln_b, Wd, bd, src, tgt, tp, "none", 0.0, None, 1, trace=tr, aggregation=agg)
+        out[agg] = tr[0]["agg"].numpy()
+    np.testing.assert_array_equal(out["max"], [[5.0, 6.0], [0.0, 0.0], [3.0, 2.0]])
+    np.testing.assert_array_equal(out["sum"], [[5.0, 6.0], [0.0, 0.0], [4.0, -2.0]])
+    np.testing.assert_array_equal(out["mean"], [[5.0, 6.0], [0.0, 0.0], [2.0, -1.0]])
+    assert O.OracleConfig().msg_aggregation == "max"
+
+
 def test_embedder_dropout_placement_hand_checked():
     """Dropout of the subtoken embedder before or after the max over subtokens (oracle.embed_nodes): with every subtoken of a node
     kept the two placements give the same values; a dropped winner lets another subtoken (or the 0 of a dropped one) win only

@@ -84,3 +84,27 @@ def test_registry_passes_subtoken_combination_to_the_embedder(tmp_path):
         assert len(emb) == 1 and emb[0].subtoken_combination == comb
     with pytest.raises(ValueError):
         load_model({"modelName": "gnn-mlp", "node_representations": {"subtoken_combination": "median"}}, Path(tmp_path / "x.pkl.gz"))
+
+
+def test_registry_passes_the_aggregation_function_to_the_layers(tmp_path):
+    """`message_aggregation_function` in the model spec reaches every MlpMessagePassingLayer; combinations the HIP path does not run
+    are refused at construction, not at the first step."""
+    from buglab.data.synthetic import make_buglab_dataset
+    from buglab.models.layers.messagepassing import MlpMessagePassingLayer
+    from buglab.models.modelregistry import load_model
+
+    data = make_buglab_dataset(4, seed=2)
+    for agg in ("max", "sum", "mean"):
+        model = load_model({"modelName": "gnn-mlp", "hidden_state_size": 64, "message_aggregation_function": agg}, Path(tmp_path / f"{agg}.pkl.gz"))[0]
+        model.compute_metadata(copy.deepcopy(data))
+        layers = [m for m in model.build_neural_module().modules() if isinstance(m, MlpMessagePassingLayer)]
+        assert len(layers) == 8 and all(l.message_aggregation_function == agg for l in layers)
+    bad = load_model({"modelName": "gnn-mlp", "hidden_state_size": 64, "message_aggregation_function": "sum",
+                      "message_activation_placement": "message"}, Path(tmp_path / "bad.pkl.gz"))[0]
+    bad.compute_metadata(copy.deepcopy(data))
+    with pytest.raises(NotImplementedError):
+        bad.build_neural_module()
+    with pytest.raises(NotImplementedError):
+        load_model({"modelName": "ggnn", "message_aggregation_function": "sum"}, Path(tmp_path / "g.pkl.gz"))
+    with pytest.raises(ValueError):
+        MlpMessagePassingLayer(64, 64, 64, 4, message_aggregation_function="median")
