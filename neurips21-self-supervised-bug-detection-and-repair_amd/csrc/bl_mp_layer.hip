@@ -16,6 +16,8 @@
 // HIP events per device (created once) used to fork / join the side stream.
 #include <vector>
 
+#include <string.h>
+
 #include "bl_common.h"
 
 // ---- per-kernel timing ----------------------------------------------------------------------------
@@ -202,7 +204,7 @@ int g_msg_h3 = -1;
 bool msg_h3() {
   if (g_msg_h3 < 0) {
     const char* e = getenv("BL_MSG_GEMM");
-    g_msg_h3 = (e && (e[0] == 'x' || e[0] == 'b')) ? 0 : ((e && (e[0] == 'a' || (e[0] == 'f' && e[4] == '1'))) ? 2 : 1);  // "x6" / "bf16x6" -> 0; "amp" / "f16x1" -> 2; default f16x3
+    g_msg_h3 = (e && (e[0] == 'x' || e[0] == 'b')) ? 0 : ((e && (strcmp(e, "amp") == 0 || strcmp(e, "f16x1") == 0)) ? 2 : 1);  // "x6" / "bf16x6" -> 0; "amp" / "f16x1" -> 2; default f16x3
     g_h3_one_term = g_msg_h3 == 2;
   }
   return g_msg_h3 >= 1;

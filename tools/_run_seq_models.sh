@@ -10,4 +10,3 @@ for m in seq-transformer seq-gru; do
   [ -n "$f" ] && head -25 "$f" > $O/${TAG}_bench_${m}_kernel_stats.csv
   rm -rf $O/${TAG}_prof_${m}
 done
-python -m pytest tests/test_seq_great_gpu.py -x -q -k "accumulate and (transformer or gru)" 2>&1 | tail -3
