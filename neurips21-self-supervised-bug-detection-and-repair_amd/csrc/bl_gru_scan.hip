@@ -7,8 +7,8 @@
 // Split of the work: the input projections of all time steps and both directions, gi = x W_ih + b_ih [B L, 2 x 3 Hh], are one MFMA
 // row GEMM outside (and so are their gradients); what is left is sequential in t and tiny per step -- gh = h W_hh + b_hh (Hh x 3 Hh
 // MACs per sequence) and the gate arithmetic.  One workgroup per (sequence, direction), 3 Hh threads: thread j keeps column j of
-// W_hh (Hh floats) in registers for the whole scan, h lives in LDS and is read as broadcast float4s, gi of the NEXT step is loaded
-// before the current step's arithmetic.  Exact fp32 FMAs (no split products needed: the recurrence is latency-bound, ~1 us per step).
+// W_hh (Hh floats) in registers for the whole scan, h lives in LDS and is read as broadcast float4s, gi is loaded two steps
+// ahead of the arithmetic.  Exact fp32 FMAs (no split products needed: the recurrence is latency-bound, ~1 us per step).
 // torch gate order [r | z | n]:  r = sig(gi_r + gh_r), z = sig(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h.
 //
 // Backward walks the steps in reverse processing order with W_hh's ROWS split over the threads (thread (k, part) holds
@@ -22,6 +22,8 @@
 #include "bl_common.h"
 
 namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int HH>
 __global__ __launch_bounds__(3 * HH) void gru_scan_fwd_kernel(const float* __restrict__ gi, int ld_gi, const float* __restrict__ w_hh,
@@ -47,20 +49,24 @@ __global__ __launch_bounds__(3 * HH) void gru_scan_fwd_kernel(const float* __res
   if (j < HH) hs[j] = 0.f;
   __syncthreads();
   const float* gcol = gi + (size_t)dir * 3 * HH + j;
+  // gi two steps ahead (a step is ~0.6 us: less than a round trip to HBM)
   float g_next = len > 0 ? gcol[(row0 + (dir ? len - 1 : 0)) * ld_gi] : 0.f;
+  float g_next2 = len > 1 ? gcol[(row0 + (dir ? len - 2 : 1)) * ld_gi] : 0.f;
   for (int s = 0; s < len; ++s) {
     const int t = dir ? len - 1 - s : s;
     const float g = g_next;
-    if (s + 1 < len) g_next = gcol[(row0 + (dir ? t - 1 : t + 1)) * ld_gi];
-    float acc = bias;
+    g_next = g_next2;
+    if (s + 2 < len) g_next2 = gcol[(row0 + (dir ? t - 2 : t + 2)) * ld_gi];
+    // four independent chains (a step is latency: one chain of HH dependent FMAs would be most of it)
+    // (pairs: v_pk_fma_f32 retires two fp32 FMAs per lane and issue slot -- the 128 FMAs per thread are most of a step)
+    f32x2 p0 = {bias, 0.f}, p1 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < HH; k += 4) {
       const float4 h4 = *reinterpret_cast<const float4*>(&hs[k]);  // same address in every lane: an LDS broadcast
-      acc = fmaf(h4.x, w[k], acc);
-      acc = fmaf(h4.y, w[k + 1], acc);
-      acc = fmaf(h4.z, w[k + 2], acc);
-      acc = fmaf(h4.w, w[k + 3], acc);
+      p0 = __builtin_elementwise_fma(f32x2{h4.x, h4.y}, f32x2{w[k], w[k + 1]}, p0);
+      p1 = __builtin_elementwise_fma(f32x2{h4.z, h4.w}, f32x2{w[k + 2], w[k + 3]}, p1);
     }
+    const float acc = (p0.x + p0.y) + (p1.x + p1.y);
     if (gate < 2) {
       pre[j] = 1.f / (1.f + expf(-(g + acc)));
     } else {
@@ -108,14 +114,23 @@ __global__ __launch_bounds__(3 * HH) void gru_scan_bwd_kernel(const float* __res
   }
   if (j < HH) dhr[j] = 0.f;
   __syncthreads();
+  // this step's saved gates / incoming gradient are loaded one step ahead (a global round trip per step would be the step)
+  float nx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define GRU_BWD_LOAD(t_)                                                                         \
+  if (j < HH) {                                                                                  \
+    const float* sv_ = saved + ((size_t)dir * R + row0 + (t_)) * 4 * HH;                         \
+    nx[0] = sv_[u]; nx[1] = sv_[HH + u]; nx[2] = sv_[2 * HH + u]; nx[3] = sv_[3 * HH + u];       \
+    nx[4] = saved[(size_t)2 * R * 4 * HH + ((size_t)dir * R + row0 + (t_)) * HH + u];            \
+    nx[5] = g_out[(row0 + (t_)) * ld_g + dir * HH + u];                                          \
+  }
+  if (len > 0) GRU_BWD_LOAD(dir ? 0 : len - 1)
   for (int s = len - 1; s >= 0; --s) {
     const int t = dir ? len - 1 - s : s;
     float carry = 0.f;
+    const float r = nx[0], z = nx[1], n = nx[2], ghn = nx[3], hp = nx[4], go = nx[5];
+    if (s > 0) GRU_BWD_LOAD(dir ? len - s : s - 1)
     if (j < HH) {
-      const float* sv = saved + ((size_t)dir * R + row0 + t) * 4 * HH;
-      const float r = sv[u], z = sv[HH + u], n = sv[2 * HH + u], ghn = sv[3 * HH + u];
-      const float hp = saved[(size_t)2 * R * 4 * HH + ((size_t)dir * R + row0 + t) * HH + u];
-      const float dh = g_out[(row0 + t) * ld_g + dir * HH + u] + dhr[u];
+      const float dh = go + dhr[u];
       const float dnp = dh * (1.f - z) * (1.f - n * n);
       const float drp = dnp * ghn * r * (1.f - r);
       const float dzp = dh * (hp - n) * z * (1.f - z);
@@ -130,16 +145,14 @@ __global__ __launch_bounds__(3 * HH) void gru_scan_bwd_kernel(const float* __res
       carry = dh * z;
     }
     __syncthreads();
-    float acc = 0.f;
+    f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < HH; i += 4) {
       const float4 d4 = *reinterpret_cast<const float4*>(&dgh[part * HH + i]);
-      acc = fmaf(d4.x, w[i], acc);
-      acc = fmaf(d4.y, w[i + 1], acc);
-      acc = fmaf(d4.z, w[i + 2], acc);
-      acc = fmaf(d4.w, w[i + 3], acc);
+      p0 = __builtin_elementwise_fma(f32x2{d4.x, d4.y}, f32x2{w[i], w[i + 1]}, p0);
+      p1 = __builtin_elementwise_fma(f32x2{d4.z, d4.w}, f32x2{w[i + 2], w[i + 3]}, p1);
     }
-    ps[part][u] = acc;
+    ps[part][u] = (p0.x + p0.y) + (p1.x + p1.y);
     __syncthreads();
     if (j < HH) dhr[u] = ps[0][u] + ps[1][u] + ps[2][u] + carry;
     __syncthreads();
