@@ -108,3 +108,25 @@ def test_registry_passes_the_aggregation_function_to_the_layers(tmp_path):
         load_model({"modelName": "ggnn", "message_aggregation_function": "sum"}, Path(tmp_path / "g.pkl.gz"))
     with pytest.raises(ValueError):
         MlpMessagePassingLayer(64, 64, 64, 4, message_aggregation_function="median")
+
+
+@pytest.mark.parametrize("name", ["seq-transformer", "seq-gru"])
+def test_checkpoint_roundtrip_of_the_new_sequence_models(tmp_path, name):
+    """save / restore_model (reference AbstractNeuralModel.save / restore_model as train.py:96 and evaluate.py use them): the pickled
+    pair comes back with identical parameters and the same layer classes."""
+    from buglab.data.synthetic import make_buglab_seq_dataset
+    from buglab.models.modelregistry import load_model
+    from buglab.models.seqmodel import SeqBugLabModel
+
+    data = make_buglab_seq_dataset(4, seed=2)
+    model = load_model({"modelName": name, "hidden_state_size": 64, "num_layers": 2, "num_heads": 4, "intermediate_dimension_size": 96},
+                       Path(tmp_path / "m.pkl.gz"))[0]
+    model.compute_metadata(copy.deepcopy(data))
+    torch.manual_seed(3)
+    nn_ = model.build_neural_module()
+    model.save(tmp_path / "m.pkl.gz", nn_)
+    model2, nn2 = SeqBugLabModel.restore_model(tmp_path / "m.pkl.gz", torch.device("cpu"))
+    a, b = dict(nn_.named_parameters()), dict(nn2.named_parameters())
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    assert [type(m).__name__ for m in nn_.modules()] == [type(m).__name__ for m in nn2.modules()]
+    assert model2.tensorize(copy.deepcopy(data[0])) is not None
