@@ -10,7 +10,7 @@ bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.log 2>&1
 python bench.py --hidden 256 --graphs 32 --no-cpu-baseline --no-also > $O/${TAG}_bench_c3.json 2>/dev/null
 python bench.py --hidden 256 --graphs 32 --degree powerlaw --no-cpu-baseline --no-also > $O/${TAG}_bench_c4.json 2>/dev/null
 python bench.py --graphs 15 --no-cpu-baseline --no-also > $O/${TAG}_bench_30k.json 2>/dev/null
-bash tools/_run_seq_models.sh $TAG > $O/${TAG}_seq_models.log 2>&1
+bash tools/seq_models_run.sh $TAG > $O/${TAG}_seq_models.log 2>&1
 python bench.py --msg-gemm f16x1 --no-cpu-baseline --no-also > $O/${TAG}_bench_amp.json 2>/dev/null
 python bench.py --aggregation sum --no-cpu-baseline --no-also > $O/${TAG}_bench_sum.json 2>/dev/null
 python tools/gemm_bench.py --which fwd_x6,fwd_h3,nk_x6,nk_h3,wgrad_x6,wgrad_h3 --mixed 2 > $O/${TAG}_gemm_bench.log 2>&1
