@@ -131,6 +131,58 @@ def test_sum_and_mean_aggregation_hand_checked():
     assert O.OracleConfig().msg_aggregation == "max"
 
 
+def test_oracle_layers_equal_compositions_of_torch_modules():
+    """What CAN be pinned of M0 - M4 without ptgnn: the oracle's layers against the torch.nn modules ptgnn's layers are assembled from
+    (nn.Linear per edge type without bias, nn.GELU, nn.LayerNorm, nn.Linear, nn.Tanh for the MLP layer; nn.GRUCell for the gated one;
+    nn.Embedding for the embedder), composed in the frozen spec's order, with torch.scatter_reduce as the aggregation: values and
+    gradients agree to rounding.  This pins the ARITHMETIC of every piece to torch's own modules; the ORDER of the pieces is the
+    written spec and stays unpinned."""
+    torch.manual_seed(0)
+    N, E, T, Din, Dm, Dout = 23, 90, 3, 8, 12, 8
+    rng = np.random.default_rng(0)
+    type_ptr = np.array([0, 40, 40, 90])  # (an empty type)
+    src, tgt = rng.integers(0, N, E), rng.integers(0, N - 3, E)  # (the last three nodes receive nothing)
+    h = torch.randn(N, Din, dtype=torch.float64, requires_grad=True)
+    lin = [torch.nn.Linear(2 * Din, Dm, bias=False).double() for _ in range(T)]
+    ln, dense = torch.nn.LayerNorm(Dm).double(), torch.nn.Linear(Dm, Dout).double()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.3, 0.3)
+    for agg_name, reduce in (("max", "amax"), ("sum", "sum"), ("mean", "mean")):
+        # --- torch.nn composition
+        msgs = torch.cat([lin[t](torch.cat([h[src[type_ptr[t]:type_ptr[t + 1]]], h[tgt[type_ptr[t]:type_ptr[t + 1]]]], dim=-1)) for t in range(T)])
+        idx = torch.as_tensor(tgt).view(E, 1).expand(E, Dm)
+        agg = torch.zeros(N, Dm, dtype=torch.float64).scatter_reduce(0, idx, msgs, reduce=reduce, include_self=False)
+        want = torch.tanh(dense(ln(torch.nn.functional.gelu(agg))))
+        gw = torch.autograd.grad(want.square().sum(), [h] + [l.weight for l in lin] + [ln.weight, ln.bias, dense.weight, dense.bias])
+        # --- oracle
+        W = torch.stack([l.weight.t() for l in lin]).detach().requires_grad_(True)
+        p = [t.detach().clone().requires_grad_(True) for t in (h, ln.weight, ln.bias, dense.weight.t(), dense.bias)]
+        got = O.mp_layer(p[0], W, p[1], p[2], p[3], p[4], src, tgt, type_ptr, "gelu", 0.0, None, 1, aggregation=agg_name)
+        go = torch.autograd.grad(got.square().sum(), [p[0], W, p[1], p[2], p[3], p[4]])
+        assert float((got - want).abs().max()) < 1e-12, agg_name
+        assert float((go[0] - gw[0]).abs().max()) < 1e-10
+        for t in range(T):
+            assert float((go[1][t] - gw[1 + t].t()).abs().max()) < 1e-10
+        assert float((go[2] - gw[1 + T]).abs().max()) < 1e-10 and float((go[3] - gw[2 + T]).abs().max()) < 1e-10
+        assert float((go[4] - gw[3 + T].t()).abs().max()) < 1e-10 and float((go[5] - gw[4 + T]).abs().max()) < 1e-10
+    # --- gated layer: nn.GRUCell(input = aggregate, hidden = h)
+    D = 8
+    cell = torch.nn.GRUCell(Dm, D).double()
+    Wg = torch.randn(T, D, Dm, dtype=torch.float64)
+    hh = torch.randn(N, D, dtype=torch.float64)
+    m = torch.cat([hh[src[type_ptr[t]:type_ptr[t + 1]]] @ Wg[t] for t in range(T)])
+    agg = torch.zeros(N, Dm, dtype=torch.float64).scatter_reduce(0, torch.as_tensor(tgt).view(E, 1).expand(E, Dm), m, reduce="amax", include_self=False)
+    want = cell(agg, hh)
+    got = O.gated_mp_layer(hh, Wg, cell.weight_ih.t(), cell.bias_ih, cell.weight_hh.t(), cell.bias_hh, src, tgt, type_ptr, 0.0, None, 1)
+    assert float((got - want).abs().max()) < 1e-12
+    # --- embedder: nn.Embedding rows, max over the real subtokens
+    emb = torch.nn.Embedding(50, 6).double()
+    ids, lens = rng.integers(0, 50, (N, 4)), rng.integers(1, 5, N)
+    e = emb(torch.as_tensor(ids)).masked_fill(torch.arange(4)[None, :, None] >= torch.as_tensor(lens)[:, None, None], -math.inf)
+    assert torch.equal(O.embed_nodes(emb.weight, ids, lens, 0.0, None), e.max(dim=1).values)
+
+
 def test_embedder_dropout_placement_hand_checked():
     """Dropout of the subtoken embedder before or after the max over subtokens (oracle.embed_nodes): with every subtoken of a node
     kept the two placements give the same values; a dropped winner lets another subtoken (or the 0 of a dropped one) win only
