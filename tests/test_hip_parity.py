@@ -157,7 +157,8 @@ def _check_tie_aware(cfg, mb_np, seed=None, tie_eps=1e-5, max_flip_frac=2e-3):
     params = O.init_params(cfg, seed=0)
     p64 = {k: v.double() for k, v in params.items()}
     trace = []
-    out, _ = O.forward_backward(p64, mb_np, cfg, seed=seed, trace=trace)
+    with torch.no_grad():  # (values and winner tables only: the gradients come from the second pass, with the HIP routing injected)
+        out = O.forward_loss(p64, mb_np, cfg, seed=seed, trace=trace)
     layers = [t for t in trace if "arg" in t]
     module = Hh.build_module_like(cfg, params)
     module.train(True)
@@ -244,10 +245,11 @@ def test_baseline_graph_size_matches_fp64_oracle(H, degree, B, placement):
     tables equal up to near-ties, every gradient within 1e-4 (routing injected)."""
     if B >= 64 and (os.cpu_count() or 1) < 64:
         pytest.skip("the fp64 oracle of the full 64-graph minibatch needs a many-core host (3 minutes on the 256-thread GPU boxes)")
-    if B >= 64 and placement != "aggregated" and os.environ.get("BL_FULL_PARITY", "0") == "0":
-        # (the full minibatch under the NON-default placement costs another 3 minutes of fp64 oracle: run with BL_FULL_PARITY=1;
-        # green at the final tree of round 6, profiles/r06y_gputest.log: 153 passed with it)
-        pytest.skip("full 64-graph minibatch under the non-default activation placement: set BL_FULL_PARITY=1 (3 more minutes of fp64 oracle)")
+    if placement != "aggregated" and (B >= 8 or (H, degree) == (256, "uniform")) and os.environ.get("BL_FULL_PARITY", "0") == "0":
+        # (the NON-default placement runs the 2-graph cases at hidden 128 and at hidden 256 with power-law hubs by default; its 8- and
+        # 64-graph minibatches and the uniform hidden-256 case cost another 4 minutes of fp64 oracle: BL_FULL_PARITY=1, as
+        # tools/final_run.sh does; green at the final trees of round 6, profiles/r06*_gputest.log)
+        pytest.skip("larger minibatches under the non-default activation placement: set BL_FULL_PARITY=1 (4 more minutes of fp64 oracle)")
     cfg, _, mb = Hh.make_case(B=B, n=2000, E=10000, T=16, H=H, layers=8, vocab=15000, C=40, degree=degree, max_degree=512, seed=21,
                               msg_act_placement=placement)
     if degree == "powerlaw":
