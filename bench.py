@@ -119,6 +119,32 @@ def message_gemm_bytes_per_step(H, layers, N, E, T, packed_bytes_per_elem):
     return out
 
 
+def dataflow_bytes_per_step(H, layers, N, E, T, packed_bytes_per_elem, vocab=15000):
+    """Algorithmic bytes of ONE TRAINING STEP of the gnn-mlp stack as the dataflow is built: every launch's
+    operands read once and its results written once, summed over the launches of a layer's forward and backward call and over the
+    layers, plus the optimiser.  Unlike SURVEY 8d's compulsory bytes (a layer's inputs, outputs and parameters only: the figure a
+    perfectly fused layer would move) this counts the E-sized fp32 intermediates the gather -> GEMM -> segmented-reduce formulation
+    materialises -- [E, Dm] messages, [E, 2 Din] input-gradient rows -- and the packed operand copies; it does NOT count re-reads
+    (a gathered row fetched once per message that uses it), which is what `roofline.traffic` measures.  Embedder and heads
+    (< 1 % of the bytes) are left out.  -> (total, {kind: bytes})"""
+    pk, d3 = packed_bytes_per_elem, 6.0  # message operands: f16x2 = 4 / bf16x3 = 6 bytes per element; dense node update: bf16x3
+    msg = message_gemm_bytes_per_step(H, layers, N, E, T, pk)
+    kinds = {"msg_gemm": msg["fwd"], "msg_dgrad": msg["dgrad"], "msg_wgrad": msg["wgrad"], "pack_rows": 0.0, "segment_max_ln": 0.0,
+             "dense_fwd": 0.0, "node_update_bwd": 0.0, "dense_wgrad": 0.0, "node_grad_sums": 0.0}
+    theta = vocab * H
+    for li in range(layers):
+        din, dm, dout = (2 * H, 2 * H, H) if li % 4 == 3 else (H, H, H)
+        theta += T * 2 * din * dm + dm * dout + 2 * dm + dout
+        kinds["pack_rows"] += (4.0 + pk) * N * din + (4.0 + pk) * N * dm          # layer input (forward), node gradient gq (backward)
+        kinds["segment_max_ln"] += 4.0 * E * dm + 4.0 * N + (4.0 + 4.0 + d3) * N * dm + E * dm / 8.0 + 8.0 * N  # messages, CSR; aggregate, act', LN out (packed), routing bits, mean / rstd
+        kinds["dense_fwd"] += d3 * N * dm + d3 * dm * dout + 4.0 * N * dout
+        kinds["node_update_bwd"] += 2 * 4.0 * N * dout + 2 * 4.0 * N * dm + 8.0 * N + d3 * N * dout + 4.0 * N * dm  # g_out, h_out, aggregate, act', stats -> g_z (packed), gq
+        kinds["dense_wgrad"] += d3 * N * (dm + dout) + 4.0 * dm * dout
+        kinds["node_grad_sums"] += 4.0 * E * 2 * din + 8.0 * E + 8.0 * N + 4.0 * N * din
+    kinds["adam_clip"] = (4.0 + 4.0 + 16.0 + 12.0) * theta  # zero fill, norm, read p / g / m / v, write p / m / v
+    return sum(kinds.values()), kinds
+
+
 def attach_message_gemm_bytes(kern, a, prof_steps):
     """gives the message-GEMM kinds of a profile table their algorithmic bytes, so that build_roofline can price them against BOTH
     ceilings and report the one that binds (with f16x3 the routed input gradient -- 57 FLOP/B -- is below the 104 FLOP/B ridge)"""
@@ -133,7 +159,8 @@ def attach_message_gemm_bytes(kern, a, prof_steps):
     return kern
 
 
-def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, fwd_flop, fwd_bytes, brief=False):
+def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, fwd_flop, fwd_bytes, brief=False, dataflow=None,
+                   graphs_per_step=0):
     """The `roofline` object of a bench line from the HIP-event tables of the profiling passes (hip_ops.KernelTimer).
     Dominant kernel = largest EXCLUSIVE time per step among the MFMA GEMM kinds of the serial pass (msg_dgrad_nodes runs
     on the vector units / LDS: listed with its non-zero FLOP rate, not a candidate; seq-great's attention kernels stream
@@ -187,6 +214,10 @@ def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, 
         "step_frac_of_mfma_x6_roofline": round(per_gpu_rate * 3 * fwd_flop / (MFMA_X6_PEAK_TFLOPS * 1e12), 4),
         "step_frac_of_mfma_h3_roofline": round(per_gpu_rate * 3 * fwd_flop / (MFMA_H3_PEAK_TFLOPS * 1e12), 4),
     }
+    if dataflow is not None and graphs_per_step > 0:
+        # whole step against the HBM ceiling by the bytes its dataflow moves (dataflow_bytes_per_step): steps per second x bytes per step
+        roof["step_dataflow_gb"] = round(dataflow[0] / 1e9, 2)
+        roof["step_frac_of_hbm_roofline_dataflow_bytes"] = round(per_gpu_rate / graphs_per_step * dataflow[0] / (HBM_PEAK_GBS * 1e9), 4)
     mfma_busy = measured_mfma_busy(dom)
     if mfma_busy is not None:
         roof["mfma_busy_frac"], roof["mfma_busy_source"] = mfma_busy
@@ -204,6 +235,8 @@ def build_roofline(kern, kern_overlap, prof_steps, serial_step_s, per_gpu_rate, 
         "step_frac_of_mfma_f32_roofline": round(per_gpu_rate * 3 * fwd_flop / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),
         "step_frac_of_hbm_roofline_compulsory_bytes": round(per_gpu_rate * 3 * fwd_bytes / (HBM_PEAK_GBS * 1e9), 4),
     })
+    if dataflow is not None:
+        roof["step_dataflow_gb_by_kind"] = {k: round(v / 1e9, 2) for k, v in sorted(dataflow[1].items(), key=lambda kv: -kv[1])}
     return roof
 
 
@@ -224,9 +257,14 @@ def calibrate_rooflines(box, roof, also, per_gpu_rate):
         else:
             return
         r["frac_calibrated"] = round(r["achieved"] / r["peak_calibrated"], 4)
+    def step(r):
+        if r and "step_frac_of_hbm_roofline_dataflow_bytes" in r:
+            r["step_frac_of_hbm_calibrated_dataflow_bytes"] = round(r["step_frac_of_hbm_roofline_dataflow_bytes"] * HBM_PEAK_GBS / (1e3 * box["hbm_calib_tbs"]), 4)
     one(roof)
+    step(roof)
     for entry in (also or {}).values():
         one(entry.get("roofline"))
+        step(entry.get("roofline"))
     box["value_per_calibrated_pflops"] = round(per_gpu_rate / (box["mfma_calib_tflops"] / 1e3), 1)
     # the headline at a reference step clock: the step's kernels follow the shader clock with an exponent of ~0.4 (round 5 measured
     # 7.6 % more clock -> 2.9 % less GEMM time, profiles/r05x_mixed_clock.log; four boxes of round 6 with a 2.4 % raw spread agree to
@@ -523,6 +561,13 @@ def main():
                     a.layers * (3 * 4.0 * Ls * Dh) + 4.0 * n_par / a.graphs)
         return algorithmic_work_per_graph(a.hidden, a.layers, a.nodes, a.messages, a.types, a.graphs)
 
+    def dataflow_of(a):
+        """bytes one training step of configuration `a` moves as the dataflow is built (gnn-mlp with the max aggregation and an
+        fp32-accurate split of the message GEMMs; None otherwise)"""
+        if a.model != "gnn-mlp" or a.aggregation != "max" or a.msg_gemm not in ("f16x3", "bf16x6"):
+            return None
+        return dataflow_bytes_per_step(a.hidden, a.layers, a.nodes * a.graphs, a.messages * a.graphs, a.types, 4.0 if a.msg_gemm == "f16x3" else 6.0)
+
     def side_config(**over):
         """One more BASELINE configuration, timed the same way (warm-up, barrier + synchronize on both sides, max over
         ranks) AFTER the headline run, on its own model and minibatch: reported under `also`, never as `value`."""
@@ -550,7 +595,7 @@ def main():
         return {"value": round(rate_, 2), "unit": unit, "ms_per_step": round(1e3 * el_ / args.steps, 3),
                 "per_gpu": a.graphs, "n_gpus": world,
                 "roofline": build_roofline(attach_message_gemm_bytes(kern_, a, prof_steps), {}, prof_steps, serial_s_, rate_ / world, *fwd_work(a),
-                                           brief=True)}
+                                           brief=True, dataflow=dataflow_of(a), graphs_per_step=a.graphs)}
 
     if not args.default_stream:
         hip_ops.use_step_stream(device)  # what ModelTrainer.train does before its first step
@@ -668,7 +713,7 @@ def main():
         fwd_flop, fwd_bytes = fwd_work(args)
         value = total_graphs / elapsed
         roof = build_roofline(attach_message_gemm_bytes(kern, args, prof_steps), kern_overlap, prof_steps, serial_step_s, value / world,
-                              fwd_flop, fwd_bytes)
+                              fwd_flop, fwd_bytes, dataflow=dataflow_of(args), graphs_per_step=args.graphs)
         if box is not None:
             calibrate_rooflines(box, roof, also, value / world)
         line = {
