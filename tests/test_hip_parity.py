@@ -241,15 +241,13 @@ def test_baseline_graph_size_matches_fp64_oracle(H, degree, B, placement):
     2-graph minibatch (what bench.py's cpu_baseline leg runs) and, at the headline configuration's width, on an 8-graph
     one (16 000 nodes / 80 000 messages: several tiles per edge type in every GEMM, 250 tiles in the node kernels) and on the
     FULL 64-graph minibatch of BASELINE configs[1] -- the bench's workload, 128 000 nodes / 640 000 messages (the fp64 oracle
-    takes ~3 minutes of host time for it): loss, log-probabilities and node states within 1e-4 of the fp64 oracle, winner
+    takes about a minute of host time for it): loss, log-probabilities and node states within 1e-4 of the fp64 oracle, winner
     tables equal up to near-ties, every gradient within 1e-4 (routing injected)."""
     if B >= 64 and (os.cpu_count() or 1) < 64:
-        pytest.skip("the fp64 oracle of the full 64-graph minibatch needs a many-core host (3 minutes on the 256-thread GPU boxes)")
-    if placement != "aggregated" and (B >= 8 or (H, degree) == (256, "uniform")) and os.environ.get("BL_FULL_PARITY", "0") == "0":
-        # (the NON-default placement runs the 2-graph cases at hidden 128 and at hidden 256 with power-law hubs by default; its 8- and
-        # 64-graph minibatches and the uniform hidden-256 case cost another 4 minutes of fp64 oracle: BL_FULL_PARITY=1, as
-        # tools/final_run.sh does; green at the final trees of round 6, profiles/r06*_gputest.log)
-        pytest.skip("larger minibatches under the non-default activation placement: set BL_FULL_PARITY=1 (4 more minutes of fp64 oracle)")
+        pytest.skip("the fp64 oracle of the full 64-graph minibatch needs a many-core host (a minute at 16 threads on the GPU boxes)")
+    # (every case under BOTH placements by default: with the oracle at 16 host threads -- tests/conftest.py -- the two full minibatches
+    # cost 50 - 70 s each and the whole GPU suite 3.5 minutes, profiles/r06zzd_gputest.log; until then the non-default placement's
+    # full minibatch sat behind BL_FULL_PARITY=1)
     cfg, _, mb = Hh.make_case(B=B, n=2000, E=10000, T=16, H=H, layers=8, vocab=15000, C=40, degree=degree, max_degree=512, seed=21,
                               msg_act_placement=placement)
     if degree == "powerlaw":

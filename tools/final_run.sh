@@ -18,6 +18,6 @@ python tools/gemm_bench.py --which fwd_x6w,fwd_h3,nk_x6w,nk_h3,wgrad_x6,wgrad_h3
 python tools/hbm_bench.py > $O/${TAG}_hbm_bench.log 2>&1
 timeout 600 python tools/dp_check.py --ranks 8 > $O/${TAG}_dp_check_8ranks_1gpu.log 2>&1; grep -c "step" $O/${TAG}_dp_check_8ranks_1gpu.log
 timeout 600 python tools/e2e_train_bench.py --graphs 8192 --nodes 1300 --shards 128 --workers 32 --epochs 3 --real-validation 8 > $O/${TAG}_e2e_train_bench.log 2>&1; tail -3 $O/${TAG}_e2e_train_bench.log
-BL_FULL_PARITY=1 timeout 2400 python -m pytest tests -x -q -m gpu > $O/${TAG}_gputest.log 2>&1; tail -2 $O/${TAG}_gputest.log
+timeout 2400 python -m pytest tests -x -q -m gpu --durations=10 > $O/${TAG}_gputest.log 2>&1; tail -2 $O/${TAG}_gputest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -2 $O/${TAG}_smoke.log
 ls $O | grep $TAG | wc -l
