@@ -235,7 +235,8 @@ def test_c3_c4_shapes_hidden_256_match_oracle(placement):
 
 
 @pytest.mark.parametrize("placement", PLACEMENTS)
-@pytest.mark.parametrize("H,degree,B", [(128, "uniform", 2), (256, "uniform", 2), (256, "powerlaw", 2), (128, "uniform", 8), (128, "uniform", 64)])
+@pytest.mark.parametrize("H,degree,B", [(128, "uniform", 2), (256, "uniform", 2), (256, "powerlaw", 2), (128, "uniform", 8), (128, "uniform", 64),
+                                        (256, "powerlaw", 32)])
 def test_baseline_graph_size_matches_fp64_oracle(H, degree, B, placement):
     """The BASELINE per-graph size -- 2000 nodes / 10000 messages per graph, 8 layers, 16 edge types -- on a
     2-graph minibatch (what bench.py's cpu_baseline leg runs) and, at the headline configuration's width, on an 8-graph
@@ -243,8 +244,17 @@ def test_baseline_graph_size_matches_fp64_oracle(H, degree, B, placement):
     FULL 64-graph minibatch of BASELINE configs[1] -- the bench's workload, 128 000 nodes / 640 000 messages (the fp64 oracle
     takes about a minute of host time for it): loss, log-probabilities and node states within 1e-4 of the fp64 oracle, winner
     tables equal up to near-ties, every gradient within 1e-4 (routing injected)."""
-    if B >= 64 and (os.cpu_count() or 1) < 64:
+    if B >= 32 and (os.cpu_count() or 1) < 64:
         pytest.skip("the fp64 oracle of the full 64-graph minibatch needs a many-core host (a minute at 16 threads on the GPU boxes)")
+    if (H, B) == (256, 32):
+        # BASELINE configs[2]'s per-GPU shard with configs[3]'s degree distribution at FULL size (64 000 nodes / 320 000 messages, hidden
+        # 256, hubs of degree 512 in every graph): the default placement only, and only where the fp64 oracle's activations fit the host
+        import psutil
+
+        if placement != "aggregated":
+            pytest.skip("the full hidden-256 shard runs under the default placement (the other one is covered at 2 graphs)")
+        if psutil.virtual_memory().available < 96 * 2**30:
+            pytest.skip("the fp64 oracle of the full hidden-256 shard keeps tens of GB of activations: needs a large host")
     # (every case under BOTH placements by default: with the oracle at 16 host threads -- tests/conftest.py -- the two full minibatches
     # cost 50 - 70 s each and the whole GPU suite 3.5 minutes, profiles/r06zzd_gputest.log; until then the non-default placement's
     # full minibatch sat behind BL_FULL_PARITY=1)
