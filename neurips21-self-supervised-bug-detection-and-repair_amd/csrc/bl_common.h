@@ -144,6 +144,17 @@ __device__ __forceinline__ float bl_act_grad_from_out(int act, float y) {
   }
 }
 
+// ---- streaming accesses -------------------------------------------------------------------------------
+// Results that are written once and read by a LATER kernel, and are far larger than the 32 MB of L2 (the [E, Dm] / [E, 2 Din] fp32 rows of
+// the message GEMMs: 328 / 655 MB per launch), leave with the `nt` hint: as plain stores they are allocated in the XCD's L2 like
+// anything else and push out the operand rows the kernel gathers.  Measured on the routed input-gradient GEMM at the c2 layer
+// shape: 0.263 -> 0.211 ms per launch, and the segmented sums that read the rows next 0.157 -> 0.148 ms; c2 step 13.40 -> 12.85 ms
+// (tools/experiments/nt_probe.sh, profiles/r06zze_nt_probe.log).
+typedef float bl_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bl_store_streaming(float* p, const float4& v) {
+  __builtin_nontemporal_store(__builtin_bit_cast(bl_f32x4, v), reinterpret_cast<bl_f32x4*>(p));
+}
+
 // ---- wave-level reductions (64 lanes) -----------------------------------------------------------
 __device__ __forceinline__ float bl_wave_sum(float v) {
 #pragma unroll

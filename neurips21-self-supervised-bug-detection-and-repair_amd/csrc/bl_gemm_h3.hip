@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_rows_h3_kernel(
       const int r = (lane >> 4) + 4 * j;
       const int mm = wm * 64 + ti * 32 + r;
       const float4 v = *reinterpret_cast<const float4*>(stage + r * 68 + 4 * c4);
-      if (mm < nrows && n < N) *reinterpret_cast<float4*>(c + (size_t)(row0 + mm) * ldc + n) = v;
+      if (mm < nrows && n < N) bl_store_streaming(c + (size_t)(row0 + mm) * ldc + n, v);
     }
   }
 }
