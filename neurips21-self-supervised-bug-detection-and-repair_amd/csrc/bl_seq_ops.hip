@@ -482,7 +482,7 @@ __global__ __launch_bounds__(1024) void attn_probs_fwd_kernel(const HeadView q, 
         const int key = 256 * c + 4 * lane;
         if (key < L) {  // (L % 4 == 0)
           float4 pr = make_float4(s[r][4 * c] * inv, s[r][4 * c + 1] * inv, s[r][4 * c + 2] * inv, s[r][4 * c + 3] * inv);
-          *reinterpret_cast<float4*>(P + row * L + key) = pr;
+          bl_store_streaming(P + row * L + key, pr);  // (268 MB per layer that only the products after this kernel read: bl_common.h)
           if (Pd) {
             const uint32_t e0 = (uint32_t)row * (uint32_t)L + (uint32_t)key;
             pr.x = bl_keep(drop, e0) ? pr.x * drop.scale : 0.f;
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(1024) void attn_probs_bwd_kernel(const HeadView g_c
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         const int key = 256 * c + 4 * lane;
-        if (key < L) *reinterpret_cast<float4*>(dS + row * L + key) = make_float4(s[r][4 * c], s[r][4 * c + 1], s[r][4 * c + 2], s[r][4 * c + 3]);
+        if (key < L) bl_store_streaming(dS + row * L + key, make_float4(s[r][4 * c], s[r][4 * c + 1], s[r][4 * c + 2], s[r][4 * c + 3]));
       }
       if (ecnt[r] > 0) {
         any_edges = true;
