@@ -2,7 +2,7 @@
 # When should a layer's routed weight gradient (side stream) start?  Product: together with the routed input gradient (both fork after the
 # gradient operand is packed: two matrix-core kernels side by side).  Variants: after the input gradient has been LAUNCHED (next to the
 # segmented sums and the next layer's node-update backward: bandwidth-bound neighbours), or after the sums.
-# The variant sources are generated from csrc/bl_mp_layer.hip by the python snippets in this round's log (block moves only).
+# The variant sources are generated from csrc/bl_mp_layer.hip by tools/experiments/fork_variants.py (block moves only).
 #   GPU box: bash tools/experiments/fork_probe.sh run > gpurun_out/r06zzn_fork_probe.log 2>&1
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd)
@@ -10,6 +10,7 @@ C=$R/neurips21-self-supervised-bug-detection-and-repair_amd/csrc
 B=$R/tools/experiments/build
 if [ "$1" = build ]; then
   (cd $C && make -s)
+  python3 $R/tools/experiments/fork_variants.py
   for v in forkafter_dgrad forkafter_sums; do
     mkdir -p $B/fp && cp $B/bl_mp_layer_$v.hip $B/fp/bl_mp_layer.hip
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$C -I$R/include -c $B/fp/bl_mp_layer.hip -o $B/fp/m.o
