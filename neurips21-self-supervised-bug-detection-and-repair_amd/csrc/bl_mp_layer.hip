@@ -472,7 +472,14 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
     if (!fused_node) BL_TRY(bl_amax(B.g_ln, (int64_t)N * Dm, B.amax, st));  // (the fused node-update backward took it on the way)
     BL_TRY(bl_pack_f16x2(B.g_ln, Dm, N, Dm, Dm, 0, 1.0f, B.amax, B.gqp, st));
   }
-  if (E > 0) {
+  // The routed weight gradient (side stream) reads what is ready at this point: the packed layer input, the packed gradient operand, the
+  // routing bits.  WHEN it is forked decides what it runs next to.  Layers up to 128 wide: here, side by side with the routed input
+  // gradient.  Wider layers (the hidden-256 configurations): behind the segmented sums, i.e. next to the bandwidth-bound tail of this layer
+  // and the head of the next one -- measured on one box, two interleaved pairs (tools/experiments/fork_probe.sh,
+  // profiles/r06zzn_fork_probe.log): c3 shard 1 664 / 1 660 -> 1 684 / 1 692 graphs/s with the late fork, c2 4 917 / 4 942 -> 4 904 / 4 911
+  // (and 4 768 / 4 774 when forked between the input gradient and the sums).
+  const bool late_fork = two && Dout >= 256;
+  auto launch_wgrad = [&]() -> int {
     bl_rows_packed_t a;
     a.xp[0] = S.hp; a.xp[1] = S.hp; a.xp[2] = nullptr;
     a.idx[0] = L->msg_src; a.idx[1] = L->msg_tgt; a.idx[2] = nullptr;
@@ -494,6 +501,10 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
       else
         BL_TRY(bl_gemm_wgrad_x6(&a, B.gqp, L->msg_tgt, L->type_ptr, nullptr, T, E, Dm, 2 * Din, g_W, (int64_t)2 * Din * Dm, Dm, side));
     }
+    return BL_OK;
+  };
+  if (E > 0) {
+    if (!late_fork) BL_TRY(launch_wgrad());
     bl_rows_packed_t g;
     g.xp[0] = B.gqp; g.xp[1] = g.xp[2] = nullptr; g.idx[0] = L->msg_tgt; g.idx[1] = g.idx[2] = nullptr;
     g.width[0] = Dm; g.width[1] = g.width[2] = 0; g.nsrc = 1;
@@ -538,6 +549,7 @@ extern "C" int bl_mp_layer_bwd(const bl_mp_layer_t* L, const float* h_out, const
     BL_TRY(bl_mp_scatter_grad_hubs_impl(B.g_a, 2 * Din, L->src_ptr, L->src_msgs, L->tgt_ptr, L->tgt_msgs, N, Din, width_lo, g_h_lo, ld_lo,
                                         g_h_hi, ld_hi, node_order, L->num_hub_slots, st));
   }
+  if (E > 0 && late_fork) BL_TRY(launch_wgrad());
   if (two && join_side) {
     (void)hipEventRecord(ev->join, side);
     (void)hipStreamWaitEvent(st, ev->join, 0);

@@ -4,7 +4,10 @@ input gradient's launch (forkafter_dgrad) or behind the segmented sums (forkafte
 import os
 
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src = open(os.path.join(R, "neurips21-self-supervised-bug-detection-and-repair_amd/csrc/bl_mp_layer.hip")).read()
+import subprocess
+
+# (the source as it was when the probe ran: the product has since taken the late fork for layers 256 wide and up, as a run-time choice)
+src = subprocess.check_output(["git", "-C", R, "show", "57ba164:neurips21-self-supervised-bug-detection-and-repair_amd/csrc/bl_mp_layer.hip"], text=True)
 B = os.path.join(R, "tools/experiments/build")
 os.makedirs(B, exist_ok=True)
 fork = """    if (two) {
