@@ -103,3 +103,26 @@ def test_roofline_reports_the_ceiling_that_binds():
     del kern["msg_dgrad_h3"]
     r2 = bench.build_roofline(kern, {}, 1, 0.014, 4800.0, 9.83e9, 19.5e6, brief=True)
     assert r2["kernel"] == "msg_wgrad_h3" and r2["bound"] == "mfma" and r2["peak"] == round(bench.MFMA_H3_PEAK_TFLOPS, 1)
+
+
+def test_dataflow_bytes_of_a_step_add_up():
+    """bench.py's whole-step HBM view (`step_frac_of_hbm_roofline_dataflow_bytes`): the bytes a training step's dataflow moves are the sum of
+    its kinds, the three message-GEMM kinds are message_gemm_bytes_per_step's, the two E-sized fp32 intermediates are counted written AND
+    read, and the figure at BASELINE configs[1] is the 35.9 GB DESIGN.md section 5 quotes."""
+    import bench
+
+    H, layers, N, E, T = 128, 8, 64 * 2000, 64 * 10000, 16
+    total, kinds = bench.dataflow_bytes_per_step(H, layers, N, E, T, 4.0)
+    assert abs(total - sum(kinds.values())) < 1.0
+    msg = bench.message_gemm_bytes_per_step(H, layers, N, E, T, 4.0)
+    assert kinds["msg_gemm"] == msg["fwd"] and kinds["msg_dgrad"] == msg["dgrad"] and kinds["msg_wgrad"] == msg["wgrad"]
+    assert 35.5e9 < total < 36.2e9
+    # [E, Dm] messages: written by the forward GEMM, read by the segmented max; [E, 2 Din] input-gradient rows: written by the routed
+    # GEMM, read by the segmented sums (six layers (H, H), two (2H, 2H))
+    messages = sum(4.0 * E * (2 * H if li % 4 == 3 else H) for li in range(layers))
+    rows = sum(4.0 * E * 2 * (2 * H if li % 4 == 3 else H) for li in range(layers))
+    assert kinds["msg_gemm"] > messages and kinds["segment_max_ln"] > messages
+    assert kinds["msg_dgrad"] > rows and kinds["node_grad_sums"] > rows
+    # the bf16x6 split packs 6 instead of 4 bytes per operand element: more bytes, same structure
+    total6, _ = bench.dataflow_bytes_per_step(H, layers, N, E, T, 6.0)
+    assert total < total6 < 1.1 * total
