@@ -1,8 +1,15 @@
 #!/bin/bash
 # The loss kernels with / without the up-front touch of the descriptor's index arrays (csrc/bl_loss.hip::warm_index_arrays): kernel times from
 # rocprofv3 --kernel-trace --stats of short bench runs at 64 and 15 graphs; `lossold` = the library with the previous bl_loss.hip.
-#   GPU box: bash tools/experiments/loss_touch.sh > gpurun_out/r06zzq_loss_touch.log 2>&1
+#   build here: bash tools/experiments/loss_touch.sh build ; GPU box: bash tools/experiments/loss_touch.sh > gpurun_out/r06zzq_loss_touch.log 2>&1
 R=$(pwd)
+if [ "$1" = build ]; then  # the library with bl_loss.hip as it was before commit 7cf7a0d
+  C=$R/neurips21-self-supervised-bug-detection-and-repair_amd/csrc; B=$R/tools/experiments/build; mkdir -p $B/t
+  (cd $C && make -s) && git -C $R show 7cf7a0d^:neurips21-self-supervised-bug-detection-and-repair_amd/csrc/bl_loss.hip > $B/t/bl_loss.hip
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$C -I$R/include -c $B/t/bl_loss.hip -o $B/t/l.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v /bl_loss.o) $B/t/l.o -o $B/libbuglab_hip_lossold.so
+  rm -rf $B/t; exit 0
+fi
 cd /tmp && export TMPDIR=/tmp
 for v in product lossold product lossold; do
   if [ $v = product ]; then unset BL_HIP_LIB; else export BL_HIP_LIB=$R/tools/experiments/build/libbuglab_hip_$v.so; fi
